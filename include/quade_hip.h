@@ -1,0 +1,197 @@
+/*
+ * quade_hip.h -- C ABI of the MI355X (gfx950) demultiplexing library, libquade_hip.so.
+ *
+ * Drop-in boundary for the per-read hot path of a-slide/Quade 0.3.2.  The reference has no FFI:
+ * its seam is one Python classmethod call per read pair.  Each entry point below names the
+ * reference interface it replaces (file:line under /root/reference).  The library is
+ * batch-granular: one call processes n read pairs whose index reads were packed into
+ * fixed-stride rows (layout: qd_layout).
+ *
+ * Conventions
+ *   - plain C types only; every function returns QD_OK (0) or a negative QD_ERR_* code;
+ *     qd_last_error() gives the text.  No exceptions or callbacks cross the boundary.
+ *   - a qd_ctx is bound to one HIP device and must be driven by one thread at a time;
+ *     different contexts may be driven concurrently from different threads.
+ *   - there is NO CPU fallback: qd_create() fails with QD_ERR_NO_DEVICE when no gfx950 device is
+ *     usable.  The host-only helpers (qd_plan_layout, qd_pack_*, qd_fastq_*, qd_route_*,
+ *     qd_version, qd_strerror) never touch the GPU.
+ *
+ * Routing code (uint16) written per pair -- src/Sample.py:65-91:
+ *     0xFFFF            index matches no sample            (Sample.py:86-91, "Undetermined")
+ *     2*ordinal         matched, min phred >= minimal_qual (Sample.py:70-75, "<name>_pass")
+ *     2*ordinal + 1     matched, quality gate failed       (Sample.py:78-83, "<name>_fail")
+ *   ordinal = position of the sample in SAMPLE_LIST, i.e. order of the [sampleN] sections
+ *   (src/Quade.py:133, src/Sample.py:153).
+ *
+ * Counter vector (uint64[2*S+4]) -- src/Sample.py:32,62,71-72,79-80,88:
+ *     [0] TOTAL  [1] PASS_QUAL  [2] FAIL_QUAL  [3] UNDETERMINED
+ *     [4+2*i] sample i pass_qual   [5+2*i] sample i fail_qual
+ */
+#ifndef QUADE_HIP_H
+#define QUADE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QD_ABI_VERSION 1
+
+#define QD_OK 0
+#define QD_ERR_INVALID (-1)     /* bad argument (NULL pointer, misaligned buffer, size out of range)   */
+#define QD_ERR_NO_DEVICE (-2)   /* no usable HIP device / not gfx950 -- the library never falls back   */
+#define QD_ERR_HIP (-3)         /* a HIP runtime call failed; text in qd_last_error()                   */
+#define QD_ERR_STATE (-4)       /* call order: plan and barcodes must be set before demux/submit        */
+#define QD_ERR_UNSUPPORTED (-5) /* plan outside the supported envelope (window > QD_MAX_WINDOW ...)     */
+#define QD_ERR_BARCODE (-6)     /* barcode table rejected (duplicate index: src/Sample.py:140)          */
+#define QD_ERR_FORMAT (-7)      /* malformed fastq text handed to a host helper                         */
+
+#define QD_CODE_UNDETERMINED 0xFFFFu
+#define QD_MAX_WINDOW 64   /* widest index-read window (idx U mol) kept per row, bytes                  */
+#define QD_MAX_KEY 32      /* longest fused barcode the match kernels compare, bytes                    */
+#define QD_MAX_SAMPLES 32767
+
+typedef struct qd_ctx qd_ctx;
+
+/* ---- plan: the parameters the hot path reads (src/Quade.py:96-116) -------------------------------
+ * start values are 0-based (the conf's 1-based start minus 1, Quade.py:106), end values are the
+ * conf's 1-based inclusive ends, so a slice is read[start:end] exactly as Quade.py:217-218,246-247.
+ * Disabled parts are 0:0 (Quade.py:109-116).  min_qual is the phred threshold (Quade.py:96,
+ * Sample.py:70), 0..40 (Quade.py:262). */
+typedef struct qd_plan {
+    int32_t dual;     /* [index] index2 (Quade.py:100): 1 = two index reads fused, 0 = one */
+    int32_t min_qual; /* [quality] minimal_qual */
+    int32_t idx1_start, idx1_end;
+    int32_t idx2_start, idx2_end;
+    int32_t mol1_start, mol1_end;
+    int32_t mol2_start, mol2_end;
+} qd_plan;
+
+/* ---- row layout derived from a plan --------------------------------------------------------------
+ * For index stream k (0 = index_R1, 1 = index_R2):
+ *   seq row  : seq_stride[k] bytes = columns [seq_off[k], seq_off[k]+seq_width[k]) of the read's
+ *              sequence line, as read (case preserved), zero-padded (0x00) to the stride and where
+ *              the read is shorter than the window.
+ *   qual row : qual_stride[k] bytes = quality characters (Phred+33 text, as read) of columns
+ *              [qual_off[k], qual_off[k]+qual_width[k]) = the barcode slice only (Sample.py:70 takes
+ *              the minimum over the fused barcode positions, nothing else), padded with 0xFF.
+ *   len row  : optional uint8 per read = min(255, read length).  Omitted (NULL) when every read of
+ *              the batch covers its whole window -- then the fast kernels run.
+ * Outputs: codes = uint16 per pair; mol = mol_width bytes per pair (raw case, I1 part then I2 part
+ * packed together, zero padded when reads are short) -- Quade.py:218.  Strides are powers of two.   */
+typedef struct qd_layout {
+    int32_t n_streams;
+    int32_t seq_off[2], seq_width[2], seq_stride[2];
+    int32_t qual_off[2], qual_width[2], qual_stride[2];
+    int32_t key_width; /* K = fused barcode slice width = sum of (idx_end-idx_start)            */
+    int32_t mol_width; /* M = fused molecular slice width; 0 when both molecular flags are off  */
+} qd_layout;
+
+/* Host only.  Replaces nothing in the reference; states the packing contract. */
+int qd_plan_layout(const qd_plan* plan, qd_layout* out);
+
+/* ---- library ------------------------------------------------------------------------------------*/
+int qd_version(void);
+const char* qd_strerror(int code);
+/* Text of the last error on this context (ctx == NULL: last error of qd_create on this thread). */
+const char* qd_last_error(const qd_ctx* ctx);
+
+/* ---- context --------------------------------------------------------------------------------------
+ * qd_create replaces the implicit process-global state of src/Sample.py:32-44 (one run per
+ * process) with an explicit context bound to HIP device `device_id`. */
+int qd_create(int device_id, qd_ctx** out);
+int qd_destroy(qd_ctx* ctx);
+/* name: >= 64 bytes.  Any output pointer may be NULL. */
+int qd_device_info(const qd_ctx* ctx, char* name, int32_t name_cap, int32_t* compute_units,
+                   int64_t* total_mem_bytes);
+
+/* Replaces Sample.CLASS_INIT(min_qual=...) (src/Sample.py:48-54, called at src/Quade.py:125-129)
+ * and the position fields of Quade.__init__ (src/Quade.py:99-116).  The write_* flags are not a
+ * device concern: counters move regardless (Sample.py:71-91) and routing is decided by code. */
+int qd_set_plan(qd_ctx* ctx, const qd_plan* plan);
+int qd_get_layout(const qd_ctx* ctx, qd_layout* out);
+
+/* Replaces the registration side of Sample.__init__ (src/Sample.py:132-153, called at
+ * src/Quade.py:137,139): n_samples upper-case barcodes in ordinal order, concatenated in
+ * `barcodes`, barcode i = barcodes[offsets[i] .. offsets[i+1]).  Lengths may differ from the slice
+ * width and from each other (the reference never checks, Sample.py:132-141); such a barcode can
+ * only match reads whose clamped slice has exactly that length.  Duplicate -> QD_ERR_BARCODE.
+ * Alphabet checks stay on the Python side (message text parity, Sample.py:141). Resets counters. */
+int qd_set_barcodes(qd_ctx* ctx, int32_t n_samples, const uint8_t* barcodes, const int32_t* offsets);
+
+/* ---- device-resident hot path ---------------------------------------------------------------------
+ * Replaces, for n_pairs reads at once: index/molecular extraction and fusion (src/Quade.py:217-218,
+ * 246-247) + Sample.FINDER (src/Sample.py:56-91).  All pointers are DEVICE pointers, 16-byte
+ * aligned, laid out as qd_layout says.  seq[1]/qual[1]/len[1] are ignored for a single-index plan.
+ * codes_dev: n_pairs uint16.  mol_dev: n_pairs*mol_width bytes, may be NULL when mol_width == 0.
+ * `stream` is a hipStream_t (NULL = the context's own stream).  Asynchronous: returns after the
+ * launch.  Counters accumulate in the context. */
+typedef struct qd_rows {
+    const uint8_t* seq[2];
+    const uint8_t* qual[2];
+    const uint8_t* len[2]; /* NULL: every read covers its window */
+} qd_rows;
+int qd_demux_device(qd_ctx* ctx, int64_t n_pairs, const qd_rows* rows, uint16_t* codes_dev,
+                    uint8_t* mol_dev, void* stream);
+
+/* Which kernel qd_demux_device would launch for a batch: 1 = fast (LDS table, vector rows),
+ * 2 = generic.  Informational (tests, bench). */
+int qd_kernel_kind(const qd_ctx* ctx, int has_len);
+
+/* ---- counters: replace the class counters of src/Sample.py:32,144 and feed Sample.REPORT ---------
+ * qd_get_counts waits for outstanding work of this context, then writes 2*S+4 values. */
+int qd_get_counts(qd_ctx* ctx, uint64_t* out, int32_t n_values);
+int qd_reset_counts(qd_ctx* ctx);
+/* Adds externally reduced counts (e.g. the RCCL all-reduce result of other ranks) -- unused by
+ * single-GPU runs.  n_values = 2*S+4. */
+int qd_synchronize(qd_ctx* ctx);
+
+/* ---- host-staged streaming: pinned slots, H2D || kernel || D2H -------------------------------------
+ * Replaces the per-read loop body of Quade.double_index_parser / simple_index_parser
+ * (src/Quade.py:210-221, 240-250) for host-resident rows.  The library owns pinned host and device
+ * buffers of n_slots slots x max_pairs.  A slot's host buffers are caller-writable from qd_wait()
+ * (or creation) until the next qd_submit() of that slot. */
+typedef struct qd_slot_buffers {
+    uint8_t* seq[2];
+    uint8_t* qual[2];
+    uint8_t* len[2];
+    uint16_t* codes; /* valid after qd_wait */
+    uint8_t* mol;    /* valid after qd_wait; NULL when mol_width == 0 */
+    int64_t max_pairs;
+} qd_slot_buffers;
+int qd_slots_create(qd_ctx* ctx, int32_t n_slots, int64_t max_pairs);
+int qd_slots_destroy(qd_ctx* ctx);
+int qd_slot_get(qd_ctx* ctx, int32_t slot, qd_slot_buffers* out);
+/* has_len != 0: the len rows were filled and the generic kernel runs. Non-blocking. */
+int qd_submit(qd_ctx* ctx, int32_t slot, int64_t n_pairs, int32_t has_len);
+int qd_wait(qd_ctx* ctx, int32_t slot);
+
+/* ---- host helpers: fastq text -> rows (replace what the path consumed from pyFastq, a9) -----------
+ * Scans decompressed fastq text (4-line records).  A record whose sequence and quality lengths
+ * differ is skipped inside its own stream (pinned by the reference's golden run);
+ * a trailing partial record ends the scan.  For every kept record r (r < max_records):
+ *   rec_off[r]  = byte offset of its '@' line,   rec_off[n] = offset one past the last kept record
+ * Returns the number of kept records (>= 0) or a negative error code.  *consumed = bytes scanned
+ * (start of the first record NOT consumed) so a caller can stream a file in pieces. */
+int64_t qd_fastq_index(const uint8_t* text, int64_t text_len, int64_t max_records, int64_t* rec_off,
+                       int64_t* consumed);
+
+/* Packs stream `k` (0/1) of `layout` from fastq text: for kept record r writes seq row r, qual row
+ * r and len row r (len_rows may be NULL).  *all_full is set to 0 when any read is shorter than its
+ * window (then the caller must pass len rows to the device).  Same skipping rule and return value
+ * as qd_fastq_index. */
+int64_t qd_pack_index_fastq(const qd_layout* layout, int32_t k, const uint8_t* text, int64_t text_len,
+                            int64_t max_records, uint8_t* seq_rows, uint8_t* qual_rows,
+                            uint8_t* len_rows, int32_t* all_full, int64_t* consumed);
+
+/* Packs rows from already separated reads (concatenated sequence and quality bytes + offsets):
+ * used by tests and by callers that hold records rather than text. */
+int qd_pack_index_reads(const qd_layout* layout, int32_t k, int64_t n, const uint8_t* seq,
+                        const uint8_t* qual, const int64_t* offsets, uint8_t* seq_rows,
+                        uint8_t* qual_rows, uint8_t* len_rows, int32_t* all_full);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUADE_HIP_H */

@@ -1,0 +1,112 @@
+// Host-only helpers of libquade_hip.so: fastq text -> record index / packed index rows.
+// They restate what the hot path consumed from the reference's (un-vendored) pyFastq reader:
+// 4-line records, and a record whose sequence and quality lengths differ is dropped inside its
+// own stream (pinned by the reference's bundled golden run).  No GPU calls here.
+#include <cstring>
+
+#include "../../include/quade_hip.h"
+
+namespace {
+
+struct Rec {
+    int64_t head, seq, seq_end, qual, qual_end, next;
+};
+
+// Parses one record starting at `pos`.  Returns false when fewer than four newline-terminated
+// lines remain.  A trailing '\r' is not part of a line.
+inline bool next_record(const uint8_t* t, int64_t len, int64_t pos, Rec& r) {
+    int64_t p = pos;
+    int64_t starts[4], ends[4];
+    for (int i = 0; i < 4; ++i) {
+        if (p >= len) return false;
+        const void* nl = memchr(t + p, '\n', (size_t)(len - p));
+        if (!nl) return false;
+        const int64_t e = (const uint8_t*)nl - t;
+        starts[i] = p;
+        ends[i] = (e > p && t[e - 1] == '\r') ? e - 1 : e;
+        p = e + 1;
+    }
+    r.head = starts[0];
+    r.seq = starts[1];
+    r.seq_end = ends[1];
+    r.qual = starts[3];
+    r.qual_end = ends[3];
+    r.next = p;
+    return true;
+}
+
+inline void pack_row(const qd_layout* L, int k, const uint8_t* seq, const uint8_t* qual, int64_t len,
+                     uint8_t* srow, uint8_t* qrow) {
+    const int so = L->seq_off[k], sw = L->seq_width[k], ss = L->seq_stride[k];
+    const int qo = L->qual_off[k], qw = L->qual_width[k], qs = L->qual_stride[k];
+    int avail = (int)(len - so < 0 ? 0 : (len - so > sw ? sw : len - so));
+    if (avail > 0) memcpy(srow, seq + so, (size_t)avail);
+    memset(srow + avail, 0x00, (size_t)(ss - avail));
+    avail = (int)(len - qo < 0 ? 0 : (len - qo > qw ? qw : len - qo));
+    if (avail > 0) memcpy(qrow, qual + qo, (size_t)avail);
+    memset(qrow + avail, 0xFF, (size_t)(qs - avail));
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t qd_fastq_index(const uint8_t* text, int64_t text_len, int64_t max_records, int64_t* rec_off,
+                       int64_t* consumed) {
+    if (!text || text_len < 0 || max_records < 0 || !rec_off) return QD_ERR_INVALID;
+    int64_t pos = 0, n = 0;
+    Rec r;
+    while (n < max_records && next_record(text, text_len, pos, r)) {
+        if (r.seq_end - r.seq == r.qual_end - r.qual) rec_off[n++] = r.head;
+        pos = r.next;
+    }
+    rec_off[n] = pos;
+    if (consumed) *consumed = pos;
+    return n;
+}
+
+int64_t qd_pack_index_fastq(const qd_layout* L, int32_t k, const uint8_t* text, int64_t text_len,
+                            int64_t max_records, uint8_t* seq_rows, uint8_t* qual_rows, uint8_t* len_rows,
+                            int32_t* all_full, int64_t* consumed) {
+    if (!L || k < 0 || k >= L->n_streams || !text || text_len < 0 || max_records < 0 || !seq_rows || !qual_rows)
+        return QD_ERR_INVALID;
+    const int ss = L->seq_stride[k], qs = L->qual_stride[k];
+    const int64_t need = (int64_t)L->seq_off[k] + L->seq_width[k];
+    int64_t pos = 0, n = 0;
+    int32_t full = 1;
+    Rec r;
+    while (n < max_records && next_record(text, text_len, pos, r)) {
+        const int64_t len = r.seq_end - r.seq;
+        if (len == r.qual_end - r.qual) {
+            pack_row(L, k, text + r.seq, text + r.qual, len, seq_rows + n * ss, qual_rows + n * qs);
+            if (len_rows) len_rows[n] = (uint8_t)(len > 255 ? 255 : len);
+            if (len < need) full = 0;
+            ++n;
+        }
+        pos = r.next;
+    }
+    if (all_full) *all_full = full;
+    if (consumed) *consumed = pos;
+    return n;
+}
+
+int qd_pack_index_reads(const qd_layout* L, int32_t k, int64_t n, const uint8_t* seq, const uint8_t* qual,
+                        const int64_t* offsets, uint8_t* seq_rows, uint8_t* qual_rows, uint8_t* len_rows,
+                        int32_t* all_full) {
+    if (!L || k < 0 || k >= L->n_streams || n < 0 || !seq || !qual || !offsets || !seq_rows || !qual_rows)
+        return QD_ERR_INVALID;
+    const int ss = L->seq_stride[k], qs = L->qual_stride[k];
+    const int64_t need = (int64_t)L->seq_off[k] + L->seq_width[k];
+    int32_t full = 1;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t len = offsets[i + 1] - offsets[i];
+        if (len < 0) return QD_ERR_INVALID;
+        pack_row(L, k, seq + offsets[i], qual + offsets[i], len, seq_rows + i * ss, qual_rows + i * qs);
+        if (len_rows) len_rows[i] = (uint8_t)(len > 255 ? 255 : len);
+        if (len < need) full = 0;
+    }
+    if (all_full) *all_full = full;
+    return QD_OK;
+}
+
+}  // extern "C"

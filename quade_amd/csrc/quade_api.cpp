@@ -1,0 +1,591 @@
+// C ABI of libquade_hip.so: context, plan, barcode table, launches, counters, pinned slots.
+// Host C++ over the HIP runtime; kernels live in quade_kernels.hip.  See include/quade_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/quade_hip.h"
+#include "quade_common.h"
+#include "quade_kernels.h"
+
+typedef uint64_t u64;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    uint8_t* h_base = nullptr;  // pinned
+    uint8_t* d_base = nullptr;
+    qd_slot_buffers h{};        // host views
+    qd_slot_buffers d{};        // device views (same struct, device pointers)
+    bool busy = false;
+};
+
+}  // namespace
+
+struct qd_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    mutable std::string err;
+    char dev_name[256] = {0};
+    int cu = 0;
+    int64_t total_mem = 0;
+
+    bool have_plan = false, have_table = false;
+    qd_plan plan{};
+    qd_layout lay{};
+
+    // host copy of the barcodes
+    int32_t S = 0;
+    std::vector<uint8_t> bc;
+    std::vector<int32_t> bc_off;
+
+    // device table
+    uint32_t* d_slots_fast = nullptr;
+    uint32_t* d_slots_gen = nullptr;
+    u64* d_bk16 = nullptr;
+    u64* d_bk32 = nullptr;
+    uint8_t* d_blen = nullptr;
+    uint32_t mask_fast = 0, mask_gen = 0, seed_fast = 0, seed_gen = 0;
+    bool fast_ok = false;
+    uint32_t lds_bk_off = 0, lds_hist_off = 0;
+    size_t lds_bytes = 0;
+    int blocks_per_cu = 1;
+
+    // counters
+    u64* d_partial = nullptr;
+    u64* d_counts = nullptr;
+    uint32_t partial_rows = 0, cnt_stride = 0;
+    uint64_t total_pairs = 0;
+
+    std::vector<Slot> slots;
+    int64_t slot_pairs = 0;
+};
+
+namespace {
+
+int fail(const qd_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((c), QD_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+int32_t pow2_at_least(int32_t v, int32_t lo) {
+    int32_t s = lo;
+    while (s < v) s <<= 1;
+    return s;
+}
+
+// canonical key of a byte string: little-endian packed, zero padded
+void canon(const uint8_t* b, int len, u64 w[QD_KEY_WORDS]) {
+    for (int i = 0; i < QD_KEY_WORDS; ++i) w[i] = 0;
+    for (int i = 0; i < len && i < QD_MAX_KEY; ++i) w[i >> 3] |= (u64)b[i] << (8 * (i & 7));
+}
+
+// open-addressing table over the given barcode ordinals; picks the seed with the shortest
+// worst-case probe sequence.  Returns slots (size mask+1).
+std::vector<uint32_t> build_slots(const std::vector<int>& ids, const std::vector<u64>& keys32,
+                                  const std::vector<uint8_t>& blen, uint32_t& mask, uint32_t& seed) {
+    uint32_t m = 16;
+    while (m < 4u * (uint32_t)ids.size()) m <<= 1;
+    mask = m - 1;
+    std::vector<uint32_t> best;
+    uint32_t best_worst = ~0u;
+    for (uint32_t sd = 0; sd < 8; ++sd) {
+        std::vector<uint32_t> t(m, QD_EMPTY_SLOT);
+        uint32_t worst = 0;
+        for (int id : ids) {
+            const uint32_t h = qd_hash_key(&keys32[(size_t)id * QD_KEY_WORDS], blen[id], sd);
+            uint32_t s = h & mask, probes = 1;
+            while (t[s] != QD_EMPTY_SLOT) {
+                s = (s + 1) & mask;
+                ++probes;
+            }
+            t[s] = qd_slot_entry(h, (uint32_t)id);
+            worst = std::max(worst, probes);
+        }
+        if (worst < best_worst) {
+            best_worst = worst;
+            best.swap(t);
+            seed = sd;
+        }
+        if (best_worst <= 2) break;
+    }
+    return best;
+}
+
+void free_table(qd_ctx* c) {
+    if (c->d_slots_fast) (void)hipFree(c->d_slots_fast);
+    if (c->d_slots_gen) (void)hipFree(c->d_slots_gen);
+    if (c->d_bk16) (void)hipFree(c->d_bk16);
+    if (c->d_bk32) (void)hipFree(c->d_bk32);
+    if (c->d_blen) (void)hipFree(c->d_blen);
+    if (c->d_partial) (void)hipFree(c->d_partial);
+    if (c->d_counts) (void)hipFree(c->d_counts);
+    c->d_slots_fast = c->d_slots_gen = nullptr;
+    c->d_bk16 = c->d_bk32 = nullptr;
+    c->d_blen = nullptr;
+    c->d_partial = c->d_counts = nullptr;
+    c->have_table = false;
+}
+
+// (re)build the device table from the host barcodes and the current plan
+int rebuild(qd_ctx* c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    free_table(c);
+    const int S = c->S;
+    const int K = c->lay.key_width;
+    std::vector<u64> k32((size_t)std::max(S, 1) * QD_KEY_WORDS, 0), k16((size_t)std::max(S, 1) * 2, 0);
+    std::vector<uint8_t> blen(std::max(S, 1), 0);
+    std::vector<int> ids_fast, ids_gen;
+    std::map<std::string, int> seen;
+    for (int i = 0; i < S; ++i) {
+        const uint8_t* b = c->bc.data() + c->bc_off[i];
+        const int len = c->bc_off[i + 1] - c->bc_off[i];
+        std::string s((const char*)b, (size_t)len);
+        if (seen.count(s)) {
+            char m[128];
+            snprintf(m, sizeof m, "barcode %d duplicates barcode %d (Index is not unique)", i, seen[s]);
+            return fail(c, QD_ERR_BARCODE, m);
+        }
+        seen[s] = i;
+        blen[i] = (uint8_t)std::min(len, 255);
+        if (len == 0 || len > QD_MAX_KEY) continue;  // can never equal a slice (empty: see DESIGN.md)
+        canon(b, len, &k32[(size_t)i * QD_KEY_WORDS]);
+        ids_gen.push_back(i);
+        if (len == K && K <= 16) {
+            k16[2 * (size_t)i] = k32[(size_t)i * QD_KEY_WORDS];
+            k16[2 * (size_t)i + 1] = k32[(size_t)i * QD_KEY_WORDS + 1];
+            ids_fast.push_back(i);
+        }
+    }
+    std::vector<uint32_t> sf = build_slots(ids_fast, k32, blen, c->mask_fast, c->seed_fast);
+    std::vector<uint32_t> sg = build_slots(ids_gen, k32, blen, c->mask_gen, c->seed_gen);
+
+    HIPCHK(c, hipMalloc(&c->d_slots_fast, sf.size() * 4));
+    HIPCHK(c, hipMalloc(&c->d_slots_gen, sg.size() * 4));
+    HIPCHK(c, hipMalloc(&c->d_bk16, k16.size() * 8));
+    HIPCHK(c, hipMalloc(&c->d_bk32, k32.size() * 8));
+    HIPCHK(c, hipMalloc(&c->d_blen, blen.size()));
+    HIPCHK(c, hipMemcpy(c->d_slots_fast, sf.data(), sf.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_slots_gen, sg.data(), sg.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_bk16, k16.data(), k16.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_bk32, k32.data(), k32.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_blen, blen.data(), blen.size(), hipMemcpyHostToDevice));
+
+    // LDS image of the fast kernel: slots | keys (16 B each) | histogram (2S+1)
+    c->lds_bk_off = (uint32_t)(((size_t)(c->mask_fast + 1) * 4 + 15) & ~(size_t)15);
+    c->lds_hist_off = c->lds_bk_off + (uint32_t)S * 16;
+    c->lds_bytes = ((size_t)c->lds_hist_off + (size_t)(2 * S + 1) * 4 + 15) & ~(size_t)15;
+
+    const qd_layout& L = c->lay;
+    bool ok = (K >= 1 && K <= 16 && L.mol_width <= 16 && c->lds_bytes <= 150 * 1024);
+    for (int k = 0; k < L.n_streams; ++k) {
+        ok = ok && (L.seq_stride[k] == 8 || L.seq_stride[k] == 16) && L.qual_stride[k] == 8;
+        const int mw = (k == 0 ? c->plan.mol1_end - c->plan.mol1_start : c->plan.mol2_end - c->plan.mol2_start);
+        ok = ok && mw <= 8 && L.qual_width[k] <= 8;
+    }
+    c->fast_ok = ok;
+    c->blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / QD_FAST_BLOCK, (160 * 1024) / std::max<size_t>(c->lds_bytes, 1)));
+
+    c->cnt_stride = (uint32_t)((2 * S + 1 + 3) & ~3);
+    c->partial_rows = (uint32_t)c->cu * 4;
+    HIPCHK(c, hipMalloc(&c->d_partial, (size_t)c->partial_rows * c->cnt_stride * 8));
+    HIPCHK(c, hipMalloc(&c->d_counts, (size_t)c->cnt_stride * 8));
+    HIPCHK(c, hipMemset(c->d_partial, 0, (size_t)c->partial_rows * c->cnt_stride * 8));
+    c->total_pairs = 0;
+    c->have_table = true;
+    return QD_OK;
+}
+
+void fill_params(const qd_ctx* c, DemuxParams& p, bool fast) {
+    memset(&p, 0, sizeof p);
+    const qd_layout& L = c->lay;
+    const qd_plan& P = c->plan;
+    p.partial = c->d_partial;
+    p.slots = fast ? c->d_slots_fast : c->d_slots_gen;
+    p.slot_mask = fast ? c->mask_fast : c->mask_gen;
+    p.seed = fast ? c->seed_fast : c->seed_gen;
+    p.bk16 = c->d_bk16;
+    p.bk32 = c->d_bk32;
+    p.blen = c->d_blen;
+    p.n_samples = (uint32_t)c->S;
+    p.cnt_stride = c->cnt_stride;
+    p.partial_rows = c->partial_rows;
+    p.lds_bk_off = c->lds_bk_off;
+    p.lds_hist_off = c->lds_hist_off;
+    p.thr = (uint32_t)(P.min_qual + 33);
+    p.n_streams = L.n_streams;
+    p.K = L.key_width;
+    p.M = L.mol_width;
+    const int is[2] = {P.idx1_start, P.idx2_start}, ie[2] = {P.idx1_end, P.idx2_end};
+    const int ms[2] = {P.mol1_start, P.mol2_start}, me[2] = {P.mol1_end, P.mol2_end};
+    for (int k = 0; k < 2; ++k) {
+        p.seq_stride[k] = L.seq_stride[k];
+        p.qual_stride[k] = L.qual_stride[k];
+        const bool used = k < L.n_streams;
+        p.idx_w[k] = used ? ie[k] - is[k] : 0;
+        p.mol_w[k] = used ? me[k] - ms[k] : 0;
+        p.idx_col[k] = is[k];
+        p.mol_col[k] = ms[k];
+        p.idx_off[k] = p.idx_w[k] ? is[k] - L.seq_off[k] : 0;
+        p.mol_off[k] = p.mol_w[k] ? ms[k] - L.seq_off[k] : 0;
+        p.idx_mask[k] = p.idx_w[k] >= 8 ? ~0ull : ((1ull << (8 * p.idx_w[k])) - 1);
+        p.mol_mask[k] = p.mol_w[k] >= 8 ? ~0ull : ((1ull << (8 * p.mol_w[k])) - 1);
+    }
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* mol, hipStream_t st) {
+    const qd_layout& L = c->lay;
+    bool has_len = false;
+    for (int k = 0; k < L.n_streams; ++k) {
+        if (!rows->seq[k] || !rows->qual[k]) return fail(c, QD_ERR_INVALID, "NULL row pointer");
+        if (!aligned16(rows->seq[k]) || !aligned16(rows->qual[k]))
+            return fail(c, QD_ERR_INVALID, "row buffers must be 16-byte aligned");
+        has_len = has_len || rows->len[k] != nullptr;
+    }
+    if (!codes || !aligned16(codes)) return fail(c, QD_ERR_INVALID, "codes buffer NULL or not 16-byte aligned");
+    if (L.mol_width > 0 && (!mol || !aligned16(mol)))
+        return fail(c, QD_ERR_INVALID, "mol buffer NULL or not 16-byte aligned");
+    const bool fast = c->fast_ok && !has_len;
+    DemuxParams p;
+    fill_params(c, p, fast);
+    for (int k = 0; k < L.n_streams; ++k) {
+        p.seq[k] = rows->seq[k];
+        p.qual[k] = rows->qual[k];
+        p.len[k] = rows->len[k];
+    }
+    p.codes = codes;
+    p.mol = mol;
+    p.n = n;
+    hipError_t e;
+    if (fast) {
+        const int64_t tile = qd_fast_tile_pairs();
+        const int64_t ntiles = (n + tile - 1) / tile;
+        const int grid = (int)std::min<int64_t>(ntiles, (int64_t)c->cu * c->blocks_per_cu);
+        e = qd_launch_fast(p, grid, c->lds_bytes, st);
+    } else {
+        const int64_t nb = (n + QD_GEN_BLOCK - 1) / QD_GEN_BLOCK;
+        const int grid = (int)std::min<int64_t>(nb, (int64_t)c->cu * 8);
+        e = qd_launch_generic(p, grid, st);
+    }
+    if (e != hipSuccess) return fail(c, QD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    c->total_pairs += (uint64_t)n;
+    return QD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qd_version(void) { return QD_ABI_VERSION; }
+
+const char* qd_strerror(int code) {
+    switch (code) {
+        case QD_OK: return "ok";
+        case QD_ERR_INVALID: return "invalid argument";
+        case QD_ERR_NO_DEVICE: return "no usable gfx950 HIP device";
+        case QD_ERR_HIP: return "HIP runtime error";
+        case QD_ERR_STATE: return "plan and barcodes must be set first";
+        case QD_ERR_UNSUPPORTED: return "plan outside the supported envelope";
+        case QD_ERR_BARCODE: return "barcode table rejected";
+        case QD_ERR_FORMAT: return "malformed fastq text";
+    }
+    return "unknown error";
+}
+
+const char* qd_last_error(const qd_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int qd_plan_layout(const qd_plan* P, qd_layout* L) {
+    if (!P || !L) return QD_ERR_INVALID;
+    memset(L, 0, sizeof *L);
+    if (P->min_qual < 0 || P->min_qual > 40) return QD_ERR_INVALID;  // src/Quade.py:262
+    const int is[2] = {P->idx1_start, P->idx2_start}, ie[2] = {P->idx1_end, P->idx2_end};
+    const int ms[2] = {P->mol1_start, P->mol2_start}, me[2] = {P->mol1_end, P->mol2_end};
+    L->n_streams = P->dual ? 2 : 1;
+    for (int k = 0; k < 2; ++k) {
+        L->seq_stride[k] = 8;
+        L->qual_stride[k] = 8;
+        if (k >= L->n_streams) continue;
+        if (is[k] < 0 || ie[k] < is[k] || ms[k] < 0 || me[k] < ms[k]) return QD_ERR_INVALID;  // Quade.py:277-279
+        if (ie[k] > 255 || me[k] > 255) return QD_ERR_UNSUPPORTED;
+        const int iw = ie[k] - is[k], mw = me[k] - ms[k];
+        int lo = 0, hi = 0;
+        if (iw > 0 && mw > 0) {
+            lo = std::min(is[k], ms[k]);
+            hi = std::max(ie[k], me[k]);
+        } else if (iw > 0) {
+            lo = is[k];
+            hi = ie[k];
+        } else if (mw > 0) {
+            lo = ms[k];
+            hi = me[k];
+        }
+        if (hi - lo > QD_MAX_WINDOW) return QD_ERR_UNSUPPORTED;
+        L->seq_off[k] = lo;
+        L->seq_width[k] = hi - lo;
+        L->seq_stride[k] = pow2_at_least(hi - lo, 8);
+        L->qual_off[k] = is[k];
+        L->qual_width[k] = iw;
+        L->qual_stride[k] = pow2_at_least(iw, 8);
+        L->key_width += iw;
+        L->mol_width += mw;
+    }
+    if (L->key_width > QD_MAX_KEY) return QD_ERR_UNSUPPORTED;
+    return QD_OK;
+}
+
+int qd_create(int device_id, qd_ctx** out) {
+    if (!out) return fail(nullptr, QD_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, QD_ERR_NO_DEVICE,
+                    std::string("no HIP device visible (") + hipGetErrorString(e) + "); this library has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, QD_ERR_INVALID, "device_id out of range");
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess)
+        return fail(nullptr, QD_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, QD_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    if ((e = hipSetDevice(device_id)) != hipSuccess)
+        return fail(nullptr, QD_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    qd_ctx* c = new qd_ctx();
+    c->device = device_id;
+    c->cu = prop.multiProcessorCount;
+    c->total_mem = (int64_t)prop.totalGlobalMem;
+    snprintf(c->dev_name, sizeof c->dev_name, "%s (%s)", prop.name, prop.gcnArchName);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete c;
+        return fail(nullptr, QD_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return QD_OK;
+}
+
+int qd_destroy(qd_ctx* c) {
+    if (!c) return QD_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    qd_slots_destroy(c);
+    free_table(c);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return QD_OK;
+}
+
+int qd_device_info(const qd_ctx* c, char* name, int32_t cap, int32_t* cus, int64_t* mem) {
+    if (!c) return QD_ERR_INVALID;
+    if (name && cap > 0) snprintf(name, (size_t)cap, "%s", c->dev_name);
+    if (cus) *cus = c->cu;
+    if (mem) *mem = c->total_mem;
+    return QD_OK;
+}
+
+int qd_set_plan(qd_ctx* c, const qd_plan* plan) {
+    if (!c || !plan) return QD_ERR_INVALID;
+    qd_layout L;
+    const int r = qd_plan_layout(plan, &L);
+    if (r != QD_OK) return fail(c, r, "plan rejected: positions must satisfy 0 <= start <= end <= 255, window <= 64, "
+                                       "fused barcode <= 32, 0 <= minimal_qual <= 40");
+    if (!c->slots.empty()) return fail(c, QD_ERR_STATE, "destroy the slots before changing the plan");
+    c->plan = *plan;
+    c->lay = L;
+    c->have_plan = true;
+    if (c->S > 0 || c->have_table) return rebuild(c);
+    return QD_OK;
+}
+
+int qd_get_layout(const qd_ctx* c, qd_layout* out) {
+    if (!c || !out) return QD_ERR_INVALID;
+    if (!c->have_plan) return fail(c, QD_ERR_STATE, "qd_set_plan first");
+    *out = c->lay;
+    return QD_OK;
+}
+
+int qd_set_barcodes(qd_ctx* c, int32_t S, const uint8_t* barcodes, const int32_t* offsets) {
+    if (!c || S < 0 || S > QD_MAX_SAMPLES || (S > 0 && (!barcodes || !offsets)))
+        return fail(c, QD_ERR_INVALID, "bad barcode arguments (0 <= n_samples <= 32767)");
+    if (!c->have_plan) return fail(c, QD_ERR_STATE, "qd_set_plan first");
+    for (int i = 0; i < S; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(c, QD_ERR_INVALID, "offsets must be non-decreasing");
+    c->S = S;
+    c->bc.assign(barcodes, barcodes + (S ? offsets[S] : 0));
+    c->bc_off.assign(offsets, offsets + (S ? S + 1 : 0));
+    if (S == 0) c->bc_off.assign(1, 0);
+    return rebuild(c);
+}
+
+int qd_kernel_kind(const qd_ctx* c, int has_len) {
+    if (!c || !c->have_table) return QD_ERR_STATE;
+    return (c->fast_ok && !has_len) ? 1 : 2;
+}
+
+int qd_demux_device(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* mol, void* stream) {
+    if (!c || !rows || n < 0) return fail(c, QD_ERR_INVALID, "bad arguments");
+    if (!c->have_plan || !c->have_table) return fail(c, QD_ERR_STATE, "qd_set_plan and qd_set_barcodes first");
+    if (n == 0) return QD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    return launch(c, n, rows, codes, mol, stream ? (hipStream_t)stream : c->stream);
+}
+
+int qd_synchronize(qd_ctx* c) {
+    if (!c) return QD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    return QD_OK;
+}
+
+int qd_get_counts(qd_ctx* c, uint64_t* out, int32_t n_values) {
+    if (!c || !out) return QD_ERR_INVALID;
+    if (!c->have_table) return fail(c, QD_ERR_STATE, "qd_set_barcodes first");
+    if (n_values != 2 * c->S + 4) return fail(c, QD_ERR_INVALID, "n_values must be 2*S+4");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    const uint32_t ncnt = (uint32_t)(2 * c->S + 1);
+    hipError_t e = qd_launch_reduce(c->d_partial, c->partial_rows, c->cnt_stride, ncnt, c->d_counts, c->stream);
+    if (e != hipSuccess) return fail(c, QD_ERR_HIP, std::string("reduce launch: ") + hipGetErrorString(e));
+    std::vector<u64> h(ncnt);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->d_counts, (size_t)ncnt * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t pass = 0, failq = 0;
+    for (int i = 0; i < c->S; ++i) {
+        out[4 + 2 * i] = h[2 * i];
+        out[5 + 2 * i] = h[2 * i + 1];
+        pass += h[2 * i];
+        failq += h[2 * i + 1];
+    }
+    out[0] = c->total_pairs;  // TOTAL: pairs submitted (Sample.py:62)
+    out[1] = pass;
+    out[2] = failq;
+    out[3] = h[2 * c->S];     // UNDETERMINED: counted on the device, not derived
+    return QD_OK;
+}
+
+int qd_reset_counts(qd_ctx* c) {
+    if (!c) return QD_ERR_INVALID;
+    if (!c->have_table) return QD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemset(c->d_partial, 0, (size_t)c->partial_rows * c->cnt_stride * 8));
+    c->total_pairs = 0;
+    return QD_OK;
+}
+
+// ---- pinned slots ---------------------------------------------------------------------------------
+static size_t carve(qd_slot_buffers& v, uint8_t* base, const qd_layout& L, int64_t n) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        uint8_t* p = base ? base + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return p;
+    };
+    for (int k = 0; k < 2; ++k) {
+        const bool used = k < L.n_streams;
+        v.seq[k] = used ? take((size_t)n * L.seq_stride[k]) : nullptr;
+        v.qual[k] = used ? take((size_t)n * L.qual_stride[k]) : nullptr;
+        v.len[k] = used ? take((size_t)n) : nullptr;
+    }
+    v.codes = (uint16_t*)take((size_t)n * 2);
+    v.mol = L.mol_width ? take((size_t)n * L.mol_width) : nullptr;
+    v.max_pairs = n;
+    return off;
+}
+
+int qd_slots_create(qd_ctx* c, int32_t n_slots, int64_t max_pairs) {
+    if (!c || n_slots < 1 || n_slots > 64 || max_pairs < 1) return fail(c, QD_ERR_INVALID, "bad slot arguments");
+    if (!c->have_plan) return fail(c, QD_ERR_STATE, "qd_set_plan first");
+    if (!c->slots.empty()) return fail(c, QD_ERR_STATE, "slots already exist");
+    HIPCHK(c, hipSetDevice(c->device));
+    qd_slot_buffers probe{};
+    const size_t bytes = carve(probe, nullptr, c->lay, max_pairs);
+    c->slots.resize((size_t)n_slots);
+    c->slot_pairs = max_pairs;
+    for (auto& s : c->slots) {
+        HIPCHK(c, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIPCHK(c, hipHostMalloc((void**)&s.h_base, bytes, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc((void**)&s.d_base, bytes));
+        carve(s.h, s.h_base, c->lay, max_pairs);
+        carve(s.d, s.d_base, c->lay, max_pairs);
+    }
+    return QD_OK;
+}
+
+int qd_slots_destroy(qd_ctx* c) {
+    if (!c) return QD_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    for (auto& s : c->slots) {
+        if (s.stream) {
+            (void)hipStreamSynchronize(s.stream);
+            (void)hipStreamDestroy(s.stream);
+        }
+        if (s.h_base) (void)hipHostFree(s.h_base);
+        if (s.d_base) (void)hipFree(s.d_base);
+    }
+    c->slots.clear();
+    return QD_OK;
+}
+
+int qd_slot_get(qd_ctx* c, int32_t slot, qd_slot_buffers* out) {
+    if (!c || !out || slot < 0 || slot >= (int)c->slots.size()) return fail(c, QD_ERR_INVALID, "bad slot");
+    *out = c->slots[(size_t)slot].h;
+    return QD_OK;
+}
+
+int qd_submit(qd_ctx* c, int32_t slot, int64_t n, int32_t has_len) {
+    if (!c || slot < 0 || slot >= (int)c->slots.size()) return fail(c, QD_ERR_INVALID, "bad slot");
+    if (n < 0 || n > c->slot_pairs) return fail(c, QD_ERR_INVALID, "n_pairs exceeds the slot capacity");
+    if (!c->have_table) return fail(c, QD_ERR_STATE, "qd_set_barcodes first");
+    Slot& s = c->slots[(size_t)slot];
+    if (s.busy) return fail(c, QD_ERR_STATE, "slot already submitted; qd_wait it first");
+    HIPCHK(c, hipSetDevice(c->device));
+    s.busy = true;
+    if (n == 0) return QD_OK;
+    const qd_layout& L = c->lay;
+    qd_rows rows{};
+    for (int k = 0; k < L.n_streams; ++k) {
+        HIPCHK(c, hipMemcpyAsync(s.d.seq[k], s.h.seq[k], (size_t)n * L.seq_stride[k], hipMemcpyHostToDevice, s.stream));
+        HIPCHK(c, hipMemcpyAsync(s.d.qual[k], s.h.qual[k], (size_t)n * L.qual_stride[k], hipMemcpyHostToDevice, s.stream));
+        rows.seq[k] = s.d.seq[k];
+        rows.qual[k] = s.d.qual[k];
+        if (has_len) {
+            HIPCHK(c, hipMemcpyAsync(s.d.len[k], s.h.len[k], (size_t)n, hipMemcpyHostToDevice, s.stream));
+            rows.len[k] = s.d.len[k];
+        }
+    }
+    const int r = launch(c, n, &rows, s.d.codes, s.d.mol, s.stream);
+    if (r != QD_OK) return r;
+    HIPCHK(c, hipMemcpyAsync(s.h.codes, s.d.codes, (size_t)n * 2, hipMemcpyDeviceToHost, s.stream));
+    if (L.mol_width)
+        HIPCHK(c, hipMemcpyAsync(s.h.mol, s.d.mol, (size_t)n * L.mol_width, hipMemcpyDeviceToHost, s.stream));
+    return QD_OK;
+}
+
+int qd_wait(qd_ctx* c, int32_t slot) {
+    if (!c || slot < 0 || slot >= (int)c->slots.size()) return fail(c, QD_ERR_INVALID, "bad slot");
+    Slot& s = c->slots[(size_t)slot];
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(s.stream));
+    s.busy = false;
+    return QD_OK;
+}
+
+}  // extern "C"

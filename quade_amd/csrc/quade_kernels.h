@@ -1,0 +1,43 @@
+// Kernel parameter block and launch entry points (internal to libquade_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define QD_CODE_UNDET 0xFFFFu
+#define QD_MAX_KEY_BYTES 32
+
+#define QD_FAST_BLOCK 512  /* threads per workgroup, fast kernel      */
+#define QD_FAST_UNITS 2    /* 2-pair units per lane per tile          */
+#define QD_GEN_BLOCK 256
+
+struct DemuxParams {
+    // packed rows (device)
+    const uint8_t* seq[2];
+    const uint8_t* qual[2];
+    const uint8_t* len[2];
+    // outputs (device)
+    uint16_t* codes;
+    uint8_t* mol;
+    uint64_t* partial;  // [partial_rows][cnt_stride] per-workgroup counter rows
+    // barcode table (device, global memory)
+    const uint32_t* slots;              // [slot_mask+1]  (fingerprint<<16 | ordinal), 0xFFFFFFFF empty
+    const uint64_t* bk16;     // [S][2]  canonical keys of the barcodes whose length == K
+    const uint64_t* bk32;     // [S][4]  canonical keys of every barcode (generic kernel)
+    const uint8_t* blen;                // [S]     barcode lengths
+    int64_t n;
+    uint32_t slot_mask, seed, n_samples, cnt_stride, partial_rows;
+    uint32_t lds_bk_off, lds_hist_off;
+    uint32_t thr;  // minimal_qual + 33, compared with raw quality bytes
+    int32_t n_streams, K, M;
+    int32_t seq_stride[2], qual_stride[2];
+    int32_t idx_off[2], idx_w[2];  // byte offset of the barcode slice inside a seq row, width
+    int32_t mol_off[2], mol_w[2];
+    int32_t idx_col[2], mol_col[2];  // absolute 0-based column of the slices (length clamping)
+    uint64_t idx_mask[2], mol_mask[2];  // (1 << 8*w) - 1
+};
+
+int64_t qd_fast_tile_pairs();
+hipError_t qd_launch_fast(const DemuxParams& p, int grid, size_t lds_bytes, hipStream_t st);
+hipError_t qd_launch_generic(const DemuxParams& p, int grid, hipStream_t st);
+hipError_t qd_launch_reduce(const uint64_t* partial, uint32_t rows, uint32_t cnt_stride,
+                            uint32_t ncnt, uint64_t* out, hipStream_t st);

@@ -1,0 +1,307 @@
+# -*- coding: utf-8 -*-
+"""
+ctypes binding of libquade_hip.so (include/quade_hip.h) -- the only compute path of this package.
+
+There is deliberately no fallback: if the shared library is missing, or no gfx950 device is
+usable, construction fails with an exception that says so.  numpy is used for host buffers only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libquade_hip.so")
+
+QD_OK = 0
+QD_ERR_INVALID, QD_ERR_NO_DEVICE, QD_ERR_HIP, QD_ERR_STATE = -1, -2, -3, -4
+QD_ERR_UNSUPPORTED, QD_ERR_BARCODE, QD_ERR_FORMAT = -5, -6, -7
+CODE_UNDETERMINED = 0xFFFF
+
+
+class QuadeHipError(RuntimeError):
+    def __init__(self, code, text):
+        RuntimeError.__init__(self, "libquade_hip error %d: %s" % (code, text))
+        self.code = code
+
+
+class qd_plan(C.Structure):
+    _fields_ = [("dual", C.c_int32), ("min_qual", C.c_int32),
+                ("idx1_start", C.c_int32), ("idx1_end", C.c_int32),
+                ("idx2_start", C.c_int32), ("idx2_end", C.c_int32),
+                ("mol1_start", C.c_int32), ("mol1_end", C.c_int32),
+                ("mol2_start", C.c_int32), ("mol2_end", C.c_int32)]
+
+
+class qd_layout(C.Structure):
+    _fields_ = [("n_streams", C.c_int32),
+                ("seq_off", C.c_int32 * 2), ("seq_width", C.c_int32 * 2), ("seq_stride", C.c_int32 * 2),
+                ("qual_off", C.c_int32 * 2), ("qual_width", C.c_int32 * 2), ("qual_stride", C.c_int32 * 2),
+                ("key_width", C.c_int32), ("mol_width", C.c_int32)]
+
+
+class qd_rows(C.Structure):
+    _fields_ = [("seq", C.c_void_p * 2), ("qual", C.c_void_p * 2), ("len", C.c_void_p * 2)]
+
+
+class qd_slot_buffers(C.Structure):
+    _fields_ = [("seq", C.c_void_p * 2), ("qual", C.c_void_p * 2), ("len", C.c_void_p * 2),
+                ("codes", C.c_void_p), ("mol", C.c_void_p), ("max_pairs", C.c_int64)]
+
+
+# every symbol include/quade_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("qd_plan_layout", C.c_int, [C.POINTER(qd_plan), C.POINTER(qd_layout)]),
+    ("qd_version", C.c_int, []),
+    ("qd_strerror", C.c_char_p, [C.c_int]),
+    ("qd_last_error", C.c_char_p, [_P]),
+    ("qd_create", C.c_int, [C.c_int, C.POINTER(_P)]),
+    ("qd_destroy", C.c_int, [_P]),
+    ("qd_device_info", C.c_int, [_P, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    ("qd_set_plan", C.c_int, [_P, C.POINTER(qd_plan)]),
+    ("qd_get_layout", C.c_int, [_P, C.POINTER(qd_layout)]),
+    ("qd_set_barcodes", C.c_int, [_P, C.c_int32, _P, _P]),
+    ("qd_demux_device", C.c_int, [_P, C.c_int64, C.POINTER(qd_rows), _P, _P, _P]),
+    ("qd_kernel_kind", C.c_int, [_P, C.c_int]),
+    ("qd_get_counts", C.c_int, [_P, _P, C.c_int32]),
+    ("qd_reset_counts", C.c_int, [_P]),
+    ("qd_synchronize", C.c_int, [_P]),
+    ("qd_slots_create", C.c_int, [_P, C.c_int32, C.c_int64]),
+    ("qd_slots_destroy", C.c_int, [_P]),
+    ("qd_slot_get", C.c_int, [_P, C.c_int32, C.POINTER(qd_slot_buffers)]),
+    ("qd_submit", C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32]),
+    ("qd_wait", C.c_int, [_P, C.c_int32]),
+    ("qd_fastq_index", C.c_int64, [_P, C.c_int64, C.c_int64, _P, C.POINTER(C.c_int64)]),
+    ("qd_pack_index_fastq", C.c_int64, [C.POINTER(qd_layout), C.c_int32, _P, C.c_int64, C.c_int64, _P, _P, _P,
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    ("qd_pack_index_reads", C.c_int, [C.POINTER(qd_layout), C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P,
+                                      C.POINTER(C.c_int32)]),
+]
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads libquade_hip.so and types every entry point.  Raises (never falls back)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s not found: build it first (python -c 'import __graft_entry__ as g; g.build()' or "
+            "make -C quade_amd/csrc).  quade_amd has no CPU fallback." % path)
+    lib = C.CDLL(path)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    """address of a numpy array (host) / int address / None"""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    return a.ctypes.data
+
+
+def plan_layout(plan: qd_plan) -> qd_layout:
+    lib = load_library()
+    lay = qd_layout()
+    r = lib.qd_plan_layout(C.byref(plan), C.byref(lay))
+    if r != QD_OK:
+        raise QuadeHipError(r, lib.qd_strerror(r).decode())
+    return lay
+
+
+def make_plan(dual, min_qual, idx1, idx2=(0, 0), mol1=(0, 0), mol2=(0, 0)) -> qd_plan:
+    """Positions are (start0, end) pairs exactly as src/Quade.py:105-116 stores them."""
+    return qd_plan(int(bool(dual)), int(min_qual), idx1[0], idx1[1], idx2[0], idx2[1],
+                   mol1[0], mol1[1], mol2[0], mol2[1])
+
+
+# ---- host helpers (no GPU) ---------------------------------------------------------------------------
+def fastq_index(text: bytes | np.ndarray, max_records=None):
+    """Offsets of the kept records of decompressed fastq text (see qd_fastq_index).
+    Returns (rec_off int64[n+1], consumed)."""
+    lib = load_library()
+    buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else text
+    if max_records is None:
+        max_records = int(np.count_nonzero(buf == 10)) // 4 + 1
+    off = np.empty(max_records + 1, dtype=np.int64)
+    consumed = C.c_int64(0)
+    n = lib.qd_fastq_index(_ptr(buf), buf.size, max_records, _ptr(off), C.byref(consumed))
+    if n < 0:
+        raise QuadeHipError(int(n), lib.qd_strerror(int(n)).decode())
+    return off[:n + 1], consumed.value
+
+
+def pack_index_fastq(layout: qd_layout, k: int, text, seq_rows, qual_rows, len_rows, max_records):
+    """Packs stream k from fastq text into the given row arrays (numpy uint8, C-contiguous, or raw
+    addresses).  Returns (n_records, all_full, consumed)."""
+    lib = load_library()
+    buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else text
+    full = C.c_int32(1)
+    consumed = C.c_int64(0)
+    n = lib.qd_pack_index_fastq(C.byref(layout), k, _ptr(buf), buf.size, max_records, _ptr(seq_rows),
+                                _ptr(qual_rows), _ptr(len_rows), C.byref(full), C.byref(consumed))
+    if n < 0:
+        raise QuadeHipError(int(n), lib.qd_strerror(int(n)).decode())
+    return int(n), bool(full.value), consumed.value
+
+
+def pack_index_reads(layout: qd_layout, k: int, seqs, quals):
+    """Packs lists of bytes (sequences, quality strings) -> (seq_rows, qual_rows, len_rows, all_full)."""
+    lib = load_library()
+    n = len(seqs)
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=n)
+    assert all(len(q) == len(s) for s, q in zip(seqs, quals)), "seq/qual length mismatch"
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    seq = np.frombuffer(b"".join(seqs) + b"\0", dtype=np.uint8)
+    qual = np.frombuffer(b"".join(quals) + b"\0", dtype=np.uint8)
+    seq_rows = np.empty((n, layout.seq_stride[k]), dtype=np.uint8)
+    qual_rows = np.empty((n, layout.qual_stride[k]), dtype=np.uint8)
+    len_rows = np.empty(n, dtype=np.uint8)
+    full = C.c_int32(1)
+    r = lib.qd_pack_index_reads(C.byref(layout), k, n, _ptr(seq), _ptr(qual), _ptr(offsets), _ptr(seq_rows),
+                                _ptr(qual_rows), _ptr(len_rows), C.byref(full))
+    if r != QD_OK:
+        raise QuadeHipError(r, lib.qd_strerror(r).decode())
+    return seq_rows, qual_rows, len_rows, bool(full.value)
+
+
+# ---- device context -------------------------------------------------------------------------------------
+class Engine(object):
+    """One libquade_hip context = one MI355X.  Mirrors what Sample.CLASS_INIT + Sample(name, index)
+    configure in the reference (src/Sample.py:48-54,132-153) and runs FINDER for whole batches."""
+
+    def __init__(self, device_id=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        r = self.lib.qd_create(int(device_id), C.byref(h))
+        if r != QD_OK:
+            raise QuadeHipError(r, self.lib.qd_last_error(None).decode())
+        self._h = h
+        self.device_id = int(device_id)
+        self.n_samples = 0
+        self.layout = None
+        self._slot_views = {}
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.qd_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r):
+        if r != QD_OK:
+            raise QuadeHipError(r, self.lib.qd_last_error(self._h).decode() or self.lib.qd_strerror(r).decode())
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_int32(0), C.c_int64(0)
+        self._chk(self.lib.qd_device_info(self._h, name, 256, C.byref(cus), C.byref(mem)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "total_mem": mem.value}
+
+    # -- configuration
+    def set_plan(self, plan: qd_plan):
+        self._chk(self.lib.qd_set_plan(self._h, C.byref(plan)))
+        lay = qd_layout()
+        self._chk(self.lib.qd_get_layout(self._h, C.byref(lay)))
+        self.layout = lay
+        self.plan = plan
+        return lay
+
+    def set_barcodes(self, barcodes):
+        """barcodes: list of upper-case str/bytes in sample-ordinal order (SAMPLE_LIST order)."""
+        bs = [b.encode("latin-1") if isinstance(b, str) else bytes(b) for b in barcodes]
+        offs = np.zeros(len(bs) + 1, dtype=np.int32)
+        if bs:
+            np.cumsum([len(b) for b in bs], out=offs[1:])
+        blob = np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8)
+        self._chk(self.lib.qd_set_barcodes(self._h, len(bs), _ptr(blob), _ptr(offs)))
+        self.n_samples = len(bs)
+
+    def kernel_kind(self, has_len=False):
+        return {1: "fast", 2: "generic"}[self.lib.qd_kernel_kind(self._h, int(has_len))]
+
+    # -- device-resident batches (pointers are device addresses, e.g. torch tensor .data_ptr())
+    def demux_device(self, n_pairs, seq, qual, codes, mol=None, lens=(None, None), stream=None):
+        rows = qd_rows()
+        for k in range(2):
+            rows.seq[k] = seq[k] if k < len(seq) else None
+            rows.qual[k] = qual[k] if k < len(qual) else None
+            rows.len[k] = lens[k] if k < len(lens) else None
+        self._chk(self.lib.qd_demux_device(self._h, int(n_pairs), C.byref(rows), codes, mol, stream))
+
+    def synchronize(self):
+        self._chk(self.lib.qd_synchronize(self._h))
+
+    def counts(self):
+        out = np.zeros(2 * self.n_samples + 4, dtype=np.uint64)
+        self._chk(self.lib.qd_get_counts(self._h, _ptr(out), out.size))
+        return out
+
+    def reset_counts(self):
+        self._chk(self.lib.qd_reset_counts(self._h))
+
+    # -- pinned slots
+    def slots_create(self, n_slots, max_pairs):
+        self._chk(self.lib.qd_slots_create(self._h, int(n_slots), int(max_pairs)))
+        self._slot_views = {}
+        self.n_slots, self.slot_pairs = int(n_slots), int(max_pairs)
+
+    def slots_destroy(self):
+        self._slot_views = {}
+        self._chk(self.lib.qd_slots_destroy(self._h))
+
+    def slot(self, i):
+        """numpy views over the pinned host buffers of slot i."""
+        if i in self._slot_views:
+            return self._slot_views[i]
+        sb = qd_slot_buffers()
+        self._chk(self.lib.qd_slot_get(self._h, i, C.byref(sb)))
+        L, n = self.layout, sb.max_pairs
+
+        def view(addr, shape, dtype=np.uint8):
+            if not addr:
+                return None
+            nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            buf = (C.c_uint8 * nbytes).from_address(addr)
+            return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+        v = {"seq": [], "qual": [], "len": [], "max_pairs": n}
+        for k in range(L.n_streams):
+            v["seq"].append(view(sb.seq[k], (n, L.seq_stride[k])))
+            v["qual"].append(view(sb.qual[k], (n, L.qual_stride[k])))
+            v["len"].append(view(sb.len[k], (n,)))
+        v["codes"] = view(sb.codes, (n,), np.uint16)
+        v["mol"] = view(sb.mol, (n, L.mol_width)) if L.mol_width else None
+        self._slot_views[i] = v
+        return v
+
+    def submit(self, slot, n_pairs, has_len=False):
+        self._chk(self.lib.qd_submit(self._h, int(slot), int(n_pairs), int(bool(has_len))))
+
+    def wait(self, slot):
+        self._chk(self.lib.qd_wait(self._h, int(slot)))

@@ -1,0 +1,162 @@
+# -*- coding: utf-8 -*-
+"""
+Synthetic demultiplexing workloads as packed index rows.
+
+One generator, written with torch tensor ops so that it runs on the CPU (tests, small sizes) and on
+the GPU (bench.py, 10^8 pairs without a host round trip).  torch is used here only as the
+array/RNG library that owns device memory; nothing in it is on the measured path.
+
+Recipe per config (all random draws from one seeded torch.Generator):
+  barcodes  : S distinct uniform strings over ACGT, 8 per index read (dual: S distinct pairs, K=16),
+              pairwise Hamming distance >= 2 so a single substitution never lands on another sample
+  index read: 90 % carry a uniformly chosen sample's barcode; 5 % that barcode with one base
+              substituted by a different symbol of ACGTN; 5 % uniform over ACGT (re-drawn while it
+              equals a real barcode); 1 % of all reads get one base lower-cased
+  qualities : 85 % good (every base phred uniform 30..40); 15 % bad (one barcode position set to
+              phred uniform 2..24)
+  read length: 8 (cfg 2, 3, 5) or 14 with a 6-base molecular index behind the barcode (cfg 4)
+The expected routing code of every pair is known by construction and returned with the rows.
+"""
+from __future__ import annotations
+
+import torch
+
+from .hip_backend import make_plan, plan_layout
+
+ACGT = torch.tensor([65, 67, 71, 84], dtype=torch.uint8)
+ACGTN = torch.tensor([65, 67, 71, 84, 78], dtype=torch.uint8)
+
+CONFIGS = {
+    # name: dual, S, index-read length, molecular, min_qual, pairs in BASELINE.json
+    "cfg2": dict(dual=False, S=12, read_len=8, mol=False, min_qual=0, pairs=10_000_000),
+    "cfg3": dict(dual=True, S=96, read_len=8, mol=False, min_qual=25, pairs=100_000_000),
+    "cfg4": dict(dual=True, S=384, read_len=14, mol=True, min_qual=25, pairs=500_000_000),
+    "cfg5": dict(dual=True, S=1536, read_len=8, mol=False, min_qual=25, pairs=1_000_000_000),
+}
+# algorithmic bytes per pair (SURVEY.md 8d / BASELINE.md section 3)
+ALGO_BYTES = {"cfg2": 18, "cfg3": 34, "cfg4": 58, "cfg5": 34}
+
+
+def config_plan(name):
+    c = CONFIGS[name]
+    mol = (8, 14) if c["mol"] else (0, 0)
+    return make_plan(c["dual"], c["min_qual"], (0, 8), (0, 8) if c["dual"] else (0, 0),
+                     mol, mol if c["dual"] else (0, 0))
+
+
+def _key64(rows):
+    """[n, 8k] uint8 -> [n, k] int64 (little-endian words)"""
+    return rows.contiguous().view(torch.int64)
+
+
+def _mix(words):
+    """cheap 64-bit mix of a [n, k] int64 key, used only to pre-filter collisions"""
+    h = torch.zeros(words.shape[0], dtype=torch.int64, device=words.device)
+    for j in range(words.shape[1]):
+        h = (h ^ words[:, j]) * -7046029254386353131  # 0x9E3779B97F4A7C15 as int64
+        h = h ^ (h >> 29)
+    return h
+
+
+def make_barcodes(S, K, gen, device="cpu"):
+    """S distinct ACGT strings of length K with pairwise Hamming distance >= 2 -> uint8 [S, K]"""
+    out = torch.empty((0, K), dtype=torch.uint8)
+    while out.shape[0] < S:
+        cand = ACGT[torch.randint(0, 4, (S, K), generator=gen)]
+        allb = torch.cat([out, cand])
+        d = (allb[:, None, :] != allb[None, :, :]).sum(-1)
+        d.fill_diagonal_(K)
+        keep = torch.ones(allb.shape[0], dtype=torch.bool)
+        # drop the later member of every too-close pair
+        bad = torch.nonzero(torch.triu(d < 2, diagonal=1))
+        keep[bad[:, 1]] = False
+        out = allb[keep][:S]
+    return out.to(device)
+
+
+class Workload(object):
+    """Packed rows of one synthetic batch (tensors on `device`)."""
+
+    def __init__(self, name, n, seq, qual, expected, barcodes, plan, layout):
+        self.name, self.n = name, n
+        self.seq, self.qual = seq, qual          # lists (1 or 2) of uint8 [n, stride]
+        self.expected = expected                 # uint16-valued int32 [n] routing codes by construction
+        self.barcodes = barcodes                 # uint8 [S, K] (cpu)
+        self.plan, self.layout = plan, layout
+
+    def barcode_strings(self):
+        return [bytes(r.tolist()).decode() for r in self.barcodes.cpu()]
+
+
+def generate(name, n, seed=None, device="cpu", chunk=8_000_000):
+    """Builds `n` pairs of config `name`.  Deterministic for a given (name, n, seed, device type)."""
+    c = CONFIGS[name]
+    cfg_no = int(name[3:])
+    seed = 20260000 + cfg_no if seed is None else seed
+    gcpu = torch.Generator(device="cpu").manual_seed(seed)
+    dev = torch.device(device)
+    gen = gcpu if dev.type == "cpu" else torch.Generator(device=dev).manual_seed(seed)
+    ns = 2 if c["dual"] else 1
+    K = 8 * ns
+    S = c["S"]
+    L = c["read_len"]
+    plan = config_plan(name)
+    lay = plan_layout(plan)
+    bcs_cpu = make_barcodes(S, K, gcpu)
+    bcs = bcs_cpu.to(dev)
+    table_h = _mix(_key64(bcs))
+    acgt, acgtn = ACGT.to(dev), ACGTN.to(dev)
+
+    seq = [torch.empty((n, lay.seq_stride[k]), dtype=torch.uint8, device=dev) for k in range(ns)]
+    qual = [torch.empty((n, lay.qual_stride[k]), dtype=torch.uint8, device=dev) for k in range(ns)]
+    expected = torch.empty(n, dtype=torch.int32, device=dev)
+
+    def ri(lo, hi, shape):
+        return torch.randint(lo, hi, shape, generator=gen, device=dev)
+
+    for a in range(0, n, chunk):
+        m = min(chunk, n - a)
+        sample = ri(0, S, (m,))
+        key = bcs[sample].clone()                                   # [m, K]
+        kind = ri(0, 100, (m,))                                     # <90 match, 90..94 mutated, 95..99 random
+        rows = torch.arange(m, device=dev)
+        # one substitution by a different symbol of ACGTN
+        mut = kind >= 90
+        pos = ri(0, K, (m,))
+        sub = acgtn[ri(0, 5, (m,))]
+        same = sub == key[rows, pos]
+        sub = torch.where(same, torch.where(key[rows, pos] == 78, acgt[0], acgtn[4]), sub)
+        key[rows[mut], pos[mut]] = sub[mut]
+        # uniform random reads, re-drawn while they equal a registered barcode
+        rnd = kind >= 95
+        nr = int(rnd.sum())
+        if nr:
+            r = acgt[ri(0, 4, (nr, K))]
+            for _ in range(16):
+                hit = torch.isin(_mix(_key64(r)), table_h)
+                if not bool(hit.any()):
+                    break
+                r[hit] = acgt[ri(0, 4, (int(hit.sum()), K))]
+            key[rnd] = r
+        exp = torch.where(mut, torch.full_like(sample, 0xFFFF), sample * 2)
+        # 1 % lower-case one base (fold must not change the match)
+        lc = ri(0, 100, (m,)) == 0
+        lpos = ri(0, K, (m,))
+        key[rows[lc], lpos[lc]] = key[rows[lc], lpos[lc]] | 0x20
+        # qualities: phred 30..40 everywhere, 15 % get one bad barcode position (phred 2..24)
+        q = (ri(30, 41, (m, K)) + 33).to(torch.uint8)
+        bad = ri(0, 100, (m,)) < 15
+        bpos = ri(0, K, (m,))
+        bval = (ri(2, 25, (m,)) + 33).to(torch.uint8)
+        q[rows[bad], bpos[bad]] = bval[bad]
+        if c["min_qual"] > 0:
+            exp = torch.where(bad & ~mut, exp + 1, exp)
+        expected[a:a + m] = exp.to(torch.int32)
+        for k in range(ns):
+            seq[k][a:a + m].zero_()
+            seq[k][a:a + m, 0:8] = key[:, 8 * k:8 * k + 8]
+            if c["mol"]:
+                seq[k][a:a + m, 8:L] = acgt[ri(0, 4, (m, L - 8))]
+            qual[k][a:a + m].fill_(0xFF)
+            qual[k][a:a + m, 0:8] = q[:, 8 * k:8 * k + 8]
+    return Workload(name, n, seq, qual, expected, bcs_cpu, plan, lay)
