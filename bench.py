@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""
+bench.py -- read-pairs/sec of the demultiplexing hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3] [--pairs P]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (fused index extraction -> exact match -> min-phred gate ->
+molecular slice -> routing code + counters) over one batch of synthetic packed index rows that is
+already resident in HBM.  Workload at N=1: BASELINE.json configs[2] ("cfg3"): dual 8+8 bp index,
+96 samples, min-phred filter on, 100 M read-pairs -- the single-GPU configuration the metric
+(dual 8 bp index) is quoted on.  With N > 1 every rank processes its own 100 M-pair shard (weak
+scaling, no data-path collective) and the per-sample counts are summed with one RCCL all-reduce
+inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- algorithmic HBM bytes per launch / mean kernel time (HIP events on the launch
+                  stream) against the 8 TB/s HBM3E peak
+  cpu_baseline -- the CPU oracle (restated reference loop, 1 thread) timed on this host on a
+                  bounded sample of the same workload (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(w_cpu_rows, plan, layout, barcodes, hip_codes, sample_pairs):
+    """Times oracle.demux_reads (pure-Python restatement of src/Quade.py:210-221 +
+    src/Sample.py:56-91, one thread) on the first `sample_pairs` pairs of the GPU workload and
+    checks the GPU's codes against it."""
+    import numpy as np
+    from oracle import quade_oracle as qo
+
+    n = sample_pairs
+    reads = []
+    for k in range(layout.n_streams):
+        srows, qrows = w_cpu_rows["seq"][k], w_cpu_rows["qual"][k]
+        sw, qw = layout.seq_width[k], layout.qual_width[k]
+        sb = srows[:, :sw].tobytes().decode("latin-1")
+        seqs = [sb[i * sw:(i + 1) * sw] for i in range(n)]
+        qb = qrows[:, :qw].tobytes().decode("latin-1")
+        pad = "I" * (sw - qw)
+        quals = [qb[i * qw:(i + 1) * qw] + pad for i in range(n)]
+        reads += [seqs, quals]
+    if layout.n_streams == 1:
+        reads += [None, None]
+    samples = [("S%d" % i, b) for i, b in enumerate(barcodes)]
+    t0 = time.perf_counter()
+    codes, _idx, _mol, _counts = qo.demux_reads(
+        samples, plan.min_qual, (plan.idx1_start, plan.idx1_end), (plan.idx2_start, plan.idx2_end),
+        (plan.mol1_start, plan.mol1_end), (plan.mol2_start, plan.mol2_end), bool(plan.dual), *reads)
+    dt = time.perf_counter() - t0
+    ok = bool((np.array(codes, dtype=np.uint16) == hip_codes[:n]).all())
+    return {"value": n / dt, "unit": "read-pairs/s", "cores": 1, "kind": "port",
+            "sample": "first %d pairs of the same workload, oracle.quade_oracle.demux_reads "
+                      "(pure-Python per-read loop, %.1f s)" % (n, dt),
+            "matches_gpu_codes": ok}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the config's single-GPU share)")
+    ap.add_argument("--cpu-sample", type=int, default=5_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from quade_amd import synth
+    from quade_amd.hip_backend import Engine
+    from quade_amd.dist import allreduce_counts
+
+    cfg = synth.CONFIGS[args.config]
+    per_gpu_default = {"cfg2": 10_000_000, "cfg3": 100_000_000, "cfg4": 62_500_000, "cfg5": 125_000_000}
+    n = args.pairs or per_gpu_default[args.config]
+
+    t_gen = time.perf_counter()
+    w = synth.generate(args.config, n, seed=20260000 + int(args.config[3:]) + 1000 * rank, device="cuda")
+    torch.cuda.synchronize()
+    log("[rank %d] generated %d pairs of %s on the GPU in %.1f s" % (rank, n, args.config, time.perf_counter() - t_gen))
+
+    eng = Engine(local_rank)
+    lay = eng.set_plan(w.plan)
+    eng.set_barcodes(w.barcode_strings())
+    kind = eng.kernel_kind(False)
+    M = lay.mol_width
+    codes = torch.empty(n, dtype=torch.int16, device="cuda")
+    mol = torch.empty((n, max(M, 1)), dtype=torch.uint8, device="cuda")
+    seq_p = [t.data_ptr() for t in w.seq]
+    qual_p = [t.data_ptr() for t in w.qual]
+    # a non-default stream: its handle is what the library launches on, and the HIP events below
+    # are recorded on the same stream (the default stream's handle is NULL = "context's own")
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+
+    def step():
+        eng.demux_device(n, seq_p, qual_p, codes.data_ptr(), mol.data_ptr() if M else None,
+                         stream=stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    eng.reset_counts()
+
+    # ---- timed region: barrier + sync on both sides, exactly K steps, then the count reduce
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        step()
+        ev[i][1].record(stream)
+    counts = eng.counts()                      # waits for the device, sums the partial rows
+    total_counts = allreduce_counts(counts, dist, device=torch.device("cuda", local_rank)) if dist else counts
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_ms_mean = float(np.mean(kern_ms))
+
+    # ---- verification outside the timed region (every pair, by construction; counts identities)
+    verified = None
+    if not args.no_verify:
+        got = codes.view(torch.int16).to(torch.int32) & 0xFFFF
+        same = bool(torch.equal(got, w.expected))
+        S = cfg["S"]
+        exp_hist = torch.bincount(w.expected[w.expected != 0xFFFF].to(torch.int64), minlength=2 * S).cpu().numpy()
+        c = counts.astype(np.int64)
+        ok_counts = bool((c[4:] == exp_hist * args.steps).all()) and c[0] == n * args.steps and \
+            c[0] == c[1] + c[2] + c[3]
+        verified = bool(same and ok_counts)
+        if not verified:
+            log("VERIFICATION FAILED: codes_equal=%s counts_ok=%s" % (same, ok_counts))
+        if dist:
+            assert int(total_counts[0]) == n * args.steps * world
+
+    algo_bytes = synth.ALGO_BYTES[args.config]
+    achieved = n * algo_bytes / (kern_ms_mean * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+    if os.path.exists(tfile):
+        with open(tfile) as fh:
+            tj = json.load(fh)
+        if tj.get("n_pairs") == n:
+            traffic = tj.get("hbm_bytes_per_launch")
+
+    out = {
+        "metric": "read-pairs/sec demultiplexed (2x150 bp, dual 8 bp index)",
+        "value": world * n * args.steps / elapsed,
+        "unit": "read-pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s: %s 8 bp index, %d samples, minimal_qual %d%s, %d read-pairs per GPU; packed index "
+                        "rows resident in HBM; codes%s + counts out" % (
+                            args.config, "dual 8+8" if cfg["dual"] else "single", cfg["S"], cfg["min_qual"],
+                            ", molecular 6+6" if cfg["mol"] else "", n, " + molecular bytes" if M else ""),
+            "pairs_per_gpu": n, "kernel": "demux_" + kind, "sharding": "pairs split across ranks, RCCL all-reduce of counts",
+        },
+        "verified": verified,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "kernel_ms": kern_ms_mean, "algorithmic_bytes_per_pair": algo_bytes},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        ns = min(args.cpu_sample, n)
+        rows = {"seq": [t[:ns].cpu().numpy() for t in w.seq], "qual": [t[:ns].cpu().numpy() for t in w.qual]}
+        hip_codes = codes[:ns].cpu().numpy().view(np.uint16)
+        out["cpu_baseline"] = cpu_baseline(rows, w.plan, lay, w.barcode_strings(), hip_codes, ns)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist:
+        dist.destroy_process_group()
+    if verified is False:
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

@@ -139,12 +139,16 @@ int qd_demux_device(qd_ctx* ctx, int64_t n_pairs, const qd_rows* rows, uint16_t*
  * 2 = generic.  Informational (tests, bench). */
 int qd_kernel_kind(const qd_ctx* ctx, int has_len);
 
+/* Tuning / test knobs (no reference counterpart).  Names:
+ *   "fast_workgroups_per_cu"  0 = as many as the occupancy query admits (default), 1..8 = fixed
+ *   "force_generic"           1 = always launch the generic kernel */
+int qd_set_option(qd_ctx* ctx, const char* name, int64_t value);
+
 /* ---- counters: replace the class counters of src/Sample.py:32,144 and feed Sample.REPORT ---------
  * qd_get_counts waits for outstanding work of this context, then writes 2*S+4 values. */
 int qd_get_counts(qd_ctx* ctx, uint64_t* out, int32_t n_values);
 int qd_reset_counts(qd_ctx* ctx);
-/* Adds externally reduced counts (e.g. the RCCL all-reduce result of other ranks) -- unused by
- * single-GPU runs.  n_values = 2*S+4. */
+/* Waits for every outstanding launch / copy of this context's device. */
 int qd_synchronize(qd_ctx* ctx);
 
 /* ---- host-staged streaming: pinned slots, H2D || kernel || D2H -------------------------------------
@@ -190,6 +194,27 @@ int64_t qd_pack_index_fastq(const qd_layout* layout, int32_t k, const uint8_t* t
 int qd_pack_index_reads(const qd_layout* layout, int32_t k, int64_t n, const uint8_t* seq,
                         const uint8_t* qual, const int64_t* offsets, uint8_t* seq_rows,
                         uint8_t* qual_rows, uint8_t* len_rows, int32_t* all_full);
+
+/* ---- host helpers: routed records -> output text (replace FastqWriter.__call__'s formatting) --------
+ * qd_build_tags: the name suffix of every pair, ":IDX" or ":IDX:MOL" (src/FastqWriter.py:61-66):
+ * IDX = fused barcode slice as read (NOT case folded), MOL = fused molecular slice; ":MOL" is
+ * omitted when the molecular slice is empty (empty molecular index is falsy).  Slices
+ * are clamped to the read length when len rows are given.  mol_rows (optional): the molecular
+ * bytes written by the device (n x mol_width); when NULL they are sliced from seq_rows on the
+ * host -- both give the same bytes.  tag row r = tag_rows + r*tag_stride,
+ * tag_stride >= 2 + key_width + mol_width; tag_len[r] = bytes used. */
+int qd_build_tags(const qd_layout* layout, const qd_plan* plan, int64_t n, const uint8_t* const seq_rows[2],
+                  const uint8_t* const len_rows[2], const uint8_t* mol_rows, uint8_t* tag_rows,
+                  int32_t tag_stride, uint8_t* tag_len);
+
+/* qd_format_records: for the n_sel records sel[0..n_sel) (indices into rec_off, input order) of
+ * fastq `text`, writes "@" + name + tag + "\n" + seq + "\n+\n" + qual + "\n" -- the record format
+ * of the reference's output (src/FastqWriter.py:68-69 via FastqSeq.fastqstr; pinned by the bundled
+ * goldens): name = header line without its first byte, cut at the first ASCII whitespace.
+ * Returns bytes written, or -(bytes needed) when out_cap is too small. */
+int64_t qd_format_records(const uint8_t* text, const int64_t* rec_off, const int64_t* sel, int64_t n_sel,
+                          const uint8_t* tag_rows, int32_t tag_stride, const uint8_t* tag_len, uint8_t* out,
+                          int64_t out_cap);
 
 #ifdef __cplusplus
 }

@@ -109,4 +109,91 @@ int qd_pack_index_reads(const qd_layout* L, int32_t k, int64_t n, const uint8_t*
     return QD_OK;
 }
 
+int qd_build_tags(const qd_layout* L, const qd_plan* P, int64_t n, const uint8_t* const seq_rows[2],
+                  const uint8_t* const len_rows[2], const uint8_t* mol_rows, uint8_t* tag_rows, int32_t tag_stride,
+                  uint8_t* tag_len) {
+    if (!L || !P || n < 0 || !seq_rows || !tag_rows || !tag_len) return QD_ERR_INVALID;
+    if (tag_stride < 2 + L->key_width + L->mol_width || 2 + L->key_width + L->mol_width > 255) return QD_ERR_INVALID;
+    const int is[2] = {P->idx1_start, P->idx2_start}, ie[2] = {P->idx1_end, P->idx2_end};
+    const int ms[2] = {P->mol1_start, P->mol2_start}, me[2] = {P->mol1_end, P->mol2_end};
+    for (int k = 0; k < L->n_streams; ++k)
+        if (!seq_rows[k]) return QD_ERR_INVALID;
+    for (int64_t r = 0; r < n; ++r) {
+        uint8_t* t = tag_rows + r * tag_stride;
+        int o = 0;
+        t[o++] = ':';
+        for (int k = 0; k < L->n_streams; ++k) {  // IDX: I1 part then I2 part (Quade.py:217)
+            const int len = (len_rows && len_rows[k]) ? len_rows[k][r] : 0x7FFFFFFF;
+            const uint8_t* row = seq_rows[k] + r * L->seq_stride[k];
+            const int e = ie[k] < len ? ie[k] : len;
+            for (int c = is[k]; c < e; ++c) t[o++] = row[c - L->seq_off[k]];
+        }
+        const int mark = o;
+        t[o++] = ':';
+        int mo = 0;  // bytes of the device's mol row consumed so far
+        for (int k = 0; k < L->n_streams; ++k) {  // MOL (Quade.py:218)
+            const int len = (len_rows && len_rows[k]) ? len_rows[k][r] : 0x7FFFFFFF;
+            const uint8_t* row = seq_rows[k] + r * L->seq_stride[k];
+            const int e = me[k] < len ? me[k] : len;
+            for (int c = ms[k]; c < e; ++c) t[o++] = mol_rows ? mol_rows[r * L->mol_width + mo++] : row[c - L->seq_off[k]];
+        }
+        if (o == mark + 1) o = mark;  // empty molecular index: ":IDX" only
+        tag_len[r] = (uint8_t)o;
+    }
+    return QD_OK;
+}
+
+int64_t qd_format_records(const uint8_t* text, const int64_t* rec_off, const int64_t* sel, int64_t n_sel,
+                          const uint8_t* tag_rows, int32_t tag_stride, const uint8_t* tag_len, uint8_t* out,
+                          int64_t out_cap) {
+    if (!text || !rec_off || (!sel && n_sel) || n_sel < 0 || !tag_rows || !tag_len || (!out && out_cap)) return QD_ERR_INVALID;
+    int64_t need = 0;
+    for (int64_t i = 0; i < n_sel; ++i) {
+        const int64_t r = sel[i];
+        need += (rec_off[r + 1] - rec_off[r]) + tag_len[r] + 8;  // upper bound per record
+    }
+    if (need > out_cap) return -need;
+    int64_t o = 0;
+    for (int64_t i = 0; i < n_sel; ++i) {
+        const int64_t r = sel[i];
+        const uint8_t* p = text + rec_off[r];
+        const uint8_t* end = text + rec_off[r + 1];
+        // line 1: header
+        const uint8_t* nl = (const uint8_t*)memchr(p, '\n', (size_t)(end - p));
+        if (!nl) return QD_ERR_FORMAT;
+        const uint8_t* h = p + (nl > p ? 1 : 0);  // drop the first byte ('@')
+        auto is_ws = [](uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); };
+        while (h < nl && is_ws(*h)) ++h;  // str.split() semantics: leading blanks are skipped
+        const uint8_t* he = h;
+        while (he < nl && !is_ws(*he)) ++he;
+        out[o++] = '@';
+        memcpy(out + o, h, (size_t)(he - h));
+        o += he - h;
+        memcpy(out + o, tag_rows + r * tag_stride, tag_len[r]);
+        o += tag_len[r];
+        out[o++] = '\n';
+        // line 2: sequence
+        const uint8_t* s0 = nl + 1;
+        const uint8_t* s1 = (const uint8_t*)memchr(s0, '\n', (size_t)(end - s0));
+        if (!s1) return QD_ERR_FORMAT;
+        const uint8_t* se = (s1 > s0 && s1[-1] == '\r') ? s1 - 1 : s1;
+        memcpy(out + o, s0, (size_t)(se - s0));
+        o += se - s0;
+        out[o++] = '\n';
+        out[o++] = '+';
+        out[o++] = '\n';
+        // line 3: separator (dropped), line 4: quality
+        const uint8_t* p3 = (const uint8_t*)memchr(s1 + 1, '\n', (size_t)(end - (s1 + 1)));
+        if (!p3) return QD_ERR_FORMAT;
+        const uint8_t* q0 = p3 + 1;
+        const uint8_t* q1 = (const uint8_t*)memchr(q0, '\n', (size_t)(end - q0));
+        if (!q1) return QD_ERR_FORMAT;
+        const uint8_t* qe = (q1 > q0 && q1[-1] == '\r') ? q1 - 1 : q1;
+        memcpy(out + o, q0, (size_t)(qe - q0));
+        o += qe - q0;
+        out[o++] = '\n';
+    }
+    return o;
+}
+
 }  // extern "C"

@@ -57,7 +57,8 @@ struct qd_ctx {
     bool fast_ok = false;
     uint32_t lds_bk_off = 0, lds_hist_off = 0;
     size_t lds_bytes = 0;
-    int blocks_per_cu = 1;
+    int opt_wg_per_cu = 0;    // 0 = occupancy query
+    int opt_force_generic = 0;
 
     // counters
     u64* d_partial = nullptr;
@@ -201,10 +202,9 @@ int rebuild(qd_ctx* c) {
         ok = ok && mw <= 8 && L.qual_width[k] <= 8;
     }
     c->fast_ok = ok;
-    c->blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / QD_FAST_BLOCK, (160 * 1024) / std::max<size_t>(c->lds_bytes, 1)));
 
     c->cnt_stride = (uint32_t)((2 * S + 1 + 3) & ~3);
-    c->partial_rows = (uint32_t)c->cu * 4;
+    c->partial_rows = (uint32_t)c->cu * 8;
     HIPCHK(c, hipMalloc(&c->d_partial, (size_t)c->partial_rows * c->cnt_stride * 8));
     HIPCHK(c, hipMalloc(&c->d_counts, (size_t)c->cnt_stride * 8));
     HIPCHK(c, hipMemset(c->d_partial, 0, (size_t)c->partial_rows * c->cnt_stride * 8));
@@ -264,7 +264,7 @@ int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* 
     if (!codes || !aligned16(codes)) return fail(c, QD_ERR_INVALID, "codes buffer NULL or not 16-byte aligned");
     if (L.mol_width > 0 && (!mol || !aligned16(mol)))
         return fail(c, QD_ERR_INVALID, "mol buffer NULL or not 16-byte aligned");
-    const bool fast = c->fast_ok && !has_len;
+    const bool fast = c->fast_ok && !has_len && !c->opt_force_generic;
     DemuxParams p;
     fill_params(c, p, fast);
     for (int k = 0; k < L.n_streams; ++k) {
@@ -277,10 +277,7 @@ int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* 
     p.n = n;
     hipError_t e;
     if (fast) {
-        const int64_t tile = qd_fast_tile_pairs();
-        const int64_t ntiles = (n + tile - 1) / tile;
-        const int grid = (int)std::min<int64_t>(ntiles, (int64_t)c->cu * c->blocks_per_cu);
-        e = qd_launch_fast(p, grid, c->lds_bytes, st);
+        e = qd_launch_fast(p, c->cu, c->opt_wg_per_cu, c->lds_bytes, st);
     } else {
         const int64_t nb = (n + QD_GEN_BLOCK - 1) / QD_GEN_BLOCK;
         const int grid = (int)std::min<int64_t>(nb, (int64_t)c->cu * 8);
@@ -436,7 +433,21 @@ int qd_set_barcodes(qd_ctx* c, int32_t S, const uint8_t* barcodes, const int32_t
 
 int qd_kernel_kind(const qd_ctx* c, int has_len) {
     if (!c || !c->have_table) return QD_ERR_STATE;
-    return (c->fast_ok && !has_len) ? 1 : 2;
+    return (c->fast_ok && !has_len && !c->opt_force_generic) ? 1 : 2;
+}
+
+int qd_set_option(qd_ctx* c, const char* name, int64_t value) {
+    if (!c || !name) return QD_ERR_INVALID;
+    if (!strcmp(name, "fast_workgroups_per_cu")) {
+        if (value < 0 || value > 64) return fail(c, QD_ERR_INVALID, "fast_workgroups_per_cu must be 0..64");
+        c->opt_wg_per_cu = (int)value;
+        return QD_OK;
+    }
+    if (!strcmp(name, "force_generic")) {
+        c->opt_force_generic = value != 0;
+        return QD_OK;
+    }
+    return fail(c, QD_ERR_INVALID, std::string("unknown option ") + name);
 }
 
 int qd_demux_device(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* mol, void* stream) {

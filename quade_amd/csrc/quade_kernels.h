@@ -6,8 +6,12 @@
 #define QD_CODE_UNDET 0xFFFFu
 #define QD_MAX_KEY_BYTES 32
 
+#ifndef QD_FAST_BLOCK
 #define QD_FAST_BLOCK 512  /* threads per workgroup, fast kernel      */
+#endif
+#ifndef QD_FAST_UNITS
 #define QD_FAST_UNITS 2    /* 2-pair units per lane per tile          */
+#endif
 #define QD_GEN_BLOCK 256
 
 struct DemuxParams {
@@ -37,7 +41,8 @@ struct DemuxParams {
 };
 
 int64_t qd_fast_tile_pairs();
-hipError_t qd_launch_fast(const DemuxParams& p, int grid, size_t lds_bytes, hipStream_t st);
+// wg_per_cu <= 0: as many workgroups per CU as the occupancy query admits
+hipError_t qd_launch_fast(const DemuxParams& p, int cus, int wg_per_cu, size_t lds_bytes, hipStream_t st);
 hipError_t qd_launch_generic(const DemuxParams& p, int grid, hipStream_t st);
 hipError_t qd_launch_reduce(const uint64_t* partial, uint32_t rows, uint32_t cnt_stride,
                             uint32_t ncnt, uint64_t* out, hipStream_t st);

@@ -353,16 +353,29 @@ __global__ void reduce_partials(const u64* partial, uint32_t rows, uint32_t cnt_
 }
 
 template <int SS1, int SS2, bool DUAL>
-hipError_t launch_fast_t(const DemuxParams& p, int grid, size_t lds, hipStream_t st) {
+hipError_t launch_fast_t(const DemuxParams& p, int cus, int wg_per_cu, int64_t ntiles, size_t lds, hipStream_t st) {
     auto k = demux_fast<SS1, SS2, DUAL, QD_FAST_UNITS>;
     static bool attr_set = false;  // per instantiation
+    static size_t occ_lds = ~(size_t)0;
+    static int occ_blocks = 1;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(QD_FAST_BLOCK), lds, st, p);
+    if (occ_lds != lds) {
+        // persistent grid: exactly the workgroups that are co-resident (registers, LDS), so every
+        // workgroup strides over the same number of tiles and there is no second dispatch round
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, QD_FAST_BLOCK, lds);
+        if (e != hipSuccess) return e;
+        occ_blocks = nb < 1 ? 1 : nb;
+        occ_lds = lds;
+    }
+    int64_t grid = (int64_t)cus * (wg_per_cu > 0 ? wg_per_cu : occ_blocks);
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(QD_FAST_BLOCK), lds, st, p);
     return hipGetLastError();
 }
 
@@ -370,16 +383,18 @@ hipError_t launch_fast_t(const DemuxParams& p, int grid, size_t lds, hipStream_t
 
 int64_t qd_fast_tile_pairs() { return (int64_t)QD_FAST_BLOCK * 2 * QD_FAST_UNITS; }
 
-hipError_t qd_launch_fast(const DemuxParams& p, int grid, size_t lds_bytes, hipStream_t st) {
+hipError_t qd_launch_fast(const DemuxParams& p, int cus, int wg_per_cu, size_t lds_bytes, hipStream_t st) {
     const int ss1 = p.seq_stride[0], ss2 = p.seq_stride[1];
+    const int64_t tile = qd_fast_tile_pairs();
+    const int64_t nt = (p.n + tile - 1) / tile;
     if (p.n_streams == 1) {
-        if (ss1 == 8) return launch_fast_t<8, 8, false>(p, grid, lds_bytes, st);
-        return launch_fast_t<16, 8, false>(p, grid, lds_bytes, st);
+        if (ss1 == 8) return launch_fast_t<8, 8, false>(p, cus, wg_per_cu, nt, lds_bytes, st);
+        return launch_fast_t<16, 8, false>(p, cus, wg_per_cu, nt, lds_bytes, st);
     }
-    if (ss1 == 8 && ss2 == 8) return launch_fast_t<8, 8, true>(p, grid, lds_bytes, st);
-    if (ss1 == 8 && ss2 == 16) return launch_fast_t<8, 16, true>(p, grid, lds_bytes, st);
-    if (ss1 == 16 && ss2 == 8) return launch_fast_t<16, 8, true>(p, grid, lds_bytes, st);
-    return launch_fast_t<16, 16, true>(p, grid, lds_bytes, st);
+    if (ss1 == 8 && ss2 == 8) return launch_fast_t<8, 8, true>(p, cus, wg_per_cu, nt, lds_bytes, st);
+    if (ss1 == 8 && ss2 == 16) return launch_fast_t<8, 16, true>(p, cus, wg_per_cu, nt, lds_bytes, st);
+    if (ss1 == 16 && ss2 == 8) return launch_fast_t<16, 8, true>(p, cus, wg_per_cu, nt, lds_bytes, st);
+    return launch_fast_t<16, 16, true>(p, cus, wg_per_cu, nt, lds_bytes, st);
 }
 
 hipError_t qd_launch_generic(const DemuxParams& p, int grid, hipStream_t st) {

@@ -66,6 +66,7 @@ SYMBOLS = [
     ("qd_set_barcodes", C.c_int, [_P, C.c_int32, _P, _P]),
     ("qd_demux_device", C.c_int, [_P, C.c_int64, C.POINTER(qd_rows), _P, _P, _P]),
     ("qd_kernel_kind", C.c_int, [_P, C.c_int]),
+    ("qd_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("qd_get_counts", C.c_int, [_P, _P, C.c_int32]),
     ("qd_reset_counts", C.c_int, [_P]),
     ("qd_synchronize", C.c_int, [_P]),
@@ -79,6 +80,9 @@ SYMBOLS = [
                                         C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     ("qd_pack_index_reads", C.c_int, [C.POINTER(qd_layout), C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P,
                                       C.POINTER(C.c_int32)]),
+    ("qd_build_tags", C.c_int, [C.POINTER(qd_layout), C.POINTER(qd_plan), C.c_int64, C.POINTER(_P), C.POINTER(_P), _P,
+                                _P, C.c_int32, _P]),
+    ("qd_format_records", C.c_int64, [_P, _P, _P, C.c_int64, _P, C.c_int32, _P, _P, C.c_int64]),
 ]
 
 _lib = None
@@ -89,7 +93,8 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    default = path is None
+    path = path or os.environ.get("QUADE_HIP_LIB") or LIB_PATH
     if not os.path.exists(path):
         raise ImportError(
             "%s not found: build it first (python -c 'import __graft_entry__ as g; g.build()' or "
@@ -99,7 +104,8 @@ def load_library(path=None):
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = restype
         fn.argtypes = argtypes
-    _lib = lib
+    if default:
+        _lib = lib
     return lib
 
 
@@ -178,13 +184,45 @@ def pack_index_reads(layout: qd_layout, k: int, seqs, quals):
     return seq_rows, qual_rows, len_rows, bool(full.value)
 
 
+def build_tags(layout: qd_layout, plan: qd_plan, n, seq_rows, len_rows=None, mol_rows=None):
+    """Name suffixes ':IDX[:MOL]' of n pairs -> (tag_rows uint8 [n, stride], tag_len uint8 [n]).
+    mol_rows: the device's molecular output (n x mol_width), used for the MOL part when given."""
+    lib = load_library()
+    stride = 2 + layout.key_width + layout.mol_width
+    tags = np.empty((max(n, 1), stride), dtype=np.uint8)
+    tlen = np.empty(max(n, 1), dtype=np.uint8)
+    sp = (_P * 2)(*[_ptr(seq_rows[k]) if k < len(seq_rows) else None for k in range(2)])
+    lp = (_P * 2)(*[(_ptr(len_rows[k]) if len_rows and k < len(len_rows) else None) for k in range(2)])
+    r = lib.qd_build_tags(C.byref(layout), C.byref(plan), int(n), sp, lp,
+                          _ptr(mol_rows) if layout.mol_width else None, _ptr(tags), stride, _ptr(tlen))
+    if r != QD_OK:
+        raise QuadeHipError(r, lib.qd_strerror(r).decode())
+    return tags[:n], tlen[:n]
+
+
+def format_records(text, rec_off, sel, tags, tag_len):
+    """Output text (bytes) of the records `sel` (int64 indices) of `text` with their name tags."""
+    lib = load_library()
+    buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else text
+    sel = np.ascontiguousarray(sel, dtype=np.int64)
+    if sel.size == 0:
+        return b""
+    cap = int((rec_off[sel + 1] - rec_off[sel]).sum() + tag_len[sel].astype(np.int64).sum() + 8 * sel.size)
+    out = np.empty(cap, dtype=np.uint8)
+    n = lib.qd_format_records(_ptr(buf), _ptr(rec_off), _ptr(sel), sel.size, _ptr(tags), tags.shape[1],
+                              _ptr(tag_len), _ptr(out), cap)
+    if n < 0:
+        raise QuadeHipError(int(n), "qd_format_records failed")
+    return out[:n].tobytes()
+
+
 # ---- device context -------------------------------------------------------------------------------------
 class Engine(object):
     """One libquade_hip context = one MI355X.  Mirrors what Sample.CLASS_INIT + Sample(name, index)
     configure in the reference (src/Sample.py:48-54,132-153) and runs FINDER for whole batches."""
 
-    def __init__(self, device_id=0):
-        self.lib = load_library()
+    def __init__(self, device_id=0, lib_path=None):
+        self.lib = load_library(lib_path)
         h = C.c_void_p()
         r = self.lib.qd_create(int(device_id), C.byref(h))
         if r != QD_OK:
@@ -241,6 +279,9 @@ class Engine(object):
         blob = np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8)
         self._chk(self.lib.qd_set_barcodes(self._h, len(bs), _ptr(blob), _ptr(offs)))
         self.n_samples = len(bs)
+
+    def set_option(self, name, value):
+        self._chk(self.lib.qd_set_option(self._h, name.encode(), int(value)))
 
     def kernel_kind(self, has_len=False):
         return {1: "fast", 2: "generic"}[self.lib.qd_kernel_kind(self._h, int(has_len))]

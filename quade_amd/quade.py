@@ -1,0 +1,190 @@
+# -*- coding: utf-8 -*-
+"""
+Quade driver and command line: `Quade.py -c Conf.txt [-i -h]` of the reference
+(src/Quade.py:45-66, 169-193, 290-293), with the per-read loops of double_index_parser /
+simple_index_parser (src/Quade.py:195-254) replaced by a batch pipeline:
+
+    4 (or 3) fastq streams --scan/pack (native)--> pinned slot --H2D--> demux kernel (gfx950)
+        --D2H--> routing codes + molecular bytes --> per-destination gzip members, input order
+
+Several batches are in flight (one per pinned slot, round-robin over the configured GPUs); results
+are consumed in batch order, so every output file keeps the input order (chunk order, then read
+order) exactly as the reference's sequential loop does.
+"""
+from __future__ import annotations
+
+import optparse
+import sys
+from collections import deque
+from datetime import datetime
+from time import time
+
+from . import QUADE_VERSION
+from . import hip_backend as hb
+from .conf import QuadeConf, write_example_conf
+from .fastq_reader import FastqStream
+from .sample import Batch, Sample
+
+import configparser
+
+
+class Quade(object):
+    """Fastq file demultiplexer, handling double indexing, molecular indexing and filtering based
+    on index quality -- MI355X-native hot path."""
+
+    VERSION = QUADE_VERSION
+    USAGE = "Usage: %prog -c Conf.txt [-i -h]"
+
+    @classmethod
+    def class_init(cls, argv=None):
+        """Instantiate from the command line (src/Quade.py:50-66)."""
+        optparser = optparse.OptionParser(usage=cls.USAGE, version=cls.VERSION)
+        optparser.add_option('-c', dest="conf_file", help="Path to the configuration file [Mandatory]")
+        optparser.add_option('-i', dest="init_conf", action='store_true',
+                             help="Generate an example configuration file and exit [Facultative]")
+        options, args = optparser.parse_args(argv)
+        return cls(options.conf_file, options.init_conf)
+
+    def __init__(self, conf_file=None, init_conf=None, outdir="."):
+        if init_conf:
+            print("Create an example configuration file in the current folder")
+            write_example_conf()
+            sys.exit(0)
+
+        print("Initialize Quade")
+        try:
+            self.cf = QuadeConf(conf_file)
+            Sample.RESET()
+            Sample.CLASS_INIT(write_undetermined=self.cf.write_undetermined, write_pass=self.cf.write_pass,
+                              write_fail=self.cf.write_fail, min_qual=self.cf.minimal_qual, outdir=outdir,
+                              gzip_level=self.cf.gzip_level)
+            for name, index in self.cf.samples:
+                Sample(name=name, index=index)
+        # same three families of errors, same messages, exit status 1 (src/Quade.py:145-153)
+        except (configparser.NoOptionError, configparser.NoSectionError) as E:
+            print("Option or section missing. Report to the template configuration file\n" + E.message)
+            sys.exit(1)
+        except (ValueError, AssertionError) as E:
+            print("One of the value in the configuration file is not correct\n" + str(E))
+            sys.exit(1)
+        except (IOError) as E:
+            print("One of the file is incorrect or unreadable\n" + str(E))
+            sys.exit(1)
+        self.outdir = outdir
+        self.engines = []
+
+    def __repr__(self):
+        return "<Instance of {} from {} >\n".format(self.__class__.__name__, self.__module__)
+
+    # ~~~~~~~ PUBLIC METHODS ~~~~~~~ #
+    def __call__(self):
+        """Main function of the script (src/Quade.py:169-193)"""
+        start_time = time()
+        cf = self.cf
+        devices = cf.devices
+        if devices == ["all"]:
+            import torch  # only to count devices; nothing else of torch is used on this path
+            devices = list(range(torch.cuda.device_count()))
+        plan = cf.plan()
+        for d in devices:
+            eng = hb.Engine(int(d))  # raises when libquade_hip.so or the GPU is missing: no fallback
+            eng.set_plan(plan)
+            eng.set_barcodes(Sample.BARCODES())
+            eng.slots_create(cf.slots, cf.batch_pairs)
+            self.engines.append(eng)
+        self.plan, self.layout = plan, self.engines[0].layout
+
+        print("Start parsing files: {} chunks to be parsed".format(len(cf.seq_R1)))
+        if cf.idx2:
+            self.double_index_parser()
+        else:
+            self.simple_index_parser()
+
+        counts = None
+        for eng in self.engines:
+            c = eng.counts()
+            counts = c if counts is None else counts + c
+        Sample.SET_COUNTS(counts)
+        Sample.FLUSH_ALL()
+        for eng in self.engines:
+            eng.close()
+        self.engines = []
+
+        print("Generate_a csv report")
+        import os
+        with open(os.path.join(self.outdir, "Quade_report.csv"), "w") as report:
+            report.write("Program {}\tDate {}\n\n".format(self.VERSION, str(datetime.today())))
+            for descr, value in Sample.REPORT():
+                report.write("{}\t{}\n".format(descr, value))
+        print("Done in {}s".format(round(time() - start_time, 3)))
+        return 0
+
+    def double_index_parser(self):
+        cf = self.cf
+        for n, files in enumerate(zip(cf.seq_R1, cf.seq_R2, cf.index_R1, cf.index_R2)):
+            print("Start parsing chunk {}".format(n + 1))
+            self._parse_chunk(files)
+            print("\tEnd of chunk {}".format(n + 1))
+
+    def simple_index_parser(self):
+        cf = self.cf
+        for n, files in enumerate(zip(cf.seq_R1, cf.seq_R2, cf.index_R1)):
+            print("Start parsing chunk {}/{}".format(n + 1, len(cf.seq_R1)))
+            self._parse_chunk(files)
+            print("\tEnd of chunk {}".format(n + 1))
+
+    # ~~~~~~~ PRIVATE METHODS ~~~~~~~ #
+    def _parse_chunk(self, files):
+        """One chunk = 3 or 4 files read in lock step; the chunk ends at the first exhausted
+        stream (src/Quade.py:210-224)."""
+        B = self.cf.batch_pairs
+        L = self.layout
+        streams = [FastqStream(f) for f in files]
+        r1s, r2s, idx = streams[0], streams[1], streams[2:]
+        inflight = deque()
+        b = 0
+        last = False
+        try:
+            while not last:
+                eng = self.engines[b % len(self.engines)]
+                slot = (b // len(self.engines)) % eng.n_slots
+                # the slot may still hold an older batch: consume in order until it is free
+                while any(e is eng and s == slot for e, s, *_ in inflight):
+                    self._finish(inflight.popleft())
+                v = eng.slot(slot)
+                r1_text, r1_off = r1s.take(B)
+                r2_text, r2_off = r2s.take(B)
+                counts = [r1_off.size - 1, r2_off.size - 1]
+                full = True
+                for k, st in enumerate(idx):
+                    nk, fk = st.take_packed(B, L, k, v["seq"][k], v["qual"][k], v["len"][k])
+                    counts.append(nk)
+                    full = full and fk
+                n = min(counts)
+                last = n < B
+                has_len = not full
+                eng.submit(slot, n, has_len)
+                inflight.append((eng, slot, n, has_len, r1_text, r1_off, r2_text, r2_off))
+                b += 1
+            while inflight:
+                self._finish(inflight.popleft())
+        finally:
+            for st in streams:
+                st.close()
+
+    def _finish(self, item):
+        eng, slot, n, has_len, r1_text, r1_off, r2_text, r2_off = item
+        eng.wait(slot)
+        v = eng.slot(slot)
+        tags, tag_len = hb.build_tags(self.layout, self.plan, n, v["seq"], v["len"] if has_len else None,
+                                      mol_rows=v["mol"])
+        Sample.FINDER(Batch(n, r1_text, r1_off, r2_text, r2_off, v["codes"], tags, tag_len))
+
+
+def main(argv=None):
+    quade = Quade.class_init(argv)
+    return quade()
+
+
+if __name__ == '__main__':
+    sys.exit(main())

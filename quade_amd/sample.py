@@ -1,0 +1,179 @@
+# -*- coding: utf-8 -*-
+"""
+Sample registry, batch FINDER and report -- the Python face of the hot path.
+
+Mirrors the interface of the reference's Sample class (src/Sample.py): CLASS_INIT, Sample(name,
+index) with the same assertions and messages, FINDER, FLUSH_ALL, REPORT, class-level registries and
+counters (one run per process, RESET() for tests).  The difference is granularity: FINDER takes a
+whole batch whose routing codes were computed on the GPU by libquade_hip (there is no per-read
+Python matching here, and no CPU fallback); counters are the device's counters.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import hip_backend as hb
+from .fastq_writer import FastqWriter
+
+
+class Batch(object):
+    """What FINDER needs of one batch of n pairs: insert-read text + record offsets, routing codes,
+    name tags."""
+    __slots__ = ("n", "r1_text", "r1_off", "r2_text", "r2_off", "codes", "tags", "tag_len")
+
+    def __init__(self, n, r1_text, r1_off, r2_text, r2_off, codes, tags, tag_len):
+        self.n, self.r1_text, self.r1_off, self.r2_text, self.r2_off = n, r1_text, r1_off, r2_text, r2_off
+        self.codes, self.tags, self.tag_len = codes, tags, tag_len
+
+
+class Sample(object):
+    # Counters for the overall number of read at class level (src/Sample.py:32)
+    TOTAL = FAIL_QUAL = PASS_QUAL = UNDETERMINED = 0
+    WRITE_UNDETERMINED = WRITE_PASS = WRITE_FAIL = False
+    NAME_TO_SAMPLE = {}
+    INDEX_TO_SAMPLE = {}
+    SAMPLE_LIST = []
+    DNA = ["A", "T", "C", "G", "N"]
+    MIN_QUAL = 0
+    OUTDIR = "."
+    GZIP_LEVEL = 6
+    UNDETERMINED_WRITER = None
+
+    # ~~~~~~~ CLASS METHODS ~~~~~~~ #
+    @classmethod
+    def RESET(cls):
+        """Forget every sample and counter (the reference needs a fresh process for that)."""
+        cls.TOTAL = cls.FAIL_QUAL = cls.PASS_QUAL = cls.UNDETERMINED = 0
+        cls.NAME_TO_SAMPLE = {}
+        cls.INDEX_TO_SAMPLE = {}
+        cls.SAMPLE_LIST = []
+        cls.UNDETERMINED_WRITER = None
+
+    @classmethod
+    def CLASS_INIT(cls, write_undetermined=False, write_pass=False, write_fail=False, min_qual=0,
+                   outdir=".", gzip_level=6):
+        """src/Sample.py:48-54 (+ output directory and gzip level, defaulted)"""
+        cls.WRITE_UNDETERMINED = write_undetermined
+        cls.WRITE_PASS = write_pass
+        cls.WRITE_FAIL = write_fail
+        cls.MIN_QUAL = min_qual
+        cls.OUTDIR = outdir
+        cls.GZIP_LEVEL = gzip_level
+        cls.UNDETERMINED_WRITER = FastqWriter("Undetermined", outdir, gzip_level)
+
+    @classmethod
+    def BARCODES(cls):
+        """Upper-case barcodes in ordinal order: the table handed to qd_set_barcodes."""
+        return [s.index for s in cls.SAMPLE_LIST]
+
+    @classmethod
+    def FINDER(cls, batch: Batch):
+        """Route one batch (src/Sample.py:56-91 for every pair of it).  Codes: 0xFFFF undetermined,
+        2*ordinal pass, 2*ordinal+1 fail.  Within a destination the input order is kept."""
+        n = batch.n
+        if n == 0:
+            return
+        codes = np.asarray(batch.codes[:n])
+        order = np.argsort(codes, kind="stable")
+        sorted_codes = codes[order]
+        bounds = np.flatnonzero(np.diff(sorted_codes)) + 1
+        starts = np.concatenate(([0], bounds))
+        ends = np.concatenate((bounds, [n]))
+        for lo, hi in zip(starts, ends):
+            code = int(sorted_codes[lo])
+            if code == hb.CODE_UNDETERMINED:
+                if not cls.WRITE_UNDETERMINED:
+                    continue
+                writer = cls.UNDETERMINED_WRITER
+            else:
+                sample = cls.SAMPLE_LIST[code >> 1]
+                if code & 1:
+                    if not cls.WRITE_FAIL:
+                        continue
+                    writer = sample.fail_writer
+                else:
+                    if not cls.WRITE_PASS:
+                        continue
+                    writer = sample.pass_writer
+            sel = order[lo:hi]
+            writer(hb.format_records(batch.r1_text, batch.r1_off, sel, batch.tags, batch.tag_len),
+                   hb.format_records(batch.r2_text, batch.r2_off, sel, batch.tags, batch.tag_len), hi - lo)
+
+    @classmethod
+    def SET_COUNTS(cls, counts):
+        """Install the counter vector summed on the device(s): layout of include/quade_hip.h."""
+        c = [int(x) for x in counts]
+        assert len(c) == 2 * len(cls.SAMPLE_LIST) + 4
+        cls.TOTAL, cls.PASS_QUAL, cls.FAIL_QUAL, cls.UNDETERMINED = c[:4]
+        for i, s in enumerate(cls.SAMPLE_LIST):
+            s.pass_qual, s.fail_qual = c[4 + 2 * i], c[5 + 2 * i]
+
+    @classmethod
+    def COUNTS(cls):
+        out = [cls.TOTAL, cls.PASS_QUAL, cls.FAIL_QUAL, cls.UNDETERMINED]
+        for s in cls.SAMPLE_LIST:
+            out += [s.pass_qual, s.fail_qual]
+        return out
+
+    @classmethod
+    def FLUSH_ALL(cls):
+        """src/Sample.py:93-102; also closes the files"""
+        for sample in cls.SAMPLE_LIST:
+            sample.pass_writer.close()
+            sample.fail_writer.close()
+        if cls.UNDETERMINED_WRITER:
+            cls.UNDETERMINED_WRITER.close()
+
+    @classmethod
+    def REPORT(cls):
+        """src/Sample.py:104-128.  The reference is Python 2: `/` on ints floors, so the report
+        holds integer percentages (golden report: 100, 0, 82, 48, 51) -- `//` here."""
+        report = []
+        report.append(["Total pair", cls.TOTAL])
+        report.append(["Pair pass quality", cls.PASS_QUAL])
+        report.append(["Pair fail quality", cls.FAIL_QUAL])
+        report.append(["Pair Undetermined", cls.UNDETERMINED])
+        determined = cls.TOTAL - cls.UNDETERMINED
+        if determined > 0:
+            report.append(["Percent Pair pass quality (wo Undetermined)", cls.PASS_QUAL * 100 // determined])
+            report.append(["Percent Pair fail quality (wo Undetermined)", cls.FAIL_QUAL * 100 // determined])
+            report.append(["Percent Pair Undetermined", cls.UNDETERMINED * 100 // cls.TOTAL])
+        for sample in cls.SAMPLE_LIST:
+            report.append([" ", " "])
+            report.append(["Sample Name", sample.name])
+            report.append(["Total pair", sample.total])
+            report.append(["Pair pass quality", sample.pass_qual])
+            report.append(["Pair fail quality", sample.fail_qual])
+            if sample.total > 0:
+                report.append(["Percent of total pair", sample.total * 100 // determined])
+                report.append(["Percent Pair pass quality", sample.pass_qual * 100 // sample.total])
+                report.append(["Percent Pair fail quality", sample.fail_qual * 100 // sample.total])
+        return report
+
+    # ~~~~~~~ FUNDAMENTAL METHODS ~~~~~~~ #
+    def __init__(self, name, index):
+        """src/Sample.py:132-153: same checks, same order, same messages."""
+        self.name = name
+        self.index = index.upper()
+        cls = type(self)
+        assert self.name not in cls.NAME_TO_SAMPLE, "{} : Name is not unique".format(self.name)
+        assert self.index not in cls.INDEX_TO_SAMPLE, "{} : Index is not unique".format(self.name)
+        assert self._is_dna(index), "{} : Non canonical DNA base in index".format(self.name)
+        self.pass_qual = self.fail_qual = 0
+        self.ordinal = len(cls.SAMPLE_LIST)
+        self.pass_writer = FastqWriter("{}_pass".format(self.name), cls.OUTDIR, cls.GZIP_LEVEL)
+        self.fail_writer = FastqWriter("{}_fail".format(self.name), cls.OUTDIR, cls.GZIP_LEVEL)
+        cls.INDEX_TO_SAMPLE[self.index] = self
+        cls.NAME_TO_SAMPLE[self.name] = self
+        cls.SAMPLE_LIST.append(self)
+
+    @property
+    def total(self):
+        return self.pass_qual + self.fail_qual
+
+    def __repr__(self):
+        return "<Instance of {} from {} >\n".format(self.__class__.__name__, self.__module__)
+
+    def _is_dna(self, sequence):
+        # checked on the raw (not upper-cased) string: lower-case barcodes are rejected
+        return all(base in self.DNA for base in sequence)

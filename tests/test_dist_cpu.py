@@ -1,0 +1,44 @@
+"""N > 1 path on the CPU: world_size-2 gloo job, pairs sharded across ranks, counts all-reduced."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from quade_amd import synth
+from quade_amd.dist import allreduce_counts, shard_range
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions():
+    for n in [0, 1, 7, 8, 100, 12207]:
+        for world in [1, 2, 3, 8]:
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_allreduce_counts_single_process_is_identity():
+    c = np.array([5, 3, 1, 1, 2, 1], dtype=np.uint64)
+    assert (allreduce_counts(c) == c).all()
+
+
+def test_two_rank_gloo_count_reduce(tmp_path):
+    out = tmp_path / "res.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29617",
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(out.read_text())
+    w = synth.generate("cfg3", 4001, seed=99)
+    _, _, _, counts = H.oracle_on_workload(w)
+    assert res["world"] == 2
+    assert res["total"] == [int(x) for x in counts]
+    assert res["share0"] == [0, 2001]

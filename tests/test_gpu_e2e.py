@@ -1,0 +1,222 @@
+"""End to end on the GPU box: fastq(.gz) in -> per-sample fastq.gz + report out, through the CLI
+driver and the HIP library, compared byte for byte (decompressed) with (1) the reference's bundled
+golden outputs and (2) the CPU oracle's run of the same conf on generated fastq files."""
+import gzip
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from oracle import quade_oracle as qo
+
+pytestmark = pytest.mark.gpu
+
+
+def _gz(path):
+    with gzip.open(path, "rb") as fh:
+        return fh.read()
+
+
+def _run_cli(conf, workdir):
+    from quade_amd.quade import Quade
+    old = os.getcwd()
+    os.chdir(workdir)
+    try:
+        q = Quade(conf_file=conf)
+        assert q() == 0
+    finally:
+        os.chdir(old)
+
+
+def _compare_dirs(mine, ref):
+    fm = sorted(f for f in os.listdir(mine) if f.endswith(".fastq.gz"))
+    fr = sorted(f for f in os.listdir(ref) if f.endswith(".fastq.gz"))
+    assert fm == fr
+    for f in fr:
+        assert _gz(os.path.join(mine, f)) == _gz(os.path.join(ref, f)), f
+    with open(os.path.join(mine, "Quade_report.csv")) as fh:
+        a = fh.read().split("\n")
+    with open(os.path.join(ref, "Quade_report.csv")) as fh:
+        b = fh.read().split("\n")
+    assert a[0].startswith("Program Quade 0.3.2\tDate ")
+    assert a[1:] == b[1:]
+
+
+def test_bundled_golden_replay_through_hip(tmp_path, bundled_dir):
+    """BASELINE.json configs[0]: the reference's own test (README.md:67-72 of the reference)."""
+    work = tmp_path / "result"
+    work.mkdir()
+    shutil.copytree(os.path.join(bundled_dir, "dataset"), tmp_path / "dataset")
+    shutil.copy(os.path.join(bundled_dir, "result", "Quade_conf_file.txt"), work / "Quade_conf_file.txt")
+    _run_cli("Quade_conf_file.txt", str(work))
+    os.remove(work / "Quade_conf_file.txt")
+    from quade_amd.sample import Sample
+    assert Sample.COUNTS() == [299, 52, 0, 247, 25, 0, 27, 0]
+    _compare_dirs(str(work), os.path.join(bundled_dir, "result"))
+
+
+# ---- generated datasets ----------------------------------------------------------------------------
+def _write_fastq(path, names, seqs, quals, plus="+"):
+    with gzip.open(path, "wb") if str(path).endswith(".gz") else open(path, "wb") as fh:
+        for n, s, q in zip(names, seqs, quals):
+            fh.write(("@%s\n%s\n%s\n%s\n" % (n, s, plus, q)).encode("latin-1"))
+
+
+def _make_dataset(d, rng, n_chunks, n, dual, idx_len, barcodes, trunc=False, malformed=False, plain=False):
+    """barcodes: list of (b1, b2) expected at the start of index read 1 / 2."""
+    ext = ".fastq" if plain else ".fastq.gz"
+    files = {"seq_R1": [], "seq_R2": [], "index_R1": [], "index_R2": []}
+    for c in range(n_chunks):
+        names = ["SIM:1:FC:%d:%d:%d %d:N:0:" % (c, i, i * 7, 1) for i in range(n)]
+        def rnd(L):
+            return "".join(rng.choice(list("ACGT"), L))
+        def q(L, lo=30):
+            return "".join(chr(33 + int(v)) for v in rng.integers(lo, 41, L))
+        r1 = [rnd(30) for _ in range(n)]
+        r2 = [rnd(30) for _ in range(n)]
+        i1, i2, q1, q2 = [], [], [], []
+        for i in range(n):
+            b = barcodes[int(rng.integers(0, len(barcodes)))]
+            kind = int(rng.integers(0, 10))
+            parts = []
+            for k in range(2 if dual else 1):
+                s = b[k] + rnd(idx_len - len(b[k]))
+                if kind == 0:
+                    p = int(rng.integers(0, len(b[k])))
+                    s = s[:p] + "N" + s[p + 1:]
+                elif kind == 1:
+                    s = s.lower()
+                elif kind == 2:
+                    s = rnd(idx_len)
+                if trunc and rng.integers(0, 4) == 0:
+                    s = s[:int(rng.integers(0, idx_len))]
+                qq = q(len(s), lo=20 if rng.integers(0, 3) == 0 else 30)
+                parts.append((s, qq))
+            i1.append(parts[0][0]); q1.append(parts[0][1])
+            if dual:
+                i2.append(parts[1][0]); q2.append(parts[1][1])
+        qr1 = [q(30) for _ in range(n)]
+        qr2 = [q(30) for _ in range(n)]
+        if malformed and n > 5:
+            qr1[3] = qr1[3] + "I"        # R1 record 3 dropped -> R1 shifts against the others
+            q1[n // 2] = q1[n // 2][:-1] if q1[n // 2] else "I"  # an index record dropped
+        for key, (nm, ss, qs) in {"seq_R1": (names, r1, qr1), "seq_R2": (names, r2, qr2),
+                                  "index_R1": (names, i1, q1), "index_R2": (names, i2, q2)}.items():
+            if key == "index_R2" and not dual:
+                continue
+            p = os.path.join(d, "C%d_%s%s" % (c, key, ext))
+            _write_fastq(p, nm, ss, qs, plus="+" if c % 2 == 0 else "+" + "x")
+            files[key].append(p)
+    return files
+
+
+def _conf(path, files, dual, pos, minq, samples, flags=(True, True, True), gpu=""):
+    i1, i2, m1, m2 = pos
+    txt = "[quality]\nminimal_qual : %d\n[fastq]\n" % minq
+    for k in ("seq_R1", "seq_R2", "index_R1") + (("index_R2",) if dual else ()):
+        txt += "%s : %s\n" % (k, "  ".join(files[k]))
+    txt += "[index]\nindex2 : %s\nmolecular1 : %s\nmolecular2 : %s\n" % (dual, bool(m1), bool(m2))
+    txt += "index1_start : %d\nindex1_end : %d\n" % i1
+    if dual:
+        txt += "index2_start : %d\nindex2_end : %d\n" % i2
+    if m1:
+        txt += "molecular1_start : %d\nmolecular1_end : %d\n" % m1
+    if m2:
+        txt += "molecular2_start : %d\nmolecular2_end : %d\n" % m2
+    txt += "[output]\nwrite_pass : %s\nwrite_fail : %s\nwrite_undetermined : %s\n" % flags
+    txt += gpu
+    for i, (name, b1, b2) in enumerate(samples):
+        txt += "[sample%d]\nname : %s\nindex1_seq : %s\n" % (i + 1, name, b1)
+        if dual:
+            txt += "index2_seq : %s\n" % b2
+    with open(path, "w") as fh:
+        fh.write(txt)
+
+
+SCENARIOS = {
+    # name: dual, idx_len, positions (1-based incl.), min_qual, flags, trunc, malformed, plain, gpu section
+    "single_plain": dict(dual=False, idx_len=8, pos=((1, 8), None, None, None), minq=0, plain=True),
+    "single_mol_ext": dict(dual=False, idx_len=12, pos=((1, 6), None, (7, 12), None), minq=25),
+    "dual_mol_fail": dict(dual=True, idx_len=14, pos=((1, 8), (1, 8), (9, 14), (9, 14)), minq=25,
+                          gpu="[gpu]\nbatch_pairs : 37\nslots : 2\n"),
+    "dual_offset_windows": dict(dual=True, idx_len=10, pos=((2, 7), (3, 9), (1, 3), None), minq=30),
+    "flags_off": dict(dual=True, idx_len=8, pos=((1, 8), (1, 8), None, None), minq=25, flags=(True, False, False)),
+    "truncated_generic": dict(dual=True, idx_len=8, pos=((1, 8), (1, 8), (5, 8), None), minq=20, trunc=True,
+                              gpu="[gpu]\nbatch_pairs : 50\n"),
+    "malformed_desync": dict(dual=True, idx_len=8, pos=((1, 8), (1, 8), None, None), minq=25, malformed=True,
+                             gpu="[gpu]\nbatch_pairs : 16\nslots : 3\n"),
+    "wide_window_generic": dict(dual=False, idx_len=24, pos=((1, 20), None, (21, 24), None), minq=10),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_generated_dataset_matches_oracle(tmp_path, name):
+    sc = SCENARIOS[name]
+    rng = np.random.default_rng(abs(hash(name)) % (2 ** 31))
+    dual, idx_len = sc["dual"], sc["idx_len"]
+    i1 = sc["pos"][0]
+    i2 = sc["pos"][1]
+    w1 = i1[1] - i1[0] + 1
+    w2 = (i2[1] - i2[0] + 1) if i2 else 0
+    S = 7
+    bcs = set()
+    while len(bcs) < S:
+        bcs.add(("".join(rng.choice(list("ACGT"), w1)), "".join(rng.choice(list("ACGT"), w2)) if dual else ""))
+    bcs = sorted(bcs)
+    # the barcode sits at the window start inside the read
+    emb = [("A" * (i1[0] - 1) + b1, ("C" * (i2[0] - 1) + b2) if dual else "") for b1, b2 in bcs]
+    data = tmp_path / "data"
+    data.mkdir()
+    files = _make_dataset(str(data), rng, 3, 120, dual, idx_len, emb, trunc=sc.get("trunc", False),
+                          malformed=sc.get("malformed", False), plain=sc.get("plain", False))
+    samples = [("S%d" % i, b1, b2) for i, (b1, b2) in enumerate(bcs)]
+    if sc.get("trunc"):
+        samples.append(("SHORT", bcs[0][0][:5], ""))  # a barcode only a truncated read can match
+    conf = tmp_path / "conf.txt"
+    _conf(str(conf), files, dual, sc["pos"], sc["minq"], samples, sc.get("flags", (True, True, True)), sc.get("gpu", ""))
+    ref_dir, my_dir = tmp_path / "ref", tmp_path / "mine"
+    ref_dir.mkdir(); my_dir.mkdir()
+    sset, _ = qo.run_quade(str(conf), outdir=str(ref_dir))
+    _run_cli(str(conf), str(my_dir))
+    from quade_amd.sample import Sample
+    assert Sample.COUNTS() == sset.counts()
+    assert sset.counts()[1] > 0 and sset.counts()[3] > 0
+    _compare_dirs(str(my_dir), str(ref_dir))
+
+
+def test_pinned_slots_streaming_vs_oracle():
+    """H2D || kernel || D2H through the pinned slots, several batches in flight, no torch."""
+    from quade_amd import synth
+    from quade_amd.hip_backend import Engine
+    from tests import helpers as H
+    w = synth.generate("cfg4", 10000, seed=4)
+    codes_o, _, mol_o, counts_o = H.oracle_on_workload(w)
+    with Engine(0) as eng:
+        eng.set_plan(w.plan)
+        eng.set_barcodes(w.barcode_strings())
+        B, nslots = 1500, 3
+        eng.slots_create(nslots, B)
+        got_codes, got_mol = [], []
+        pending = []
+        for b, lo in enumerate(range(0, w.n, B)):
+            hi = min(lo + B, w.n)
+            slot = b % nslots
+            if len(pending) == nslots:
+                s, m = pending.pop(0)
+                eng.wait(s)
+                v = eng.slot(s)
+                got_codes.append(v["codes"][:m].copy()); got_mol.append(v["mol"][:m].copy())
+            v = eng.slot(slot)
+            for k in range(2):
+                v["seq"][k][:hi - lo] = w.seq[k][lo:hi].numpy()
+                v["qual"][k][:hi - lo] = w.qual[k][lo:hi].numpy()
+            eng.submit(slot, hi - lo)
+            pending.append((slot, hi - lo))
+        for s, m in pending:
+            eng.wait(s)
+            v = eng.slot(s)
+            got_codes.append(v["codes"][:m].copy()); got_mol.append(v["mol"][:m].copy())
+        assert (np.concatenate(got_codes) == codes_o).all()
+        assert H.mol_rows_to_str(np.concatenate(got_mol)) == mol_o
+        assert (eng.counts() == counts_o).all()

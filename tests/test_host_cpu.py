@@ -1,0 +1,272 @@
+"""Host logic without a GPU: the C-ABI library loads and exports what the header declares, the
+native fastq helpers agree with the oracle's reader/writer, conf parsing and Sample registry mirror
+the reference, the report reproduces the golden report.  No compute call is made here."""
+import gzip
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import quade_oracle as qo
+from quade_amd import hip_backend as hb
+from quade_amd.conf import QuadeConf, TEMPLATE, write_example_conf
+from quade_amd.sample import Sample
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    with open(os.path.join(ROOT, "include", "quade_hip.h")) as fh:
+        header = fh.read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(qd_[a-z_0-9]+)\s*\(", header))
+    assert len(declared) >= 25
+    lib = hb.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libquade_hip.so does not export %s" % name
+    assert declared == {s[0] for s in hb.SYMBOLS}, "ctypes table and header disagree"
+    assert lib.qd_version() == 1
+    assert lib.qd_strerror(hb.QD_ERR_NO_DEVICE) == b"no usable gfx950 HIP device"
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(hb.QuadeHipError) as ei:
+        hb.Engine(0)
+    assert ei.value.code == hb.QD_ERR_NO_DEVICE
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(ImportError):
+        hb.load_library(str(tmp_path / "nope.so"))
+
+
+def test_plan_layout_envelope():
+    lay = hb.plan_layout(hb.make_plan(True, 25, (0, 4), (0, 4), (3, 6), (3, 6)))
+    assert (lay.n_streams, list(lay.seq_off), list(lay.seq_width), list(lay.seq_stride)) == (2, [0, 0], [6, 6], [8, 8])
+    assert (list(lay.qual_off), list(lay.qual_width), lay.key_width, lay.mol_width) == ([0, 0], [4, 4], 8, 6)
+    lay = hb.plan_layout(hb.make_plan(False, 0, (2, 10), (0, 0), (12, 20)))
+    assert (lay.n_streams, lay.seq_off[0], lay.seq_width[0], lay.seq_stride[0], lay.qual_off[0]) == (1, 2, 18, 32, 2)
+    for bad in [hb.make_plan(False, 41, (0, 8)), hb.make_plan(False, 0, (5, 4)), hb.make_plan(False, 0, (-1, 4))]:
+        with pytest.raises(hb.QuadeHipError):
+            hb.plan_layout(bad)
+    with pytest.raises(hb.QuadeHipError) as ei:
+        hb.plan_layout(hb.make_plan(False, 0, (0, 40)))  # fused barcode > 32
+    assert ei.value.code == hb.QD_ERR_UNSUPPORTED
+
+
+TRICKY = (b"@r1 desc\nACGTAC\n+\nIIIIII\n"
+          b"@r2\tx\nACG\n+r2\nII\n"            # malformed: skipped inside its stream
+          b"@r3\r\nacgtNN\r\n+\r\nIII#II\r\n"   # CRLF
+          b"@  r4 lead\nAC\n+\nI5\n"            # leading blanks in the header, short read
+          b"@r5\n\n+\n\n"                       # empty read
+          b"@r6\nACGTACGTAC\n+\nIIIIIIIIII")    # no final newline
+
+
+def _oracle_records(tmp_path, data, name="x.fastq"):
+    p = tmp_path / name
+    p.write_bytes(data)
+    return list(qo.FastqReader(str(p)))
+
+
+def test_fastq_index_and_pack_match_oracle_reader(tmp_path):
+    recs = _oracle_records(tmp_path, TRICKY)
+    data = TRICKY + b"\n"
+    off, consumed = hb.fastq_index(data)
+    assert off.size - 1 == len(recs) == 5
+    assert consumed == len(data)
+    plan = hb.make_plan(False, 20, (1, 5), (0, 0), (3, 8))
+    lay = hb.plan_layout(plan)
+    n = len(recs)
+    sr = np.zeros((n, lay.seq_stride[0]), np.uint8)
+    qr = np.zeros((n, lay.qual_stride[0]), np.uint8)
+    lr = np.zeros(n, np.uint8)
+    got, full, cons = hb.pack_index_fastq(lay, 0, data, sr, qr, lr, n)
+    assert (got, full, cons) == (n, False, len(data))
+    for r, rec in enumerate(recs):
+        assert lr[r] == len(rec.seq)
+        win = rec.seq[lay.seq_off[0]:lay.seq_off[0] + lay.seq_width[0]].encode("latin-1")
+        assert bytes(sr[r]) == win + b"\0" * (lay.seq_stride[0] - len(win))
+        q = rec.qualstr[1:5].encode("latin-1")
+        assert bytes(qr[r]) == q + b"\xff" * (lay.qual_stride[0] - len(q))
+    # tags = ':IDX[:MOL]' with Python slice clamping, raw case
+    tags, tl = hb.build_tags(lay, plan, n, [sr], [lr])
+    for r, rec in enumerate(recs):
+        idx, mol = rec.seq[1:5], rec.seq[3:8]
+        exp = ":" + idx + (":" + mol if mol else "")
+        assert bytes(tags[r, :tl[r]]).decode("latin-1") == exp
+    # formatted records = oracle's fastqstr with the tag appended to the name
+    out = hb.format_records(data, off, np.arange(n), tags, tl).decode("latin-1")
+    exp = ""
+    for r, rec in enumerate(recs):
+        rec.name += bytes(tags[r, :tl[r]]).decode("latin-1")
+        exp += rec.fastqstr
+    assert out == exp
+
+
+def test_streaming_take_is_piecewise_consistent(tmp_path):
+    from quade_amd.fastq_reader import FastqStream
+    rng = np.random.default_rng(3)
+    recs = []
+    for i in range(1000):
+        L = int(rng.integers(0, 40))
+        s = "".join(rng.choice(list("ACGTN"), L))
+        q = "".join(chr(int(c)) for c in rng.integers(33, 74, L if i % 97 else L + 1))
+        recs.append("@r%d extra\n%s\n+\n%s\n" % (i, s, q))
+    p = tmp_path / "s.fastq.gz"
+    with gzip.open(p, "wb") as fh:
+        fh.write("".join(recs).encode())
+    expect = list(qo.FastqReader(str(p)))
+    st = FastqStream(str(p), read_bytes=1000)
+    names = []
+    while True:
+        text, off = st.take(64)
+        for r in range(off.size - 1):
+            names.append(bytes(text[off[r] + 1:off[r + 1]]).split()[0].decode())
+        if off.size - 1 < 64:
+            break
+    assert names == [r.name for r in expect]
+
+
+def test_bundled_index_files_pack(bundled_dir):
+    """skip-malformed inside its own stream: C1_R1 has one bad record (seq 100 nt, qual 101)"""
+    for f, n_exp in [("C1_R1", 99), ("C1_R2", 100), ("C1_R3", 100), ("C1_R4", 100)]:
+        data = gzip.open(os.path.join(bundled_dir, "dataset", f + ".fastq.gz")).read()
+        off, _ = hb.fastq_index(data)
+        assert off.size - 1 == n_exp
+
+
+def test_conf_matches_oracle_and_template_schema(tmp_path, bundled_dir):
+    golden_conf = os.path.join(bundled_dir, "result", "Quade_conf_file.txt")
+    cwd = os.getcwd()
+    os.chdir(os.path.join(bundled_dir, "result"))
+    try:
+        ref = qo.parse_conf(golden_conf)
+        mine = QuadeConf(golden_conf)
+        (tmp_path / "t").mkdir()
+        write_example_conf(str(tmp_path / "t" / "Quade_conf_file.txt"))
+        tmpl = QuadeConf(str(tmp_path / "t" / "Quade_conf_file.txt"))
+    finally:
+        os.chdir(cwd)
+    for c in (mine, tmpl):  # our -i template carries the reference template's values
+        assert c.minimal_qual == ref.minimal_qual == 25
+        assert (c.idx2, c.mol1, c.mol2) == (ref.idx2, ref.mol1, ref.mol2) == (True, True, True)
+        assert (c.idx1_pos, c.idx2_pos, c.mol1_pos, c.mol2_pos) == (ref.idx1_pos, ref.idx2_pos, ref.mol1_pos, ref.mol2_pos)
+        assert (c.seq_R1, c.seq_R2, c.index_R1, c.index_R2) == (ref.seq_R1, ref.seq_R2, ref.index_R1, ref.index_R2)
+        assert (c.write_pass, c.write_fail, c.write_undetermined) == (True, True, True)
+        assert c.samples == ref.samples == [("S1", "ACAGACAG"), ("S2", "CTTGCTTG")]
+        assert (c.devices, c.batch_pairs, c.slots) == (["0"], 4000000, 3)
+    p = mine.plan()
+    assert (p.dual, p.min_qual, p.idx1_start, p.idx1_end, p.mol2_start, p.mol2_end) == (1, 25, 0, 4, 3, 6)
+
+
+def _conf_text(**kw):
+    base = dict(minimal_qual="25", index2="False", molecular1="False", molecular2="False",
+                i1s="1", i1e="8", files="x")
+    base.update(kw)
+    return ("[quality]\nminimal_qual : {minimal_qual}\n[fastq]\nseq_R1 : {files}\nseq_R2 : {files}\nindex_R1 : {files}\n"
+            "[index]\nindex2 : {index2}\nmolecular1 : {molecular1}\nmolecular2 : {molecular2}\n"
+            "index1_start : {i1s}\nindex1_end : {i1e}\n[output]\nwrite_pass : True\nwrite_fail : False\n"
+            "write_undetermined : no\n[sample1]\nname : A\nindex1_seq : ACGTACGT\n").format(**base)
+
+
+def test_conf_validation_errors(tmp_path):
+    import configparser
+    f = tmp_path / "some.fastq"
+    f.write_text("")
+    ok = tmp_path / "ok.txt"
+    ok.write_text(_conf_text(files=str(f)))
+    c = QuadeConf(str(ok))
+    assert (c.idx2, c.mol1, c.mol2, c.idx2_pos, c.mol1_pos, c.write_fail, c.write_undetermined) == \
+        (False, False, False, {"start": 0, "end": 0}, {"start": 0, "end": 0}, False, False)
+    cases = [(dict(minimal_qual="41", files=str(f)), AssertionError, "Authorized values for minimal_qual : 0 to 40"),
+             (dict(files=str(tmp_path / "missing.fq")), IOError, "is not a valid file"),
+             (dict(minimal_qual="abc", files=str(f)), ValueError, ""),
+             (dict(i1s="5", i1e="3", files=str(f)), AssertionError, "")]
+    for kw, exc, msg in cases:
+        p = tmp_path / "bad.txt"
+        p.write_text(_conf_text(**kw))
+        with pytest.raises(exc) as ei:
+            QuadeConf(str(p))
+        assert msg in str(ei.value)
+        with pytest.raises(exc):
+            qo.parse_conf(str(p))
+    p = tmp_path / "nosec.txt"
+    p.write_text(_conf_text(files=str(f)).replace("[output]", "[outputs]"))
+    with pytest.raises(configparser.NoSectionError):
+        QuadeConf(str(p))
+    with pytest.raises(AssertionError) as ei:
+        QuadeConf(None)
+    assert str(ei.value) == "A path to the configuration file is mandatory"
+
+
+def test_cli_exit_codes_and_messages(tmp_path, capsys, monkeypatch):
+    from quade_amd.quade import Quade
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(SystemExit) as ei:
+        Quade.class_init(["-i"])
+    assert ei.value.code == 0 and (tmp_path / "Quade_conf_file.txt").read_text() == TEMPLATE
+    with pytest.raises(SystemExit) as ei:
+        Quade.class_init(["-c", "does_not_exist.txt"])
+    assert ei.value.code == 1
+    assert "One of the file is incorrect or unreadable\ndoes_not_exist.txt is not a valid file" in capsys.readouterr().out
+    with pytest.raises(SystemExit) as ei:
+        Quade.class_init([])
+    assert ei.value.code == 1
+    assert "One of the value in the configuration file is not correct\nA path to the configuration file is mandatory" \
+        in capsys.readouterr().out
+    with pytest.raises(SystemExit) as ei:
+        Quade.class_init(["--version"])
+    assert ei.value.code == 0 and "Quade 0.3.2" in capsys.readouterr().out
+    f = tmp_path / "a.fq"
+    f.write_text("")
+    (tmp_path / "dup.txt").write_text(_conf_text(files=str(f)) + "[sample2]\nname : B\nindex1_seq : ACGTACGT\n")
+    with pytest.raises(SystemExit) as ei:
+        Quade.class_init(["-c", "dup.txt"])
+    assert ei.value.code == 1 and "B : Index is not unique" in capsys.readouterr().out
+
+
+def test_sample_registry_matches_reference(finder_vectors):
+    for case in finder_vectors["registry"]:
+        Sample.RESET()
+        Sample.CLASS_INIT()
+        errors = []
+        for name, bc in case["samples"]:
+            try:
+                Sample(name, bc)
+                errors.append(None)
+            except AssertionError as E:
+                errors.append(str(E))
+        assert errors == case["errors"]
+        assert [[s.name, s.index] for s in Sample.SAMPLE_LIST] == case["registered"]
+    Sample.RESET()
+
+
+def test_report_reproduces_golden_report(bundled_dir):
+    Sample.RESET()
+    Sample.CLASS_INIT()
+    Sample("S1", "ACAGACAG")
+    Sample("S2", "CTTGCTTG")
+    Sample.SET_COUNTS([299, 52, 0, 247, 25, 0, 27, 0])
+    lines = ["{}\t{}".format(d, v) for d, v in Sample.REPORT()]
+    with open(os.path.join(bundled_dir, "result", "Quade_report.csv")) as fh:
+        ref = fh.read().split("\n")
+    assert lines == [ln for ln in ref[2:] if ln != ""]
+    # guards of src/Sample.py:112,123: nothing determined / empty sample
+    Sample.SET_COUNTS([5, 0, 0, 5, 0, 0, 0, 0])
+    assert [d for d, _ in Sample.REPORT()].count("Percent of total pair") == 0
+    Sample.RESET()
+
+
+def test_synthetic_generator_truth_equals_oracle():
+    from quade_amd import synth
+    from tests import helpers as H
+    for name in ["cfg2", "cfg3", "cfg4", "cfg5"]:
+        w = synth.generate(name, 3000, seed=11)
+        codes, _, _, counts = H.oracle_on_workload(w)
+        assert (codes == w.expected.numpy().astype(np.uint16)).all()
+        assert counts[0] == 3000 and counts[3] > 0 and (counts[2] > 0) == (synth.CONFIGS[name]["min_qual"] > 0)
