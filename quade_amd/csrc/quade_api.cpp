@@ -439,7 +439,7 @@ int qd_kernel_kind(const qd_ctx* c, int has_len) {
 int qd_set_option(qd_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return QD_ERR_INVALID;
     if (!strcmp(name, "fast_workgroups_per_cu")) {
-        if (value < 0 || value > 64) return fail(c, QD_ERR_INVALID, "fast_workgroups_per_cu must be 0..64");
+        if (value < 0 || value > 4096) return fail(c, QD_ERR_INVALID, "fast_workgroups_per_cu must be 0..4096");
         c->opt_wg_per_cu = (int)value;
         return QD_OK;
     }

@@ -10,7 +10,16 @@
 #define QD_FAST_BLOCK 512  /* threads per workgroup, fast kernel      */
 #endif
 #ifndef QD_FAST_UNITS
-#define QD_FAST_UNITS 2    /* 2-pair units per lane per tile          */
+#define QD_FAST_UNITS 1    /* 2-pair units per lane per tile          */
+#endif
+#ifndef QD_FAST_NT
+#define QD_FAST_NT 1       /* non-temporal row loads                   */
+#endif
+#ifndef QD_FAST_PREFETCH
+#define QD_FAST_PREFETCH 1 /* register double buffering of tiles       */
+#endif
+#ifndef QD_FAST_MINWAVES
+#define QD_FAST_MINWAVES 0 /* __launch_bounds__ 2nd argument (waves per SIMD), 0 = unset */
 #endif
 #define QD_GEN_BLOCK 256
 

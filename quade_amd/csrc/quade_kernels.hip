@@ -140,29 +140,142 @@ __device__ __forceinline__ uint32_t do_pair(const DemuxParams& p, const LdsTable
     klo = qd_fold8(klo);
     khi = qd_fold8(khi);
     // a4: exact match (Sample.py:65-67)
+#ifdef QD_ABLATE_PROBE  // timing-only build: no table probe (wrong results)
+    const uint32_t id = (uint32_t)(klo ^ khi) & 63u;
+#else
     const uint32_t id = probe_lds(t, klo, khi, (uint32_t)p.K, p.seed, p.slot_mask);
+#endif
     if (id == QD_CODE_UNDET) return QD_CODE_UNDET;
     // a5: min-phred gate over the barcode positions (Sample.py:70)
     uint32_t pass = qd_all_ge8(q1, p.thr);
     if (DUAL) pass &= qd_all_ge8(q2, p.thr);
     const uint32_t code = id * 2u + (pass ^ 1u);
     // a6: per-sample counters (Sample.py:71-72,79-80)
+#ifndef QD_ABLATE_HIST
     atomicAdd(&t.hist[code], 1u);
+#endif
     return code;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fast kernel.  Lane handles UNITS x 2 consecutive pairs.  Row strides: seq SS1/SS2 in {8,16},
-// qual rows 8 bytes.
+// Fast kernel.  Lane handles UNITS x 2 consecutive pairs per tile.  Row strides: seq SS1/SS2 in
+// {8,16}, qual rows 8 bytes.  Rows are read once and never again: loads are non-temporal.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ U128 ld16s(const uint8_t* p) {
+#if QD_FAST_NT
+    typedef unsigned long v2u64 __attribute__((ext_vector_type(2)));
+    const v2u64 v = __builtin_nontemporal_load(reinterpret_cast<const v2u64*>(p));  // global_load_dwordx4 ... nt
+    return U128{v.x, v.y};
+#else
+    return ld16(p);
+#endif
+}
+
 template <int SS1, int SS2, bool DUAL, int UNITS>
-__global__ __launch_bounds__(QD_FAST_BLOCK) void demux_fast(const DemuxParams p) {
+struct Tile {
+    U128 s1[UNITS][SS1 / 8], s2[UNITS][SS2 / 8], q1[UNITS], q2[UNITS];
+};
+
+// issue every load of a tile (16 B per lane per instruction, coalesced); nothing is consumed here
+template <int SS1, int SS2, bool DUAL, int UNITS>
+__device__ __forceinline__ void load_tile(Tile<SS1, SS2, DUAL, UNITS>& T, const DemuxParams& p, int64_t base,
+                                          uint32_t tid) {
+    const int64_t n = p.n;
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+        const int64_t p0 = base + ((int64_t)u * QD_FAST_BLOCK + tid) * 2;  // first pair of the unit
+        if (p0 + 1 < n) {
+#pragma unroll
+            for (int j = 0; j < SS1 / 8; ++j) T.s1[u][j] = ld16s(p.seq[0] + p0 * SS1 + 16 * j);
+            T.q1[u] = ld16s(p.qual[0] + p0 * 8);
+            if (DUAL) {
+#pragma unroll
+                for (int j = 0; j < SS2 / 8; ++j) T.s2[u][j] = ld16s(p.seq[1] + p0 * SS2 + 16 * j);
+                T.q2[u] = ld16s(p.qual[1] + p0 * 8);
+            }
+        } else if (p0 < n) {  // last, odd pair of the batch: never read past row n-1
+#pragma unroll
+            for (int j = 0; j < SS1 / 8; ++j) T.s1[u][j] = U128{0, 0};
+            T.s1[u][0].lo = ld8(p.seq[0] + p0 * SS1);
+            if (SS1 == 16) T.s1[u][0].hi = ld8(p.seq[0] + p0 * SS1 + 8);
+            T.q1[u] = U128{ld8(p.qual[0] + p0 * 8), 0};
+            if (DUAL) {
+#pragma unroll
+                for (int j = 0; j < SS2 / 8; ++j) T.s2[u][j] = U128{0, 0};
+                T.s2[u][0].lo = ld8(p.seq[1] + p0 * SS2);
+                if (SS2 == 16) T.s2[u][0].hi = ld8(p.seq[1] + p0 * SS2 + 8);
+                T.q2[u] = U128{ld8(p.qual[1] + p0 * 8), 0};
+            }
+        }
+    }
+}
+
+template <int SS1, int SS2, bool DUAL, int UNITS>
+__device__ __forceinline__ uint32_t compute_tile(const Tile<SS1, SS2, DUAL, UNITS>& T, const DemuxParams& p,
+                                                 const LdsTable& t, int64_t base, uint32_t tid) {
+    const int64_t n = p.n;
+    uint32_t undet = 0;
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+        const int64_t p0 = base + ((int64_t)u * QD_FAST_BLOCK + tid) * 2;
+        if (p0 >= n) continue;
+        const bool two = (p0 + 1 < n);
+        u64 a_lo, a_hi, b_lo, b_hi;                   // rows of pair p0 (a) and p0+1 (b), stream 1
+        u64 c_lo = 0, c_hi = 0, d_lo = 0, d_hi = 0;  // stream 2
+        if (SS1 == 8) {
+            a_lo = T.s1[u][0].lo; a_hi = 0; b_lo = T.s1[u][0].hi; b_hi = 0;
+        } else {
+            a_lo = T.s1[u][0].lo; a_hi = T.s1[u][0].hi; b_lo = T.s1[u][SS1 / 8 - 1].lo; b_hi = T.s1[u][SS1 / 8 - 1].hi;
+        }
+        if (DUAL) {
+            if (SS2 == 8) {
+                c_lo = T.s2[u][0].lo; d_lo = T.s2[u][0].hi;
+            } else {
+                c_lo = T.s2[u][0].lo; c_hi = T.s2[u][0].hi; d_lo = T.s2[u][SS2 / 8 - 1].lo; d_hi = T.s2[u][SS2 / 8 - 1].hi;
+            }
+        }
+        u64 m0lo = 0, m0hi = 0, m1lo = 0, m1hi = 0;
+        const uint32_t c0 = do_pair<SS1, SS2, DUAL>(p, t, a_lo, a_hi, T.q1[u].lo, c_lo, c_hi,
+                                                    DUAL ? T.q2[u].lo : 0, m0lo, m0hi);
+        uint32_t c1 = 0;
+        if (two)
+            c1 = do_pair<SS1, SS2, DUAL>(p, t, b_lo, b_hi, T.q1[u].hi, d_lo, d_hi, DUAL ? T.q2[u].hi : 0, m1lo, m1hi);
+        undet += (c0 == QD_CODE_UNDET) + (two && c1 == QD_CODE_UNDET);
+        // a7: routing codes, 2 x uint16 per lane = one dword store, coalesced
+        if (two)
+            *reinterpret_cast<uint32_t*>(p.codes + p0) = c0 | (c1 << 16);
+        else
+            p.codes[p0] = (uint16_t)c0;
+        if (p.M > 0) {
+            store_mol(p.mol + p0 * p.M, m0lo, m0hi, p.M);
+            if (two) store_mol(p.mol + (p0 + 1) * p.M, m1lo, m1hi, p.M);
+        }
+    }
+    return undet;
+}
+
+#if QD_FAST_MINWAVES
+#define QD_FAST_BOUNDS __launch_bounds__(QD_FAST_BLOCK, QD_FAST_MINWAVES)
+#else
+#define QD_FAST_BOUNDS __launch_bounds__(QD_FAST_BLOCK)
+#endif
+
+template <int SS1, int SS2, bool DUAL, int UNITS>
+__global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint32_t* slots = reinterpret_cast<uint32_t*>(lds_raw);
     u64* bk = reinterpret_cast<u64*>(lds_raw + p.lds_bk_off);
     uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw + p.lds_hist_off);
     const uint32_t tid = threadIdx.x;
     const uint32_t S = p.n_samples;
+    constexpr int64_t TILE = (int64_t)QD_FAST_BLOCK * 2 * UNITS;  // pairs per workgroup iteration
+    const int64_t ntiles = (p.n + TILE - 1) / TILE;
+    typedef Tile<SS1, SS2, DUAL, UNITS> TileT;
+
+    // the first tile's rows are requested before anything else, so HBM latency overlaps the staging
+    int64_t tile = blockIdx.x;
+    TileT A;
+    load_tile(A, p, tile * TILE, tid);
 
     // stage the table: global (L2) -> LDS, once per workgroup
     for (uint32_t i = tid; i <= p.slot_mask; i += QD_FAST_BLOCK) slots[i] = p.slots[i];
@@ -171,81 +284,28 @@ __global__ __launch_bounds__(QD_FAST_BLOCK) void demux_fast(const DemuxParams p)
     __syncthreads();
     const LdsTable t{slots, bk, hist};
 
-    constexpr int64_t TILE = (int64_t)QD_FAST_BLOCK * 2 * UNITS;  // pairs per workgroup iteration
-    const int64_t n = p.n;
-    const int64_t ntiles = (n + TILE - 1) / TILE;
     uint32_t undet = 0;
-
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t base = tile * TILE;
-        U128 s1[UNITS][SS1 / 8], s2[UNITS][SS2 / 8], q1[UNITS], q2[UNITS];
-        // ---- issue every load of the tile first (16 B per lane per instruction, coalesced)
-#pragma unroll
-        for (int u = 0; u < UNITS; ++u) {
-            const int64_t p0 = base + ((int64_t)u * QD_FAST_BLOCK + tid) * 2;  // first pair of the unit
-            if (p0 + 1 < n) {
-#pragma unroll
-                for (int j = 0; j < SS1 / 8; ++j) s1[u][j] = ld16(p.seq[0] + p0 * SS1 + 16 * j);
-                q1[u] = ld16(p.qual[0] + p0 * 8);
-                if (DUAL) {
-#pragma unroll
-                    for (int j = 0; j < SS2 / 8; ++j) s2[u][j] = ld16(p.seq[1] + p0 * SS2 + 16 * j);
-                    q2[u] = ld16(p.qual[1] + p0 * 8);
-                }
-            } else if (p0 < n) {  // last, odd pair of the batch: never read past row n-1
-#pragma unroll
-                for (int j = 0; j < SS1 / 8; ++j) s1[u][j] = U128{0, 0};
-                s1[u][0].lo = ld8(p.seq[0] + p0 * SS1);
-                if (SS1 == 16) s1[u][0].hi = ld8(p.seq[0] + p0 * SS1 + 8);
-                q1[u] = U128{ld8(p.qual[0] + p0 * 8), 0};
-                if (DUAL) {
-#pragma unroll
-                    for (int j = 0; j < SS2 / 8; ++j) s2[u][j] = U128{0, 0};
-                    s2[u][0].lo = ld8(p.seq[1] + p0 * SS2);
-                    if (SS2 == 16) s2[u][0].hi = ld8(p.seq[1] + p0 * SS2 + 8);
-                    q2[u] = U128{ld8(p.qual[1] + p0 * 8), 0};
-                }
-            }
-        }
-        // ---- consume
-#pragma unroll
-        for (int u = 0; u < UNITS; ++u) {
-            const int64_t p0 = base + ((int64_t)u * QD_FAST_BLOCK + tid) * 2;
-            if (p0 >= n) continue;
-            const bool two = (p0 + 1 < n);
-            u64 a_lo, a_hi, b_lo, b_hi;  // rows of pair p0 (a) and p0+1 (b), stream 1
-            u64 c_lo = 0, c_hi = 0, d_lo = 0, d_hi = 0;  // stream 2
-            if (SS1 == 8) {
-                a_lo = s1[u][0].lo; a_hi = 0; b_lo = s1[u][0].hi; b_hi = 0;
-            } else {
-                a_lo = s1[u][0].lo; a_hi = s1[u][0].hi; b_lo = s1[u][SS1 / 8 - 1].lo; b_hi = s1[u][SS1 / 8 - 1].hi;
-            }
-            if (DUAL) {
-                if (SS2 == 8) {
-                    c_lo = s2[u][0].lo; d_lo = s2[u][0].hi;
-                } else {
-                    c_lo = s2[u][0].lo; c_hi = s2[u][0].hi; d_lo = s2[u][SS2 / 8 - 1].lo; d_hi = s2[u][SS2 / 8 - 1].hi;
-                }
-            }
-            u64 m0lo = 0, m0hi = 0, m1lo = 0, m1hi = 0;
-            const uint32_t c0 = do_pair<SS1, SS2, DUAL>(p, t, a_lo, a_hi, q1[u].lo, c_lo, c_hi,
-                                                        DUAL ? q2[u].lo : 0, m0lo, m0hi);
-            uint32_t c1 = 0;
-            if (two)
-                c1 = do_pair<SS1, SS2, DUAL>(p, t, b_lo, b_hi, q1[u].hi, d_lo, d_hi, DUAL ? q2[u].hi : 0,
-                                             m1lo, m1hi);
-            undet += (c0 == QD_CODE_UNDET) + (two && c1 == QD_CODE_UNDET);
-            // a7: routing codes, 2 x uint16 per lane = one dword store, coalesced
-            if (two)
-                *reinterpret_cast<uint32_t*>(p.codes + p0) = c0 | (c1 << 16);
-            else
-                p.codes[p0] = (uint16_t)c0;
-            if (p.M > 0) {
-                store_mol(p.mol + p0 * p.M, m0lo, m0hi, p.M);
-                if (two) store_mol(p.mol + (p0 + 1) * p.M, m1lo, m1hi, p.M);
-            }
-        }
+#if QD_FAST_PREFETCH
+    // register double buffering: tile k+1 is in flight while tile k is matched
+    for (;;) {
+        TileT B;
+        const int64_t next = tile + gridDim.x;
+        if (next < ntiles) load_tile(B, p, next * TILE, tid);
+        undet += compute_tile(A, p, t, tile * TILE, tid);
+        if (next >= ntiles) break;
+        tile = next + gridDim.x;
+        if (tile < ntiles) load_tile(A, p, tile * TILE, tid);
+        undet += compute_tile(B, p, t, next * TILE, tid);
+        if (tile >= ntiles) break;
     }
+#else
+    for (;;) {
+        undet += compute_tile(A, p, t, tile * TILE, tid);
+        tile += gridDim.x;
+        if (tile >= ntiles) break;
+        load_tile(A, p, tile * TILE, tid);
+    }
+#endif
 
     // undetermined count: wavefront shuffle-reduce (64 lanes), then one LDS add per wave
 #pragma unroll
@@ -254,10 +314,12 @@ __global__ __launch_bounds__(QD_FAST_BLOCK) void demux_fast(const DemuxParams p)
     __syncthreads();
     // flush this workgroup's histogram into its own row of the partial-count matrix
     u64* row = p.partial + (size_t)(blockIdx.x % p.partial_rows) * p.cnt_stride;
+#ifndef QD_ABLATE_FLUSH
     for (uint32_t i = tid; i < 2 * S + 1; i += QD_FAST_BLOCK) {
         const uint32_t v = hist[i];
         if (v) atomicAdd(reinterpret_cast<unsigned long long*>(&row[i]), (unsigned long long)v);
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -373,7 +435,18 @@ hipError_t launch_fast_t(const DemuxParams& p, int cus, int wg_per_cu, int64_t n
         occ_blocks = nb < 1 ? 1 : nb;
         occ_lds = lds;
     }
-    int64_t grid = (int64_t)cus * (wg_per_cu > 0 ? wg_per_cu : occ_blocks);
+    // Workgroups per CU.  At least what is co-resident; more (up to 64) while re-staging the table
+    // costs < 2 % of the batch's row bytes: surplus workgroups are dispatched as earlier ones
+    // retire, which evens out the tail (measured: profiles/r01_sweep_grid.txt).
+    int64_t wg = wg_per_cu;
+    if (wg <= 0) {
+        const int64_t row_bytes = (int64_t)p.seq_stride[0] + p.qual_stride[0] +
+                                  (p.n_streams > 1 ? p.seq_stride[1] + p.qual_stride[1] : 0) + 2 + p.M;
+        wg = (p.n * row_bytes / 50) / ((int64_t)(lds ? lds : 1) * cus);
+        if (wg < occ_blocks) wg = occ_blocks;
+        if (wg > 64) wg = 64;
+    }
+    int64_t grid = (int64_t)cus * wg;
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(QD_FAST_BLOCK), lds, st, p);
     return hipGetLastError();
@@ -387,6 +460,9 @@ hipError_t qd_launch_fast(const DemuxParams& p, int cus, int wg_per_cu, size_t l
     const int ss1 = p.seq_stride[0], ss2 = p.seq_stride[1];
     const int64_t tile = qd_fast_tile_pairs();
     const int64_t nt = (p.n + tile - 1) / tile;
+#ifdef QD_SWEEP_BUILD  // tuning builds instantiate the dual 8+8 kernel only
+    return launch_fast_t<8, 8, true>(p, cus, wg_per_cu, nt, lds_bytes, st);
+#endif
     if (p.n_streams == 1) {
         if (ss1 == 8) return launch_fast_t<8, 8, false>(p, cus, wg_per_cu, nt, lds_bytes, st);
         return launch_fast_t<16, 8, false>(p, cus, wg_per_cu, nt, lds_bytes, st);

@@ -106,3 +106,72 @@ def test_reference_finder_vectors_through_hip(torch_cuda, engine, finder_vectors
         codes, _ = H.hip_on_device(engine, seq, qual, len(s1), lens)
         assert codes.tolist() == vs["codes"], (vs["S"], vs["K"], split)
         assert engine.counts().tolist() == vs["counts"]
+
+
+def test_million_pairs_vs_c_oracle_fast_and_generic(torch_cuda, engine):
+    """Mid size, beyond what the Python oracle does in seconds: 2 M pairs per config against the C
+    restatement (pinned to the Python oracle by tests/test_oracle_c.py)."""
+    from oracle import c_oracle
+    from quade_amd import synth
+    torch = torch_cuda
+    for name in ["cfg2", "cfg3", "cfg4", "cfg5"]:
+        w = synth.generate(name, 2_000_003, seed=31)
+        codes_c, mol_c, counts_c = c_oracle.demux_rows(w.layout, w.plan, w.barcode_strings(),
+                                                       [t.numpy() for t in w.seq], [t.numpy() for t in w.qual])
+        engine.set_plan(w.plan)
+        engine.set_barcodes(w.barcode_strings())
+        seq = [t.cuda() for t in w.seq]
+        qual = [t.cuda() for t in w.qual]
+        for generic in (False, True):
+            engine.set_option("force_generic", int(generic))
+            engine.reset_counts()
+            codes, mol = H.hip_on_device(engine, seq, qual, w.n)
+            assert (codes == codes_c).all(), (name, generic)
+            if mol_c is not None:
+                assert (mol == mol_c).all()
+            assert (engine.counts() == counts_c).all()
+        engine.set_option("force_generic", 0)
+
+
+def test_ragged_reads_mixed_barcodes_vs_c_oracle(torch_cuda, engine):
+    """Truncated index reads (Python slice clamping), barcodes of several lengths, offsets inside the
+    reads, lower case, 300 k pairs: the generic kernel against the C restatement."""
+    from oracle import c_oracle
+    from quade_amd.hip_backend import make_plan, pack_index_reads
+    torch = torch_cuda
+    rng = np.random.default_rng(12)
+    plan = make_plan(True, 28, (1, 7), (0, 5), (5, 9), (2, 4))
+    lay = engine.set_plan(plan)
+    bcs = ["ACGTAC" + "GGTCA", "ACGTAC", "ACG", "TTTTTT" + "AAAAA", "ACGTACGG", "GGGGGG" + "CC"]
+    engine.set_barcodes(bcs)
+    n = 300_000
+    pool1 = [b"N" + b[:6].encode() for b in bcs]
+    pool2 = [b[6:].encode() for b in bcs]
+    s1, s2, q1, q2 = [], [], [], []
+    tail = rng.choice(list(b"ACGTn"), size=(n, 2, 5)).astype(np.uint8)
+    cut = rng.integers(0, 40, size=(n, 2))
+    which = rng.integers(0, len(bcs), size=n)
+    low = rng.integers(0, 8, size=n) == 0
+    qv = rng.integers(25 + 33, 41 + 33, size=(n, 2, 12)).astype(np.uint8)
+    for i in range(n):
+        r1 = pool1[which[i]] + bytes(tail[i, 0, :3])
+        r2 = pool2[which[i]] + bytes(tail[i, 1])
+        if cut[i, 0] <= len(r1):
+            r1 = r1[:cut[i, 0]]
+        if cut[i, 1] <= len(r2):
+            r2 = r2[:cut[i, 1]]
+        if low[i]:
+            r1 = r1.lower()
+        s1.append(r1); s2.append(r2)
+        q1.append(bytes(qv[i, 0, :len(r1)])); q2.append(bytes(qv[i, 1, :len(r2)]))
+    rows = [pack_index_reads(lay, 0, s1, q1), pack_index_reads(lay, 1, s2, q2)]
+    assert not rows[0][3]
+    codes_c, mol_c, counts_c = c_oracle.demux_rows(lay, plan, bcs, [r[0] for r in rows], [r[1] for r in rows],
+                                                   [r[2] for r in rows])
+    codes, mol = H.hip_on_device(engine, [torch.from_numpy(r[0]).cuda() for r in rows],
+                                 [torch.from_numpy(r[1]).cuda() for r in rows], n,
+                                 [torch.from_numpy(r[2]).cuda() for r in rows])
+    assert (codes == codes_c).all()
+    assert (mol == mol_c).all()
+    assert (engine.counts() == counts_c).all()
+    assert len(set(codes_c.tolist())) >= 8
