@@ -140,7 +140,8 @@ int qd_demux_device(qd_ctx* ctx, int64_t n_pairs, const qd_rows* rows, uint16_t*
 int qd_kernel_kind(const qd_ctx* ctx, int has_len);
 
 /* Tuning / test knobs (no reference counterpart).  Names:
- *   "fast_workgroups_per_cu"  0 = as many as the occupancy query admits (default), 1..8 = fixed
+ *   "fast_workgroups_per_cu"  0 = automatic (default), 1..4096 = fixed
+ *   "fast_block"              0 = automatic (default), 256 / 512 / 1024 threads per workgroup
  *   "force_generic"           1 = always launch the generic kernel */
 int qd_set_option(qd_ctx* ctx, const char* name, int64_t value);
 

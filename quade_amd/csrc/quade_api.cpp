@@ -59,6 +59,7 @@ struct qd_ctx {
     size_t lds_bytes = 0;
     int opt_wg_per_cu = 0;    // 0 = occupancy query
     int opt_force_generic = 0;
+    int opt_block = 0;        // 0 = automatic
 
     // counters
     u64* d_partial = nullptr;
@@ -277,7 +278,7 @@ int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* 
     p.n = n;
     hipError_t e;
     if (fast) {
-        e = qd_launch_fast(p, c->cu, c->opt_wg_per_cu, c->lds_bytes, st);
+        e = qd_launch_fast(p, c->cu, c->opt_wg_per_cu, c->opt_block, c->lds_bytes, st);
     } else {
         const int64_t nb = (n + QD_GEN_BLOCK - 1) / QD_GEN_BLOCK;
         const int grid = (int)std::min<int64_t>(nb, (int64_t)c->cu * 8);
@@ -441,6 +442,12 @@ int qd_set_option(qd_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "fast_workgroups_per_cu")) {
         if (value < 0 || value > 4096) return fail(c, QD_ERR_INVALID, "fast_workgroups_per_cu must be 0..4096");
         c->opt_wg_per_cu = (int)value;
+        return QD_OK;
+    }
+    if (!strcmp(name, "fast_block")) {
+        if (value != 0 && value != 256 && value != 512 && value != 1024)
+            return fail(c, QD_ERR_INVALID, "fast_block must be 0, 256, 512 or 1024");
+        c->opt_block = (int)value;
         return QD_OK;
     }
     if (!strcmp(name, "force_generic")) {

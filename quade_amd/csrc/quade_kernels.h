@@ -7,7 +7,7 @@
 #define QD_MAX_KEY_BYTES 32
 
 #ifndef QD_FAST_BLOCK
-#define QD_FAST_BLOCK 512  /* threads per workgroup, fast kernel      */
+#define QD_FAST_BLOCK 512  /* default threads per workgroup, fast kernel */
 #endif
 #ifndef QD_FAST_UNITS
 #define QD_FAST_UNITS 1    /* 2-pair units per lane per tile          */
@@ -18,8 +18,11 @@
 #ifndef QD_FAST_PREFETCH
 #define QD_FAST_PREFETCH 1 /* register double buffering of tiles       */
 #endif
-#ifndef QD_FAST_MINWAVES
-#define QD_FAST_MINWAVES 0 /* __launch_bounds__ 2nd argument (waves per SIMD), 0 = unset */
+#ifndef QD_FAST_PREFETCH_MAXROW
+#define QD_FAST_PREFETCH_MAXROW 16 /* double-buffer only when seq row bytes per pair <= this */
+#endif
+#ifndef QD_FAST_BIG_LDS
+#define QD_FAST_BIG_LDS (32 * 1024) /* LDS image above which 1024-thread workgroups are used */
 #endif
 #define QD_GEN_BLOCK 256
 
@@ -49,9 +52,9 @@ struct DemuxParams {
     uint64_t idx_mask[2], mol_mask[2];  // (1 << 8*w) - 1
 };
 
-int64_t qd_fast_tile_pairs();
-// wg_per_cu <= 0: as many workgroups per CU as the occupancy query admits
-hipError_t qd_launch_fast(const DemuxParams& p, int cus, int wg_per_cu, size_t lds_bytes, hipStream_t st);
+// wg_per_cu <= 0: automatic (see launch_fast_t); block_override: 0 = automatic, else 256/512/1024
+hipError_t qd_launch_fast(const DemuxParams& p, int cus, int wg_per_cu, int block_override, size_t lds_bytes,
+                          hipStream_t st);
 hipError_t qd_launch_generic(const DemuxParams& p, int grid, hipStream_t st);
 hipError_t qd_launch_reduce(const uint64_t* partial, uint32_t rows, uint32_t cnt_stride,
                             uint32_t ncnt, uint64_t* out, hipStream_t st);

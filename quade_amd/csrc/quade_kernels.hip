@@ -115,6 +115,35 @@ __device__ __forceinline__ void store_mol(uint8_t* dst, u64 lo, u64 hi, int M) {
     }
 }
 
+// Molecular bytes of two consecutive pairs (2M contiguous bytes at an even pair index, so the
+// destination is 8-byte aligned for M % 4 == 0): 64-bit stores instead of 2 x M/4 dword stores.
+__device__ __forceinline__ void store_mol2(uint8_t* dst, u64 alo, u64 ahi, u64 blo, u64 bhi, int M) {
+    u64* d = reinterpret_cast<u64*>(dst);
+    switch (M) {
+        case 4:
+            d[0] = (alo & 0xFFFFFFFFull) | (blo << 32);
+            break;
+        case 8:
+            d[0] = alo;
+            d[1] = blo;
+            break;
+        case 12:
+            d[0] = alo;
+            d[1] = (ahi & 0xFFFFFFFFull) | (blo << 32);
+            d[2] = (blo >> 32) | (bhi << 32);
+            break;
+        case 16:
+            d[0] = alo;
+            d[1] = ahi;
+            d[2] = blo;
+            d[3] = bhi;
+            break;
+        default:
+            store_mol(dst, alo, ahi, M);
+            store_mol(dst + M, blo, bhi, M);
+    }
+}
+
 // One pair through the whole path.  Returns the routing code.
 template <int SS1, int SS2, bool DUAL>
 __device__ __forceinline__ uint32_t do_pair(const DemuxParams& p, const LdsTable& t, u64 s1lo, u64 s1hi,
@@ -177,13 +206,13 @@ struct Tile {
 };
 
 // issue every load of a tile (16 B per lane per instruction, coalesced); nothing is consumed here
-template <int SS1, int SS2, bool DUAL, int UNITS>
+template <int BLOCK, int SS1, int SS2, bool DUAL, int UNITS>
 __device__ __forceinline__ void load_tile(Tile<SS1, SS2, DUAL, UNITS>& T, const DemuxParams& p, int64_t base,
                                           uint32_t tid) {
     const int64_t n = p.n;
 #pragma unroll
     for (int u = 0; u < UNITS; ++u) {
-        const int64_t p0 = base + ((int64_t)u * QD_FAST_BLOCK + tid) * 2;  // first pair of the unit
+        const int64_t p0 = base + ((int64_t)u * BLOCK + tid) * 2;  // first pair of the unit
         if (p0 + 1 < n) {
 #pragma unroll
             for (int j = 0; j < SS1 / 8; ++j) T.s1[u][j] = ld16s(p.seq[0] + p0 * SS1 + 16 * j);
@@ -210,14 +239,14 @@ __device__ __forceinline__ void load_tile(Tile<SS1, SS2, DUAL, UNITS>& T, const 
     }
 }
 
-template <int SS1, int SS2, bool DUAL, int UNITS>
+template <int BLOCK, int SS1, int SS2, bool DUAL, int UNITS>
 __device__ __forceinline__ uint32_t compute_tile(const Tile<SS1, SS2, DUAL, UNITS>& T, const DemuxParams& p,
                                                  const LdsTable& t, int64_t base, uint32_t tid) {
     const int64_t n = p.n;
     uint32_t undet = 0;
 #pragma unroll
     for (int u = 0; u < UNITS; ++u) {
-        const int64_t p0 = base + ((int64_t)u * QD_FAST_BLOCK + tid) * 2;
+        const int64_t p0 = base + ((int64_t)u * BLOCK + tid) * 2;
         if (p0 >= n) continue;
         const bool two = (p0 + 1 < n);
         u64 a_lo, a_hi, b_lo, b_hi;                   // rows of pair p0 (a) and p0+1 (b), stream 1
@@ -247,65 +276,63 @@ __device__ __forceinline__ uint32_t compute_tile(const Tile<SS1, SS2, DUAL, UNIT
         else
             p.codes[p0] = (uint16_t)c0;
         if (p.M > 0) {
-            store_mol(p.mol + p0 * p.M, m0lo, m0hi, p.M);
-            if (two) store_mol(p.mol + (p0 + 1) * p.M, m1lo, m1hi, p.M);
+            if (two)
+                store_mol2(p.mol + p0 * p.M, m0lo, m0hi, m1lo, m1hi, p.M);
+            else
+                store_mol(p.mol + p0 * p.M, m0lo, m0hi, p.M);
         }
     }
     return undet;
 }
 
-#if QD_FAST_MINWAVES
-#define QD_FAST_BOUNDS __launch_bounds__(QD_FAST_BLOCK, QD_FAST_MINWAVES)
-#else
-#define QD_FAST_BOUNDS __launch_bounds__(QD_FAST_BLOCK)
-#endif
-
-template <int SS1, int SS2, bool DUAL, int UNITS>
-__global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p) {
+template <int BLOCK, int SS1, int SS2, bool DUAL, int UNITS>
+__global__ __launch_bounds__(BLOCK) void demux_fast(const DemuxParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint32_t* slots = reinterpret_cast<uint32_t*>(lds_raw);
     u64* bk = reinterpret_cast<u64*>(lds_raw + p.lds_bk_off);
     uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw + p.lds_hist_off);
     const uint32_t tid = threadIdx.x;
     const uint32_t S = p.n_samples;
-    constexpr int64_t TILE = (int64_t)QD_FAST_BLOCK * 2 * UNITS;  // pairs per workgroup iteration
+    constexpr int64_t TILE = (int64_t)BLOCK * 2 * UNITS;  // pairs per workgroup iteration
     const int64_t ntiles = (p.n + TILE - 1) / TILE;
     typedef Tile<SS1, SS2, DUAL, UNITS> TileT;
 
     // the first tile's rows are requested before anything else, so HBM latency overlaps the staging
     int64_t tile = blockIdx.x;
     TileT A;
-    load_tile(A, p, tile * TILE, tid);
+    load_tile<BLOCK>(A, p, tile * TILE, tid);
 
     // stage the table: global (L2) -> LDS, once per workgroup
-    for (uint32_t i = tid; i <= p.slot_mask; i += QD_FAST_BLOCK) slots[i] = p.slots[i];
-    for (uint32_t i = tid; i < 2 * S; i += QD_FAST_BLOCK) bk[i] = p.bk16[i];
-    for (uint32_t i = tid; i < 2 * S + 1; i += QD_FAST_BLOCK) hist[i] = 0;
+    for (uint32_t i = tid; i <= p.slot_mask; i += BLOCK) slots[i] = p.slots[i];
+    for (uint32_t i = tid; i < 2 * S; i += BLOCK) bk[i] = p.bk16[i];
+    for (uint32_t i = tid; i < 2 * S + 1; i += BLOCK) hist[i] = 0;
     __syncthreads();
     const LdsTable t{slots, bk, hist};
 
     uint32_t undet = 0;
-#if QD_FAST_PREFETCH
-    // register double buffering: tile k+1 is in flight while tile k is matched
-    for (;;) {
+    // register double buffering (tile k+1 in flight while tile k is matched) for the 8-byte-row
+    // instantiations; 16-byte rows already hold 96 B per lane per tile and run single-buffered
+    constexpr bool PREFETCH = QD_FAST_PREFETCH && (SS1 + (DUAL ? SS2 : 0) <= QD_FAST_PREFETCH_MAXROW);
+    if (PREFETCH) {
+      for (;;) {
         TileT B;
         const int64_t next = tile + gridDim.x;
-        if (next < ntiles) load_tile(B, p, next * TILE, tid);
-        undet += compute_tile(A, p, t, tile * TILE, tid);
+        if (next < ntiles) load_tile<BLOCK>(B, p, next * TILE, tid);
+        undet += compute_tile<BLOCK>(A, p, t, tile * TILE, tid);
         if (next >= ntiles) break;
         tile = next + gridDim.x;
-        if (tile < ntiles) load_tile(A, p, tile * TILE, tid);
-        undet += compute_tile(B, p, t, next * TILE, tid);
+        if (tile < ntiles) load_tile<BLOCK>(A, p, tile * TILE, tid);
+        undet += compute_tile<BLOCK>(B, p, t, next * TILE, tid);
         if (tile >= ntiles) break;
-    }
-#else
-    for (;;) {
-        undet += compute_tile(A, p, t, tile * TILE, tid);
+      }
+    } else {
+      for (;;) {
+        undet += compute_tile<BLOCK>(A, p, t, tile * TILE, tid);
         tile += gridDim.x;
         if (tile >= ntiles) break;
-        load_tile(A, p, tile * TILE, tid);
+        load_tile<BLOCK>(A, p, tile * TILE, tid);
+      }
     }
-#endif
 
     // undetermined count: wavefront shuffle-reduce (64 lanes), then one LDS add per wave
 #pragma unroll
@@ -315,7 +342,7 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p) {
     // flush this workgroup's histogram into its own row of the partial-count matrix
     u64* row = p.partial + (size_t)(blockIdx.x % p.partial_rows) * p.cnt_stride;
 #ifndef QD_ABLATE_FLUSH
-    for (uint32_t i = tid; i < 2 * S + 1; i += QD_FAST_BLOCK) {
+    for (uint32_t i = tid; i < 2 * S + 1; i += BLOCK) {
         const uint32_t v = hist[i];
         if (v) atomicAdd(reinterpret_cast<unsigned long long*>(&row[i]), (unsigned long long)v);
     }
@@ -414,9 +441,9 @@ __global__ void reduce_partials(const u64* partial, uint32_t rows, uint32_t cnt_
     out[i] = s;
 }
 
-template <int SS1, int SS2, bool DUAL>
-hipError_t launch_fast_t(const DemuxParams& p, int cus, int wg_per_cu, int64_t ntiles, size_t lds, hipStream_t st) {
-    auto k = demux_fast<SS1, SS2, DUAL, QD_FAST_UNITS>;
+template <int BLOCK, int SS1, int SS2, bool DUAL>
+hipError_t launch_fast_t(const DemuxParams& p, int cus, int wg_per_cu, size_t lds, hipStream_t st) {
+    auto k = demux_fast<BLOCK, SS1, SS2, DUAL, QD_FAST_UNITS>;
     static bool attr_set = false;  // per instantiation
     static size_t occ_lds = ~(size_t)0;
     static int occ_blocks = 1;
@@ -427,50 +454,64 @@ hipError_t launch_fast_t(const DemuxParams& p, int cus, int wg_per_cu, int64_t n
         attr_set = true;
     }
     if (occ_lds != lds) {
-        // persistent grid: exactly the workgroups that are co-resident (registers, LDS), so every
-        // workgroup strides over the same number of tiles and there is no second dispatch round
         int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, QD_FAST_BLOCK, lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, BLOCK, lds);
         if (e != hipSuccess) return e;
         occ_blocks = nb < 1 ? 1 : nb;
         occ_lds = lds;
     }
-    // Workgroups per CU.  At least what is co-resident; more (up to 64) while re-staging the table
-    // costs < 2 % of the batch's row bytes: surplus workgroups are dispatched as earlier ones
-    // retire, which evens out the tail (measured: profiles/r01_sweep_grid.txt).
+    const int64_t tile = (int64_t)BLOCK * 2 * QD_FAST_UNITS;
+    const int64_t ntiles = (p.n + tile - 1) / tile;
+    // Workgroups per CU (automatic), from the measurements in profiles/r01_tune_*.txt:
+    //  * dual-index, no molecular output (32 B in, 2 B out per pair): a small persistent grid, every
+    //    workgroup co-resident, tiles strided over it and double-buffered -- best and most stable;
+    //  * shapes with more output bytes or 16-byte rows: oversubscribe (surplus workgroups start as
+    //    earlier ones retire) while re-staging the table costs < 5 % of the batch's bytes.
     int64_t wg = wg_per_cu;
     if (wg <= 0) {
-        const int64_t row_bytes = (int64_t)p.seq_stride[0] + p.qual_stride[0] +
-                                  (p.n_streams > 1 ? p.seq_stride[1] + p.qual_stride[1] : 0) + 2 + p.M;
-        wg = (p.n * row_bytes / 50) / ((int64_t)(lds ? lds : 1) * cus);
-        if (wg < occ_blocks) wg = occ_blocks;
-        if (wg > 64) wg = 64;
+        if (DUAL && p.M == 0) {
+            wg = 2;
+        } else {
+            const int64_t row_bytes = (int64_t)p.seq_stride[0] + p.qual_stride[0] +
+                                      (p.n_streams > 1 ? p.seq_stride[1] + p.qual_stride[1] : 0) + 2 + p.M;
+            wg = (p.n * row_bytes / 20) / ((int64_t)(lds ? lds : 1) * cus);
+            if (wg > 64) wg = 64;
+        }
+        if (wg < 2 * occ_blocks && wg > occ_blocks) wg = occ_blocks;  // no thin second dispatch round
+        if (wg < 1) wg = 1;
     }
     int64_t grid = (int64_t)cus * wg;
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(QD_FAST_BLOCK), lds, st, p);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(BLOCK), lds, st, p);
     return hipGetLastError();
+}
+
+template <int BLOCK>
+hipError_t launch_fast_b(const DemuxParams& p, int cus, int wg_per_cu, size_t lds_bytes, hipStream_t st) {
+    const int ss1 = p.seq_stride[0], ss2 = p.seq_stride[1];
+#ifdef QD_SWEEP_BUILD  // tuning builds instantiate the dual 8+8 kernel only
+    return launch_fast_t<BLOCK, 8, 8, true>(p, cus, wg_per_cu, lds_bytes, st);
+#endif
+    if (p.n_streams == 1) {
+        if (ss1 == 8) return launch_fast_t<BLOCK, 8, 8, false>(p, cus, wg_per_cu, lds_bytes, st);
+        return launch_fast_t<BLOCK, 16, 8, false>(p, cus, wg_per_cu, lds_bytes, st);
+    }
+    if (ss1 == 8 && ss2 == 8) return launch_fast_t<BLOCK, 8, 8, true>(p, cus, wg_per_cu, lds_bytes, st);
+    if (ss1 == 8 && ss2 == 16) return launch_fast_t<BLOCK, 8, 16, true>(p, cus, wg_per_cu, lds_bytes, st);
+    if (ss1 == 16 && ss2 == 8) return launch_fast_t<BLOCK, 16, 8, true>(p, cus, wg_per_cu, lds_bytes, st);
+    return launch_fast_t<BLOCK, 16, 16, true>(p, cus, wg_per_cu, lds_bytes, st);
 }
 
 }  // namespace
 
-int64_t qd_fast_tile_pairs() { return (int64_t)QD_FAST_BLOCK * 2 * QD_FAST_UNITS; }
-
-hipError_t qd_launch_fast(const DemuxParams& p, int cus, int wg_per_cu, size_t lds_bytes, hipStream_t st) {
-    const int ss1 = p.seq_stride[0], ss2 = p.seq_stride[1];
-    const int64_t tile = qd_fast_tile_pairs();
-    const int64_t nt = (p.n + tile - 1) / tile;
-#ifdef QD_SWEEP_BUILD  // tuning builds instantiate the dual 8+8 kernel only
-    return launch_fast_t<8, 8, true>(p, cus, wg_per_cu, nt, lds_bytes, st);
-#endif
-    if (p.n_streams == 1) {
-        if (ss1 == 8) return launch_fast_t<8, 8, false>(p, cus, wg_per_cu, nt, lds_bytes, st);
-        return launch_fast_t<16, 8, false>(p, cus, wg_per_cu, nt, lds_bytes, st);
-    }
-    if (ss1 == 8 && ss2 == 8) return launch_fast_t<8, 8, true>(p, cus, wg_per_cu, nt, lds_bytes, st);
-    if (ss1 == 8 && ss2 == 16) return launch_fast_t<8, 16, true>(p, cus, wg_per_cu, nt, lds_bytes, st);
-    if (ss1 == 16 && ss2 == 8) return launch_fast_t<16, 8, true>(p, cus, wg_per_cu, nt, lds_bytes, st);
-    return launch_fast_t<16, 16, true>(p, cus, wg_per_cu, nt, lds_bytes, st);
+// Workgroup size: 512 threads; 1024 when the LDS image of the table is large (few workgroups fit a
+// CU then, and bigger ones keep the wave count up).  block_override: 0 = this rule.
+hipError_t qd_launch_fast(const DemuxParams& p, int cus, int wg_per_cu, int block_override, size_t lds_bytes,
+                          hipStream_t st) {
+    int block = block_override ? block_override : (lds_bytes > QD_FAST_BIG_LDS ? 1024 : QD_FAST_BLOCK);
+    if (block == 1024) return launch_fast_b<1024>(p, cus, wg_per_cu, lds_bytes, st);
+    if (block == 256) return launch_fast_b<256>(p, cus, wg_per_cu, lds_bytes, st);
+    return launch_fast_b<512>(p, cus, wg_per_cu, lds_bytes, st);
 }
 
 hipError_t qd_launch_generic(const DemuxParams& p, int grid, hipStream_t st) {

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Interleaved timing of launch options (workgroup size x workgroups per CU) of libquade_hip.so on
+one GPU.  usage: python tools/tune.py cfg [pairs] ; env TUNE_BLOCKS=0,256,512,1024 TUNE_WG=0,4,16,64
+TUNE_LIBS=path1,path2 (optional extra builds)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from quade_amd import synth  # noqa: E402
+from quade_amd.hip_backend import Engine, LIB_PATH  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+default_n = {"cfg2": 10_000_000, "cfg3": 100_000_000, "cfg4": 62_500_000, "cfg5": 125_000_000}
+n = int(sys.argv[2]) if len(sys.argv) > 2 else default_n[cfg]
+blocks = [int(x) for x in os.environ.get("TUNE_BLOCKS", "0,256,512,1024").split(",")]
+wgs = [int(x) for x in os.environ.get("TUNE_WG", "0,4,16,64").split(",")]
+libs = [LIB_PATH] + [p for p in os.environ.get("TUNE_LIBS", "").split(",") if p]
+rounds, reps = 3, 4
+
+w = synth.generate(cfg, n, device="cuda")
+M = w.layout.mol_width
+codes = torch.empty(n, dtype=torch.int16, device="cuda")
+mol = torch.empty((n, max(M, 1)), dtype=torch.uint8, device="cuda")
+engines = []
+for lp in libs:
+    e = Engine(0, lib_path=lp)
+    e.set_plan(w.plan)
+    e.set_barcodes(w.barcode_strings())
+    engines.append(e)
+st = torch.cuda.Stream()
+res = {}
+with torch.cuda.stream(st):
+    for r in range(rounds):
+        for lp, e in zip(libs, engines):
+            for b in blocks:
+                e.set_option("fast_block", b)
+                for wg in wgs:
+                    e.set_option("fast_workgroups_per_cu", wg)
+                    for i in range(reps + 1):
+                        a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a.record(st)
+                        e.demux_device(n, [t.data_ptr() for t in w.seq], [t.data_ptr() for t in w.qual],
+                                       codes.data_ptr(), mol.data_ptr() if M else None, stream=st.cuda_stream)
+                        z.record(st)
+                        z.synchronize()
+                        if i:
+                            res.setdefault((os.path.basename(lp), b, wg), []).append(a.elapsed_time(z))
+                    assert torch.equal(codes.view(torch.int16).to(torch.int32) & 0xFFFF, w.expected) or os.environ.get("TUNE_NOCHECK")
+B = synth.ALGO_BYTES[cfg]
+print("%s n=%d  algorithmic %d B/pair" % (cfg, n, B))
+print("%-24s %5s %4s %9s %9s %9s" % ("lib", "block", "wg", "min ms", "med ms", "GB/s(med)"))
+for (lp, b, wg), v in sorted(res.items(), key=lambda kv: np.median(kv[1])):
+    print("%-24s %5d %4d %9.4f %9.4f %9.0f" % (lp, b, wg, min(v), np.median(v), n * B / np.median(v) / 1e6))
