@@ -94,12 +94,21 @@ def main():
         log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    # Rehearsal knobs (a 1-GPU box cannot give every rank its own device): QUADE_BENCH_DEVICE pins all
+    # ranks to one device and QUADE_BENCH_BACKEND=gloo carries the count reduce.  The driver's runs set
+    # neither: one rank per GPU, backend nccl (= RCCL).
+    if os.environ.get("QUADE_BENCH_DEVICE"):
+        local_rank = int(os.environ["QUADE_BENCH_DEVICE"])
+    backend = os.environ.get("QUADE_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from quade_amd import synth
     from quade_amd.hip_backend import Engine
@@ -135,6 +144,9 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if dist:  # warm the communicator up too: its first collective builds the rings
+        red_dev0 = torch.device("cuda", local_rank) if backend == "nccl" else None
+        allreduce_counts(eng.counts(), dist, device=red_dev0)
     eng.reset_counts()
 
     # ---- timed region: barrier + sync on both sides, exactly K steps, then the count reduce
@@ -148,14 +160,15 @@ def main():
         step()
         ev[i][1].record(stream)
     counts = eng.counts()                      # waits for the device, sums the partial rows
-    total_counts = allreduce_counts(counts, dist, device=torch.device("cuda", local_rank)) if dist else counts
+    red_dev = torch.device("cuda", local_rank) if backend == "nccl" else None
+    total_counts = allreduce_counts(counts, dist, device=red_dev) if dist else counts
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     kern_ms = [a.elapsed_time(b) for a, b in ev]

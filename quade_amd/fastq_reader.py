@@ -9,7 +9,9 @@ inside its own stream -- SURVEY.md F6).  No per-read Python objects are built.
 """
 from __future__ import annotations
 
-import gzip
+import queue
+import threading
+import zlib
 
 import numpy as np
 
@@ -19,21 +21,73 @@ from . import hip_backend as hb
 class FastqStream(object):
     def __init__(self, path, read_bytes=32 << 20):
         self.path = path
-        self._fh = gzip.open(path, "rb") if path.lower().endswith(".gz") else open(path, "rb")
+        self._fh = open(path, "rb")
+        self._gz = path.lower().endswith(".gz")
         self._buf = b""
         self._eof = False
         self._read_bytes = read_bytes
         self._avg = 0.0  # running bytes per record, to size reads
+        # read-ahead thread: gunzip (releases the GIL) runs while the main thread packs and routes
+        self._q = queue.Queue(maxsize=4)
+        self._stop = False
+        self._thread = threading.Thread(target=self._reader, name="quade-gunzip", daemon=True)
+        self._thread.start()
+
+    def _reader(self):
+        """Producer: raw reads of the file, inflated with zlib directly (gzip members may be
+        concatenated -- the reference's own writer appends members, src/FastqWriter.py:83-90)."""
+        try:
+            if not self._gz:
+                while not self._stop:
+                    chunk = self._fh.read(self._read_bytes)
+                    self._q.put(chunk)
+                    if not chunk:
+                        return
+            dec = zlib.decompressobj(31)
+            out, size, fed = [], 0, False
+            while not self._stop:
+                raw = self._fh.read(4 << 20)
+                if not raw:
+                    if fed and not dec.eof:
+                        raise EOFError("%s: compressed file ended before the end-of-stream marker" % self.path)
+                    break
+                while raw:
+                    fed = True
+                    data = dec.decompress(raw)
+                    if data:
+                        out.append(data)
+                        size += len(data)
+                    if dec.eof:  # next member
+                        raw = dec.unused_data
+                        dec = zlib.decompressobj(31)
+                        fed = False
+                    else:
+                        raw = b""
+                    if size >= self._read_bytes:
+                        self._q.put(b"".join(out))
+                        out, size = [], 0
+            if size:
+                self._q.put(b"".join(out))
+            self._q.put(b"")
+        except Exception as e:  # surfaced by the consumer
+            self._q.put(e)
 
     def _fill(self, want_bytes):
-        while not self._eof and len(self._buf) < want_bytes:
-            chunk = self._fh.read(max(self._read_bytes, want_bytes - len(self._buf)))
+        parts = [self._buf]
+        have = len(self._buf)
+        while not self._eof and have < want_bytes:
+            chunk = self._q.get()
+            if isinstance(chunk, Exception):
+                raise chunk
             if not chunk:
                 self._eof = True
-                if self._buf and not self._buf.endswith(b"\n"):
-                    self._buf += b"\n"  # a last line without newline still ends a record
                 break
-            self._buf += chunk
+            parts.append(chunk)
+            have += len(chunk)
+        if len(parts) > 1:
+            self._buf = b"".join(parts)
+        if self._eof and self._buf and not self._buf.endswith(b"\n"):
+            self._buf += b"\n"  # a last line without newline still ends a record
 
     def take(self, max_records):
         """Up to max_records kept records -> (text uint8 array, rec_off int64[n+1]).
@@ -70,4 +124,11 @@ class FastqStream(object):
         return n, full
 
     def close(self):
+        self._stop = True
+        try:
+            while self._thread.is_alive():  # unblock a producer waiting on a full queue
+                self._q.get(timeout=0.05)
+        except queue.Empty:
+            pass
+        self._thread.join(timeout=5)
         self._fh.close()

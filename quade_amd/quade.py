@@ -26,6 +26,24 @@ from .fastq_reader import FastqStream
 from .sample import Batch, Sample
 
 import configparser
+import os
+from contextlib import contextmanager
+
+_PROFILE = bool(os.environ.get("QUADE_PROFILE"))
+_T = {}
+
+
+@contextmanager
+def _timed(name):
+    """Stage timers, printed at the end of a run when QUADE_PROFILE is set."""
+    if not _PROFILE:
+        yield
+        return
+    t0 = time()
+    try:
+        yield
+    finally:
+        _T[name] = _T.get(name, 0.0) + time() - t0
 
 
 class Quade(object):
@@ -105,7 +123,8 @@ class Quade(object):
             c = eng.counts()
             counts = c if counts is None else counts + c
         Sample.SET_COUNTS(counts)
-        Sample.FLUSH_ALL()
+        with _timed("drain gzip + close"):
+            Sample.FLUSH_ALL()
         for eng in self.engines:
             eng.close()
         self.engines = []
@@ -117,6 +136,9 @@ class Quade(object):
             for descr, value in Sample.REPORT():
                 report.write("{}\t{}\n".format(descr, value))
         print("Done in {}s".format(round(time() - start_time, 3)))
+        if _PROFILE:
+            for k, v in sorted(_T.items(), key=lambda kv: -kv[1]):
+                print("\t[profile] {:<28s} {:8.3f} s".format(k, v))
         return 0
 
     def double_index_parser(self):
@@ -152,14 +174,16 @@ class Quade(object):
                 while any(e is eng and s == slot for e, s, *_ in inflight):
                     self._finish(inflight.popleft())
                 v = eng.slot(slot)
-                r1_text, r1_off = r1s.take(B)
-                r2_text, r2_off = r2s.take(B)
+                with _timed("scan insert reads"):
+                    r1_text, r1_off = r1s.take(B)
+                    r2_text, r2_off = r2s.take(B)
                 counts = [r1_off.size - 1, r2_off.size - 1]
                 full = True
-                for k, st in enumerate(idx):
-                    nk, fk = st.take_packed(B, L, k, v["seq"][k], v["qual"][k], v["len"][k])
-                    counts.append(nk)
-                    full = full and fk
+                with _timed("pack index reads"):
+                    for k, st in enumerate(idx):
+                        nk, fk = st.take_packed(B, L, k, v["seq"][k], v["qual"][k], v["len"][k])
+                        counts.append(nk)
+                        full = full and fk
                 n = min(counts)
                 last = n < B
                 has_len = not full
@@ -174,11 +198,14 @@ class Quade(object):
 
     def _finish(self, item):
         eng, slot, n, has_len, r1_text, r1_off, r2_text, r2_off = item
-        eng.wait(slot)
+        with _timed("wait device"):
+            eng.wait(slot)
         v = eng.slot(slot)
-        tags, tag_len = hb.build_tags(self.layout, self.plan, n, v["seq"], v["len"] if has_len else None,
-                                      mol_rows=v["mol"])
-        Sample.FINDER(Batch(n, r1_text, r1_off, r2_text, r2_off, v["codes"], tags, tag_len))
+        with _timed("build tags"):
+            tags, tag_len = hb.build_tags(self.layout, self.plan, n, v["seq"], v["len"] if has_len else None,
+                                          mol_rows=v["mol"])
+        with _timed("route + format + queue gzip"):
+            Sample.FINDER(Batch(n, r1_text, r1_off, r2_text, r2_off, v["codes"], tags, tag_len))
 
 
 def main(argv=None):
