@@ -86,12 +86,6 @@ int fail(const qd_ctx* c, int code, const std::string& msg) {
             return fail((c), QD_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
     } while (0)
 
-int32_t pow2_at_least(int32_t v, int32_t lo) {
-    int32_t s = lo;
-    while (s < v) s <<= 1;
-    return s;
-}
-
 // canonical key of a byte string: little-endian packed, zero padded
 void canon(const uint8_t* b, int len, u64 w[QD_KEY_WORDS]) {
     for (int i = 0; i < QD_KEY_WORDS; ++i) w[i] = 0;
@@ -310,45 +304,6 @@ const char* qd_strerror(int code) {
 }
 
 const char* qd_last_error(const qd_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
-
-int qd_plan_layout(const qd_plan* P, qd_layout* L) {
-    if (!P || !L) return QD_ERR_INVALID;
-    memset(L, 0, sizeof *L);
-    if (P->min_qual < 0 || P->min_qual > 40) return QD_ERR_INVALID;  // src/Quade.py:262
-    const int is[2] = {P->idx1_start, P->idx2_start}, ie[2] = {P->idx1_end, P->idx2_end};
-    const int ms[2] = {P->mol1_start, P->mol2_start}, me[2] = {P->mol1_end, P->mol2_end};
-    L->n_streams = P->dual ? 2 : 1;
-    for (int k = 0; k < 2; ++k) {
-        L->seq_stride[k] = 8;
-        L->qual_stride[k] = 8;
-        if (k >= L->n_streams) continue;
-        if (is[k] < 0 || ie[k] < is[k] || ms[k] < 0 || me[k] < ms[k]) return QD_ERR_INVALID;  // Quade.py:277-279
-        if (ie[k] > 255 || me[k] > 255) return QD_ERR_UNSUPPORTED;
-        const int iw = ie[k] - is[k], mw = me[k] - ms[k];
-        int lo = 0, hi = 0;
-        if (iw > 0 && mw > 0) {
-            lo = std::min(is[k], ms[k]);
-            hi = std::max(ie[k], me[k]);
-        } else if (iw > 0) {
-            lo = is[k];
-            hi = ie[k];
-        } else if (mw > 0) {
-            lo = ms[k];
-            hi = me[k];
-        }
-        if (hi - lo > QD_MAX_WINDOW) return QD_ERR_UNSUPPORTED;
-        L->seq_off[k] = lo;
-        L->seq_width[k] = hi - lo;
-        L->seq_stride[k] = pow2_at_least(hi - lo, 8);
-        L->qual_off[k] = is[k];
-        L->qual_width[k] = iw;
-        L->qual_stride[k] = pow2_at_least(iw, 8);
-        L->key_width += iw;
-        L->mol_width += mw;
-    }
-    if (L->key_width > QD_MAX_KEY) return QD_ERR_UNSUPPORTED;
-    return QD_OK;
-}
 
 int qd_create(int device_id, qd_ctx** out) {
     if (!out) return fail(nullptr, QD_ERR_INVALID, "out is NULL");

@@ -146,6 +146,9 @@ SCENARIOS = {
                               gpu="[gpu]\nbatch_pairs : 50\n"),
     "malformed_desync": dict(dual=True, idx_len=8, pos=((1, 8), (1, 8), None, None), minq=25, malformed=True,
                              gpu="[gpu]\nbatch_pairs : 16\nslots : 3\n"),
+    # two contexts (both on GPU 0 here) fed round-robin: output order must still equal input order
+    "two_engines_round_robin": dict(dual=True, idx_len=8, pos=((1, 8), (1, 8), None, None), minq=25,
+                                    gpu="[gpu]\ndevices : 0 0\nbatch_pairs : 23\nslots : 2\n"),
     "wide_window_generic": dict(dual=False, idx_len=24, pos=((1, 20), None, (21, 24), None), minq=10),
 }
 
