@@ -28,7 +28,7 @@ class FastqStream(object):
         self._read_bytes = read_bytes
         self._avg = 0.0  # running bytes per record, to size reads
         # read-ahead thread: gunzip (releases the GIL) runs while the main thread packs and routes
-        self._q = queue.Queue(maxsize=4)
+        self._q = queue.Queue(maxsize=8)  # up to 8 x read_bytes of inflated text buffered per stream
         self._stop = False
         self._thread = threading.Thread(target=self._reader, name="quade-gunzip", daemon=True)
         self._thread.start()

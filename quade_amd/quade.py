@@ -143,25 +143,43 @@ class Quade(object):
 
     def double_index_parser(self):
         cf = self.cf
-        for n, files in enumerate(zip(cf.seq_R1, cf.seq_R2, cf.index_R1, cf.index_R2)):
+        chunks = list(zip(cf.seq_R1, cf.seq_R2, cf.index_R1, cf.index_R2))
+        for n, streams in enumerate(self._open_ahead(chunks)):
             print("Start parsing chunk {}".format(n + 1))
-            self._parse_chunk(files)
+            self._parse_chunk(streams)
             print("\tEnd of chunk {}".format(n + 1))
 
     def simple_index_parser(self):
         cf = self.cf
-        for n, files in enumerate(zip(cf.seq_R1, cf.seq_R2, cf.index_R1)):
+        chunks = list(zip(cf.seq_R1, cf.seq_R2, cf.index_R1))
+        for n, streams in enumerate(self._open_ahead(chunks)):
             print("Start parsing chunk {}/{}".format(n + 1, len(cf.seq_R1)))
-            self._parse_chunk(files)
+            self._parse_chunk(streams)
             print("\tEnd of chunk {}".format(n + 1))
 
+    def _open_ahead(self, chunks, lookahead=2):
+        """Yields the opened streams of each chunk in order, keeping the next `lookahead` chunks'
+        files open so that their read-ahead (gunzip) threads already run; chunks are still consumed
+        strictly in order (src/Quade.py:198,229)."""
+        opened = deque()
+        nxt = 0
+        try:
+            for i in range(len(chunks)):
+                while nxt < len(chunks) and nxt <= i + lookahead:
+                    opened.append([FastqStream(f) for f in chunks[nxt]])
+                    nxt += 1
+                yield opened.popleft()
+        finally:
+            for streams in opened:
+                for st in streams:
+                    st.close()
+
     # ~~~~~~~ PRIVATE METHODS ~~~~~~~ #
-    def _parse_chunk(self, files):
+    def _parse_chunk(self, streams):
         """One chunk = 3 or 4 files read in lock step; the chunk ends at the first exhausted
         stream (src/Quade.py:210-224)."""
         B = self.cf.batch_pairs
         L = self.layout
-        streams = [FastqStream(f) for f in files]
         r1s, r2s, idx = streams[0], streams[1], streams[2:]
         inflight = deque()
         b = 0

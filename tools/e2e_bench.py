@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 level = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+n_chunks = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # the same files listed n_chunks times
 rng = np.random.default_rng(5)
 S = 96
 bcs = set()
@@ -47,7 +48,7 @@ for key, L in (("seq_R1", 150), ("seq_R2", 150), ("index_R1", 8), ("index_R2", 8
     paths[key] = p
 conf = os.path.join(work, "conf.txt")
 with open(conf, "w") as fh:
-    fh.write("[quality]\nminimal_qual : 25\n[fastq]\n" + "".join("%s : %s\n" % kv for kv in paths.items()) +
+    fh.write("[quality]\nminimal_qual : 25\n[fastq]\n" + "".join("%s : %s\n" % (k, "  ".join([v] * n_chunks)) for k, v in paths.items()) +
              "[index]\nindex2 : True\nmolecular1 : False\nmolecular2 : False\nindex1_start : 1\nindex1_end : 8\n"
              "index2_start : 1\nindex2_end : 8\n[output]\nwrite_pass : True\nwrite_fail : True\nwrite_undetermined : True\n"
              "[gpu]\nbatch_pairs : 1000000\ngzip_level : %d\n" % level +
@@ -61,5 +62,6 @@ t0 = time.perf_counter()
 q = Quade(conf_file=conf)
 q()
 dt = time.perf_counter() - t0
-print(json.dumps({"mode": "end-to-end fastq.gz -> fastq.gz", "pairs": n, "seconds": dt, "pairs_per_s": n / dt,
+n *= n_chunks
+print(json.dumps({"mode": "end-to-end fastq.gz -> fastq.gz", "chunks": n_chunks, "pairs": n, "seconds": dt, "pairs_per_s": n / dt,
                   "gzip_level": level, "counts": Sample.COUNTS()[:4], "host_cores_used": 1}))
