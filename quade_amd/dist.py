@@ -30,3 +30,39 @@ def allreduce_counts(counts, dist=None, device=None):
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy().astype(np.uint64)
+
+
+# ---- chunk-sharded runs of the command line (one process per GPU) -----------------------------------
+def chunk_owner(chunk_index, world):
+    """Chunk files are the natural shard unit (src/Quade.py:198,229): chunk c -> rank c mod world."""
+    return chunk_index % world
+
+
+def part_dir(outdir, chunk_index):
+    import os
+    return os.path.join(outdir, ".quade_parts", "chunk%06d" % chunk_index)
+
+
+def merge_parts(outdir, n_chunks):
+    """Concatenates the per-chunk part files into the final outputs, in chunk order.  A gzip file may
+    consist of several members (the reference's own writer appends members,
+    src/FastqWriter.py:83-90), so the decompressed bytes equal those of a sequential run.  A final
+    file exists only if some chunk produced it (lazy creation, src/FastqWriter.py:55-57)."""
+    import os
+    import shutil
+    names = []
+    for c in range(n_chunks):
+        d = part_dir(outdir, c)
+        if os.path.isdir(d):
+            for f in sorted(os.listdir(d)):
+                if f.endswith(".fastq.gz") and f not in names:
+                    names.append(f)
+    for f in names:
+        with open(os.path.join(outdir, f), "wb") as out:
+            for c in range(n_chunks):
+                p = os.path.join(part_dir(outdir, c), f)
+                if os.path.exists(p):
+                    with open(p, "rb") as fh:
+                        shutil.copyfileobj(fh, out, 16 << 20)
+    shutil.rmtree(os.path.join(outdir, ".quade_parts"), ignore_errors=True)
+    return names

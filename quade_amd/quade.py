@@ -10,6 +10,12 @@ simple_index_parser (src/Quade.py:195-254) replaced by a batch pipeline:
 Several batches are in flight (one per pinned slot, round-robin over the configured GPUs); results
 are consumed in batch order, so every output file keeps the input order (chunk order, then read
 order) exactly as the reference's sequential loop does.
+
+Multi-process mode (one process per GPU): started under `python -m torch.distributed.run
+--nproc-per-node N -m quade_amd.quade -c Conf.txt`, rank r takes the chunks c with c mod N == r on GPU
+LOCAL_RANK, writes each chunk's records to that chunk's own part files, the counter vectors are
+summed with one all-reduce (RCCL over xGMI; nothing else is exchanged), and rank 0 concatenates the
+parts in chunk order (gzip members) and writes the report.
 """
 from __future__ import annotations
 
@@ -99,8 +105,17 @@ class Quade(object):
         """Main function of the script (src/Quade.py:169-193)"""
         start_time = time()
         cf = self.cf
+        self.rank, self.world, dist = 0, 1, None
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            # one process per GPU: torch.distributed only carries the final count reduce
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(os.environ.get("QUADE_DIST_BACKEND", "nccl"))
+            self.rank, self.world = dist.get_rank(), dist.get_world_size()
         devices = cf.devices
-        if devices == ["all"]:
+        if self.world > 1:
+            devices = [os.environ.get("QUADE_DEVICE", os.environ.get("LOCAL_RANK", "0"))]
+        elif devices == ["all"]:
             import torch  # only to count devices; nothing else of torch is used on this path
             devices = list(range(torch.cuda.device_count()))
         plan = cf.plan()
@@ -122,15 +137,26 @@ class Quade(object):
         for eng in self.engines:
             c = eng.counts()
             counts = c if counts is None else counts + c
-        Sample.SET_COUNTS(counts)
         with _timed("drain gzip + close"):
             Sample.FLUSH_ALL()
         for eng in self.engines:
             eng.close()
         self.engines = []
+        if self.world > 1:
+            from .dist import allreduce_counts, merge_parts
+            import torch
+            dev = torch.device("cuda", int(devices[0])) if dist.get_backend() == "nccl" else None
+            counts = allreduce_counts(counts, dist, device=dev)  # the only exchange of the run
+            dist.barrier()  # every rank's part files are closed
+            if self.rank == 0:
+                merge_parts(self.outdir, len(cf.seq_R1))
+            dist.barrier()
+            dist.destroy_process_group()
+            if self.rank != 0:
+                return 0
+        Sample.SET_COUNTS(counts)
 
         print("Generate_a csv report")
-        import os
         with open(os.path.join(self.outdir, "Quade_report.csv"), "w") as report:
             report.write("Program {}\tDate {}\n\n".format(self.VERSION, str(datetime.today())))
             for descr, value in Sample.REPORT():
@@ -144,7 +170,7 @@ class Quade(object):
     def double_index_parser(self):
         cf = self.cf
         chunks = list(zip(cf.seq_R1, cf.seq_R2, cf.index_R1, cf.index_R2))
-        for n, streams in enumerate(self._open_ahead(chunks)):
+        for n, streams in self._open_ahead(chunks):
             print("Start parsing chunk {}".format(n + 1))
             self._parse_chunk(streams)
             print("\tEnd of chunk {}".format(n + 1))
@@ -152,23 +178,30 @@ class Quade(object):
     def simple_index_parser(self):
         cf = self.cf
         chunks = list(zip(cf.seq_R1, cf.seq_R2, cf.index_R1))
-        for n, streams in enumerate(self._open_ahead(chunks)):
+        for n, streams in self._open_ahead(chunks):
             print("Start parsing chunk {}/{}".format(n + 1, len(cf.seq_R1)))
             self._parse_chunk(streams)
             print("\tEnd of chunk {}".format(n + 1))
 
     def _open_ahead(self, chunks, lookahead=2):
-        """Yields the opened streams of each chunk in order, keeping the next `lookahead` chunks'
-        files open so that their read-ahead (gunzip) threads already run; chunks are still consumed
-        strictly in order (src/Quade.py:198,229)."""
+        """Yields (chunk index, opened streams) for this rank's chunks in order, keeping the next
+        `lookahead` chunks' files open so that their read-ahead (gunzip) threads already run; chunks
+        are still consumed strictly in order (src/Quade.py:198,229).  In multi-process mode the
+        writers are pointed at the chunk's own part directory first."""
+        from .dist import chunk_owner, part_dir
+        mine = [c for c in range(len(chunks)) if chunk_owner(c, self.world) == self.rank]
         opened = deque()
         nxt = 0
         try:
-            for i in range(len(chunks)):
-                while nxt < len(chunks) and nxt <= i + lookahead:
-                    opened.append([FastqStream(f) for f in chunks[nxt]])
+            for i, c in enumerate(mine):
+                while nxt < len(mine) and nxt <= i + lookahead:
+                    opened.append([FastqStream(f) for f in chunks[mine[nxt]]])
                     nxt += 1
-                yield opened.popleft()
+                if self.world > 1:
+                    d = part_dir(self.outdir, c)
+                    os.makedirs(d, exist_ok=True)
+                    Sample.RETARGET(d)
+                yield c, opened.popleft()
         finally:
             for streams in opened:
                 for st in streams:

@@ -62,6 +62,18 @@ class Sample(object):
         cls.UNDETERMINED_WRITER = FastqWriter("Undetermined", outdir, gzip_level)
 
     @classmethod
+    def RETARGET(cls, outdir):
+        """Close every writer and point it at `outdir` (files are again created lazily there).
+        Used by the multi-process mode, where each chunk's records go to that chunk's own part
+        directory and the parts are concatenated in chunk order afterwards."""
+        cls.FLUSH_ALL()
+        cls.OUTDIR = outdir
+        cls.UNDETERMINED_WRITER = FastqWriter("Undetermined", outdir, cls.GZIP_LEVEL)
+        for s in cls.SAMPLE_LIST:
+            s.pass_writer = FastqWriter("{}_pass".format(s.name), outdir, cls.GZIP_LEVEL)
+            s.fail_writer = FastqWriter("{}_fail".format(s.name), outdir, cls.GZIP_LEVEL)
+
+    @classmethod
     def BARCODES(cls):
         """Upper-case barcodes in ordinal order: the table handed to qd_set_barcodes."""
         return [s.index for s in cls.SAMPLE_LIST]

@@ -42,3 +42,28 @@ def test_two_rank_gloo_count_reduce(tmp_path):
     assert res["world"] == 2
     assert res["total"] == [int(x) for x in counts]
     assert res["share0"] == [0, 2001]
+
+
+def test_merge_parts_keeps_chunk_order_and_lazy_creation(tmp_path):
+    """Per-chunk part files -> final files: members concatenated in chunk order, a file exists only
+    if some chunk produced it, parts removed."""
+    import gzip
+    from quade_amd.dist import chunk_owner, merge_parts, part_dir
+    assert [chunk_owner(c, 3) for c in range(7)] == [0, 1, 2, 0, 1, 2, 0]
+    out = str(tmp_path)
+    content = {0: {"A_pass_R1.fastq.gz": b"a0", "Undetermined_R1.fastq.gz": b"u0"},
+               1: {},
+               2: {"A_pass_R1.fastq.gz": b"a2", "B_fail_R1.fastq.gz": b"b2"},
+               3: {"Undetermined_R1.fastq.gz": b"u3", "A_pass_R1.fastq.gz": b"a3"}}
+    for c, files in content.items():
+        os.makedirs(part_dir(out, c), exist_ok=True)
+        for f, data in files.items():
+            with gzip.open(os.path.join(part_dir(out, c), f), "wb") as fh:
+                fh.write(data)
+    names = merge_parts(out, 4)
+    assert sorted(names) == ["A_pass_R1.fastq.gz", "B_fail_R1.fastq.gz", "Undetermined_R1.fastq.gz"]
+    assert sorted(os.listdir(out)) == sorted(names)
+    rd = lambda f: gzip.open(os.path.join(out, f)).read()  # noqa: E731
+    assert rd("A_pass_R1.fastq.gz") == b"a0a2a3"
+    assert rd("Undetermined_R1.fastq.gz") == b"u0u3"
+    assert rd("B_fail_R1.fastq.gz") == b"b2"

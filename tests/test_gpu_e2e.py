@@ -188,6 +188,35 @@ def test_generated_dataset_matches_oracle(tmp_path, name):
     _compare_dirs(str(my_dir), str(ref_dir))
 
 
+def test_two_process_chunk_sharded_run_matches_oracle(tmp_path):
+    """One process per GPU (rehearsed here with 2 ranks on GPU 0 and the gloo backend): chunks are
+    sharded over the ranks, counts all-reduced, parts merged in chunk order -> same bytes as the
+    oracle's sequential run."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(77)
+    bcs = sorted({("".join(rng.choice(list("ACGT"), 8)), "".join(rng.choice(list("ACGT"), 8))) for _ in range(9)})
+    data = tmp_path / "data"
+    data.mkdir()
+    files = _make_dataset(str(data), rng, 5, 90, True, 14, list(bcs), malformed=True)
+    samples = [("S%d" % i, b1, b2) for i, (b1, b2) in enumerate(bcs)]
+    conf = tmp_path / "conf.txt"
+    _conf(str(conf), files, True, ((1, 8), (1, 8), (9, 14), (9, 12)), 25, samples, gpu="[gpu]\nbatch_pairs : 40\n")
+    ref_dir, my_dir = tmp_path / "ref", tmp_path / "mine"
+    ref_dir.mkdir(); my_dir.mkdir()
+    sset, _ = qo.run_quade(str(conf), outdir=str(ref_dir))
+    env = dict(os.environ, PYTHONPATH=root, QUADE_DIST_BACKEND="gloo", QUADE_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", "-m", "quade_amd.quade", "-c", str(conf)]
+    r = subprocess.run(cmd, cwd=str(my_dir), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert not os.path.exists(my_dir / ".quade_parts")
+    _compare_dirs(str(my_dir), str(ref_dir))
+    with open(my_dir / "Quade_report.csv") as fh:
+        assert "Total pair\t%d" % sset.counts()[0] in fh.read()
+
+
 def test_pinned_slots_streaming_vs_oracle():
     """H2D || kernel || D2H through the pinned slots, several batches in flight, no torch."""
     from quade_amd import synth
