@@ -214,9 +214,9 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {
-            "workload": "%s: %s 8 bp index, %d samples, minimal_qual %d%s, %d read-pairs per GPU; packed index "
+            "workload": "%s: %s bp index, %d samples, minimal_qual %d%s, %d read-pairs per GPU; packed index "
                         "rows resident in HBM; codes%s + counts out" % (
-                            args.config, "dual 8+8" if cfg["dual"] else "single", cfg["S"], cfg["min_qual"],
+                            args.config, "dual 8+8" if cfg["dual"] else "single 8", cfg["S"], cfg["min_qual"],
                             ", molecular 6+6" if cfg["mol"] else "", n, " + molecular bytes" if M else ""),
             "pairs_per_gpu": n, "kernel": "demux_" + kind, "sharding": "pairs split across ranks, RCCL all-reduce of counts",
         },

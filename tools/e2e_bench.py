@@ -15,13 +15,14 @@ sys.path.insert(0, ROOT)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 level = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 n_chunks = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # the same files listed n_chunks times
+prepare_only = "--prepare-only" in sys.argv
 rng = np.random.default_rng(5)
 S = 96
 bcs = set()
 while len(bcs) < S:
     bcs.add(("".join(rng.choice(list("ACGT"), 8)), "".join(rng.choice(list("ACGT"), 8))))
 bcs = sorted(bcs)
-work = tempfile.mkdtemp(prefix="quade_e2e_")
+work = sys.argv[sys.argv.index("--prepare-only") + 1] if prepare_only else tempfile.mkdtemp(prefix="quade_e2e_")
 acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 
 
@@ -55,6 +56,8 @@ with open(conf, "w") as fh:
              "".join("[sample%d]\nname : S%d\nindex1_seq : %s\nindex2_seq : %s\n" % (i + 1, i + 1, a, b) for i, (a, b) in enumerate(bcs)))
 out = os.path.join(work, "out")
 os.mkdir(out)
+if prepare_only:
+    sys.exit(0)
 os.chdir(out)
 from quade_amd.quade import Quade  # noqa: E402
 from quade_amd.sample import Sample  # noqa: E402
