@@ -99,6 +99,7 @@ def load_library(path=None):
         raise ImportError(
             "%s not found: build it first (python -c 'import __graft_entry__ as g; g.build()' or "
             "make -C quade_amd/csrc).  quade_amd has no CPU fallback." % path)
+    _preload_shared_hip_runtime()
     lib = C.CDLL(path)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
@@ -107,6 +108,27 @@ def load_library(path=None):
     if default:
         _lib = lib
     return lib
+
+
+def _preload_shared_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64 (soname
+    libamdhip64.so.7, same as the system one this library links).  If ours is loaded first the
+    system copy gets mapped, a later `import torch` maps its bundled copy as well, and the second
+    HSA initialisation finds no GPU.  Mapping torch's copy first (when torch is installed; torch
+    itself is not imported) makes both sides resolve to the same runtime whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def _ptr(a):

@@ -1,0 +1,152 @@
+"""Edges of the library's envelope on the GPU: largest tables / keys / windows, degenerate plans,
+error returns.  Checked against the C oracle (pinned to the Python oracle by tests/test_oracle_c.py)."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def engine():
+    from quade_amd.hip_backend import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _random_reads(rng, n, L, barcodes, where, frac_hit=0.8):
+    """n reads of length L; a random barcode is planted at column `where` in frac_hit of them."""
+    arr = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=(n, L))
+    hit = rng.random(n) < frac_hit
+    which = rng.integers(0, len(barcodes), n)
+    for i in np.flatnonzero(hit):
+        b = np.frombuffer(barcodes[which[i]].encode(), dtype=np.uint8)
+        m = min(len(b), L - where)
+        arr[i, where:where + m] = b[:m]
+    low = rng.random(n) < 0.05
+    arr[low] |= 0x20
+    seqs = [bytes(r) for r in arr]
+    q = rng.integers(33 + 15, 33 + 41, size=(n, L)).astype(np.uint8)
+    quals = [bytes(r) for r in q]
+    return seqs, quals
+
+
+def _run_vs_c_oracle(engine, plan, barcodes, reads):
+    import torch
+    from oracle import c_oracle
+    from quade_amd.hip_backend import pack_index_reads
+    lay = engine.set_plan(plan)
+    engine.set_barcodes(barcodes)
+    rows = [pack_index_reads(lay, k, s, q) for k, (s, q) in enumerate(reads)]
+    full = all(r[3] for r in rows)
+    lens = None if full else [torch.from_numpy(r[2]).cuda() for r in rows]
+    n = len(reads[0][0])
+    codes_c, mol_c, counts_c = c_oracle.demux_rows(lay, plan, barcodes, [r[0] for r in rows], [r[1] for r in rows],
+                                                   None if full else [r[2] for r in rows])
+    codes, mol = H.hip_on_device(engine, [torch.from_numpy(r[0]).cuda() for r in rows],
+                                 [torch.from_numpy(r[1]).cuda() for r in rows], n, lens)
+    assert (codes == codes_c).all()
+    if mol_c is not None:
+        assert (mol == mol_c).all()
+    assert (engine.counts() == counts_c).all()
+    return codes_c, counts_c
+
+
+def _barcodes(rng, S, K):
+    out = set()
+    while len(out) < S:
+        out.add("".join(rng.choice(list("ACGT"), K)))
+    return sorted(out)
+
+
+@pytest.mark.parametrize("S,kind", [(2048, "fast"), (3000, "fast"), (6000, "generic"), (32767, "generic")])
+def test_large_sample_tables(engine, S, kind):
+    from quade_amd.hip_backend import make_plan
+    rng = np.random.default_rng(S)
+    bcs = _barcodes(rng, S, 16)
+    plan = make_plan(True, 17, (0, 8), (0, 8))
+    s1, q1 = _random_reads(rng, 60000, 8, [b[:8] for b in bcs], 0)
+    s2, q2 = _random_reads(rng, 60000, 8, [b[8:] for b in bcs], 0)
+    # make a share of the pairs carry a *matching* (i7, i5) combination
+    for i in range(0, 60000, 2):
+        b = bcs[int(rng.integers(0, S))]
+        s1[i], s2[i] = b[:8].encode(), b[8:].encode()
+    codes, counts = _run_vs_c_oracle(engine, plan, bcs, [(s1, q1), (s2, q2)])
+    assert engine.kernel_kind(False) == kind
+    assert counts[1] > 1000 and counts[2] > 1000 and counts[3] > 1000
+
+
+def test_longest_key_and_widest_window(engine):
+    """fused barcode of 32 bytes (16 + 16), index-read windows of 64 bytes, slice ends at column 255"""
+    from quade_amd.hip_backend import make_plan
+    rng = np.random.default_rng(5)
+    bcs = _barcodes(rng, 40, 32)
+    plan = make_plan(True, 20, (239, 255), (10, 26), (191, 200), (0, 10))  # I1 window 191..255 = 64 bytes
+    s1, q1 = _random_reads(rng, 20000, 255, [b[:16] for b in bcs], 239, frac_hit=0.0)
+    s2, q2 = _random_reads(rng, 20000, 40, [b[16:] for b in bcs], 10, frac_hit=0.0)
+    for i in range(0, 20000, 2):
+        b = bcs[int(rng.integers(0, 40))].encode()
+        s1[i] = s1[i][:239] + b[:16]
+        s2[i] = s2[i][:10] + b[16:] + s2[i][26:]
+    _, counts = _run_vs_c_oracle(engine, plan, bcs, [(s1, q1), (s2, q2)])
+    assert engine.kernel_kind(False) == "generic"
+    assert counts[1] + counts[2] > 5000
+
+
+def test_degenerate_plans(engine):
+    from quade_amd.hip_backend import make_plan
+    rng = np.random.default_rng(9)
+    bcs = _barcodes(rng, 6, 5)
+    # zero-width first slice (index1_start 1, index1_end 0): the key comes from index read 2 alone
+    s1, q1 = _random_reads(rng, 5000, 6, bcs, 0)
+    s2, q2 = _random_reads(rng, 5000, 7, bcs, 1)
+    _, counts = _run_vs_c_oracle(engine, make_plan(True, 25, (0, 0), (1, 6), (2, 4), (0, 0)), bcs, [(s1, q1), (s2, q2)])
+    assert counts[1] > 100
+    # one sample, everything undetermined, minimal_qual 0 and 40
+    _, counts = _run_vs_c_oracle(engine, make_plan(False, 0, (0, 5)), ["NNNNN"], [(s1, q1)])
+    assert counts[3] >= 4990
+    _, counts = _run_vs_c_oracle(engine, make_plan(False, 40, (0, 5)), bcs, [(s1, q1)])
+    assert counts[2] > 0
+    # no samples at all
+    _, counts = _run_vs_c_oracle(engine, make_plan(False, 25, (0, 5)), [], [(s1, q1)])
+    assert counts.tolist() == [5000, 0, 0, 5000]
+    # empty barcode registered next to real ones: never matches (deviation ii)
+    _, counts = _run_vs_c_oracle(engine, make_plan(False, 25, (0, 5)), bcs + [""], [(s1, q1)])
+    assert counts[-1] == 0 and counts[-2] == 0
+
+
+def test_error_returns(engine):
+    import torch
+    from quade_amd import hip_backend as hb
+    with pytest.raises(hb.QuadeHipError) as ei:
+        engine.set_barcodes(["ACGT"])          # no plan yet
+    assert ei.value.code == hb.QD_ERR_STATE
+    engine.set_plan(hb.make_plan(False, 25, (0, 8)))
+    with pytest.raises(hb.QuadeHipError) as ei:
+        engine.set_barcodes(["ACGTACGT", "TTTTTTTT", "ACGTACGT"])
+    assert ei.value.code == hb.QD_ERR_BARCODE and "Index is not unique" in str(ei.value)
+    with pytest.raises(hb.QuadeHipError) as ei:
+        engine.set_plan(hb.make_plan(False, 25, (0, 33)))
+    assert ei.value.code == hb.QD_ERR_UNSUPPORTED
+    engine.set_barcodes(["ACGTACGT"])
+    buf = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    with pytest.raises(hb.QuadeHipError) as ei:   # misaligned row pointer
+        engine.demux_device(16, [buf.data_ptr() + 8], [buf.data_ptr() + 1024], buf.data_ptr() + 2048)
+    assert ei.value.code == hb.QD_ERR_INVALID
+    with pytest.raises(hb.QuadeHipError):
+        engine.counts.__self__.lib.qd_get_counts  # noqa: B018 (attribute exists)
+        engine._chk(engine.lib.qd_get_counts(engine._h, None, 6))
+    engine.slots_create(2, 64)
+    with pytest.raises(hb.QuadeHipError) as ei:
+        engine.submit(0, 65)                   # beyond the slot capacity
+    assert ei.value.code == hb.QD_ERR_INVALID
+    engine.submit(0, 0)
+    with pytest.raises(hb.QuadeHipError) as ei:
+        engine.submit(0, 1)                    # slot not waited for
+    assert ei.value.code == hb.QD_ERR_STATE
+    engine.wait(0)
+    with pytest.raises(hb.QuadeHipError) as ei:
+        engine.set_plan(hb.make_plan(False, 25, (0, 6)))  # slots exist
+    assert ei.value.code == hb.QD_ERR_STATE
