@@ -199,7 +199,8 @@ int rebuild(qd_ctx* c) {
     c->fast_ok = ok;
 
     c->cnt_stride = (uint32_t)((2 * S + 1 + 3) & ~3);
-    c->partial_rows = (uint32_t)c->cu * 8;
+    // one counter row per workgroup (modulo), capped at 64 MiB of rows for very large tables
+    c->partial_rows = (uint32_t)std::max<size_t>(8, std::min<size_t>((size_t)c->cu * 8, ((size_t)64 << 20) / ((size_t)c->cnt_stride * 8)));
     HIPCHK(c, hipMalloc(&c->d_partial, (size_t)c->partial_rows * c->cnt_stride * 8));
     HIPCHK(c, hipMalloc(&c->d_counts, (size_t)c->cnt_stride * 8));
     HIPCHK(c, hipMemset(c->d_partial, 0, (size_t)c->partial_rows * c->cnt_stride * 8));
