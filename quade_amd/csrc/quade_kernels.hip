@@ -206,14 +206,17 @@ struct Tile {
 };
 
 // issue every load of a tile (16 B per lane per instruction, coalesced); nothing is consumed here
-template <int BLOCK, int SS1, int SS2, bool DUAL, int UNITS>
+// FULL: the tile lies entirely inside the batch -- every lane loads unconditionally, so the loads are
+// plain straight-line code and the compiler can count them (s_waitcnt vmcnt(N)) when an older tile
+// is consumed while these are in flight.  !FULL: the batch's last, partial tile, lane-guarded.
+template <bool FULL, int BLOCK, int SS1, int SS2, bool DUAL, int UNITS>
 __device__ __forceinline__ void load_tile(Tile<SS1, SS2, DUAL, UNITS>& T, const DemuxParams& p, int64_t base,
                                           uint32_t tid) {
     const int64_t n = p.n;
 #pragma unroll
     for (int u = 0; u < UNITS; ++u) {
         const int64_t p0 = base + ((int64_t)u * BLOCK + tid) * 2;  // first pair of the unit
-        if (p0 + 1 < n) {
+        if (FULL || p0 + 1 < n) {
 #pragma unroll
             for (int j = 0; j < SS1 / 8; ++j) T.s1[u][j] = ld16s(p.seq[0] + p0 * SS1 + 16 * j);
             T.q1[u] = ld16s(p.qual[0] + p0 * 8);
@@ -239,16 +242,20 @@ __device__ __forceinline__ void load_tile(Tile<SS1, SS2, DUAL, UNITS>& T, const 
     }
 }
 
-template <int BLOCK, int SS1, int SS2, bool DUAL, int UNITS>
+// TAG only makes the copies of this code distinct (an assembler comment), so that the compiler does
+// not fold the copy that runs with younger loads in flight into the copy that runs without: a folded
+// copy has to assume the younger loads are missing and waits for everything.
+template <bool FULL, int TAG, int BLOCK, int SS1, int SS2, bool DUAL, int UNITS>
 __device__ __forceinline__ uint32_t compute_tile(const Tile<SS1, SS2, DUAL, UNITS>& T, const DemuxParams& p,
                                                  const LdsTable& t, int64_t base, uint32_t tid) {
+    asm volatile("; demux tile copy %0" ::"i"(TAG));
     const int64_t n = p.n;
     uint32_t undet = 0;
 #pragma unroll
     for (int u = 0; u < UNITS; ++u) {
         const int64_t p0 = base + ((int64_t)u * BLOCK + tid) * 2;
-        if (p0 >= n) continue;
-        const bool two = (p0 + 1 < n);
+        if (!FULL && p0 >= n) continue;
+        const bool two = FULL || (p0 + 1 < n);
         u64 a_lo, a_hi, b_lo, b_hi;                   // rows of pair p0 (a) and p0+1 (b), stream 1
         u64 c_lo = 0, c_hi = 0, d_lo = 0, d_hi = 0;  // stream 2
         if (SS1 == 8) {
@@ -294,13 +301,15 @@ __global__ __launch_bounds__(BLOCK) void demux_fast(const DemuxParams p) {
     const uint32_t tid = threadIdx.x;
     const uint32_t S = p.n_samples;
     constexpr int64_t TILE = (int64_t)BLOCK * 2 * UNITS;  // pairs per workgroup iteration
-    const int64_t ntiles = (p.n + TILE - 1) / TILE;
     typedef Tile<SS1, SS2, DUAL, UNITS> TileT;
 
-    // the first tile's rows are requested before anything else, so HBM latency overlaps the staging
+    // Full tiles [0, nfull) are strided over the grid; the partial last tile (if any) is done by one
+    // workgroup after its full tiles.  The first tile's rows are requested before anything else, so
+    // HBM latency overlaps the staging of the table.
+    const int64_t nfull = p.n / TILE;
     int64_t tile = blockIdx.x;
-    TileT A;
-    load_tile<BLOCK>(A, p, tile * TILE, tid);
+    TileT A, B;
+    if (tile < nfull) load_tile<true, BLOCK>(A, p, tile * TILE, tid);
 
     // stage the table: global (L2) -> LDS, once per workgroup
     for (uint32_t i = tid; i <= p.slot_mask; i += BLOCK) slots[i] = p.slots[i];
@@ -310,28 +319,44 @@ __global__ __launch_bounds__(BLOCK) void demux_fast(const DemuxParams p) {
     const LdsTable t{slots, bk, hist};
 
     uint32_t undet = 0;
-    // register double buffering (tile k+1 in flight while tile k is matched) for the 8-byte-row
-    // instantiations; 16-byte rows already hold 96 B per lane per tile and run single-buffered
+    // Register double buffering (tile k+1 in flight while tile k is matched) for the 8-byte-row
+    // instantiations; 16-byte rows already hold 96 B per lane per tile and run single-buffered.
+    // Every "load next, then match current" pair is straight-line code with its own copy of the match
+    // (no control-flow join between issuing the younger loads and consuming the older ones): with a
+    // join the compiler must assume the younger loads may be missing and waits for them too
+    // (s_waitcnt vmcnt(3..0) instead of vmcnt(4+)), which serialises the two tiles.
     constexpr bool PREFETCH = QD_FAST_PREFETCH && (SS1 + (DUAL ? SS2 : 0) <= QD_FAST_PREFETCH_MAXROW);
-    if (PREFETCH) {
-      for (;;) {
-        TileT B;
-        const int64_t next = tile + gridDim.x;
-        if (next < ntiles) load_tile<BLOCK>(B, p, next * TILE, tid);
-        undet += compute_tile<BLOCK>(A, p, t, tile * TILE, tid);
-        if (next >= ntiles) break;
-        tile = next + gridDim.x;
-        if (tile < ntiles) load_tile<BLOCK>(A, p, tile * TILE, tid);
-        undet += compute_tile<BLOCK>(B, p, t, next * TILE, tid);
-        if (tile >= ntiles) break;
-      }
-    } else {
-      for (;;) {
-        undet += compute_tile<BLOCK>(A, p, t, tile * TILE, tid);
-        tile += gridDim.x;
-        if (tile >= ntiles) break;
-        load_tile<BLOCK>(A, p, tile * TILE, tid);
-      }
+    const int64_t G = gridDim.x;
+    if (tile < nfull) {
+        if (PREFETCH) {
+            for (;;) {
+                const int64_t next = tile + G;
+                if (next >= nfull) {
+                    undet += compute_tile<true, 0, BLOCK>(A, p, t, tile * TILE, tid);
+                    break;
+                }
+                load_tile<true, BLOCK>(B, p, next * TILE, tid);
+                undet += compute_tile<true, 1, BLOCK>(A, p, t, tile * TILE, tid);
+                tile = next + G;
+                if (tile >= nfull) {
+                    undet += compute_tile<true, 2, BLOCK>(B, p, t, next * TILE, tid);
+                    break;
+                }
+                load_tile<true, BLOCK>(A, p, tile * TILE, tid);
+                undet += compute_tile<true, 3, BLOCK>(B, p, t, next * TILE, tid);
+            }
+        } else {
+            for (;;) {
+                undet += compute_tile<true, 4, BLOCK>(A, p, t, tile * TILE, tid);
+                tile += G;
+                if (tile >= nfull) break;
+                load_tile<true, BLOCK>(A, p, tile * TILE, tid);
+            }
+        }
+    }
+    if (nfull * TILE < p.n && (int64_t)blockIdx.x == nfull % G) {  // the partial tile, lane-guarded
+        load_tile<false, BLOCK>(A, p, nfull * TILE, tid);
+        undet += compute_tile<false, 5, BLOCK>(A, p, t, nfull * TILE, tid);
     }
 
     // undetermined count: wavefront shuffle-reduce (64 lanes), then one LDS add per wave
@@ -462,26 +487,25 @@ hipError_t launch_fast_t(const DemuxParams& p, int cus, int wg_per_cu, size_t ld
     }
     const int64_t tile = (int64_t)BLOCK * 2 * QD_FAST_UNITS;
     const int64_t ntiles = (p.n + tile - 1) / tile;
-    // Workgroups per CU (automatic), from the measurements in profiles/r01_tune_*.txt:
-    //  * dual-index, no molecular output (32 B in, 2 B out per pair): a small persistent grid, every
-    //    workgroup co-resident, tiles strided over it and double-buffered -- best and most stable;
-    //  * shapes with more output bytes or 16-byte rows: oversubscribe (surplus workgroups start as
-    //    earlier ones retire) while re-staging the table costs < 5 % of the batch's bytes.
-    int64_t wg = wg_per_cu;
-    if (wg <= 0) {
-        if (DUAL && p.M == 0) {
-            wg = 2;
-        } else {
-            const int64_t row_bytes = (int64_t)p.seq_stride[0] + p.qual_stride[0] +
-                                      (p.n_streams > 1 ? p.seq_stride[1] + p.qual_stride[1] : 0) + 2 + p.M;
-            wg = (p.n * row_bytes / 20) / ((int64_t)(lds ? lds : 1) * cus);
-            if (wg > 64) wg = 64;
-        }
-        if (wg < 2 * occ_blocks && wg > occ_blocks) wg = occ_blocks;  // no thin second dispatch round
-        if (wg < 1) wg = 1;
+    // Grid (automatic), from the measurements in profiles/r01_tune*_*.txt:
+    //  * small table image (<= 24 KB of LDS): oversubscribe -- up to 64 workgroups per CU, at least 8
+    //    tiles each; surplus workgroups start as earlier ones retire, which keeps the streams'
+    //    active window compact and evens out the tail; re-staging a few KB per workgroup is free;
+    //  * large table image: a persistent grid of at most 2 co-resident workgroups per CU (staging
+    //    tens of KB and flushing thousands of counters per workgroup is not free).
+    int64_t grid;
+    if (wg_per_cu > 0) {
+        grid = (int64_t)cus * wg_per_cu;
+    } else if (lds > 24 * 1024) {
+        grid = (int64_t)cus * (occ_blocks < 2 ? occ_blocks : 2);
+    } else {
+        grid = ntiles / 8;
+        const int64_t lo = (int64_t)cus * (occ_blocks < 2 ? occ_blocks : 2), hi = (int64_t)cus * 64;
+        if (grid < lo) grid = lo;
+        if (grid > hi) grid = hi;
     }
-    int64_t grid = (int64_t)cus * wg;
     if (grid > ntiles) grid = ntiles;
+    if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(BLOCK), lds, st, p);
     return hipGetLastError();
 }
