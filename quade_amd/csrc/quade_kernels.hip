@@ -457,13 +457,19 @@ __global__ __launch_bounds__(QD_GEN_BLOCK) void demux_generic(const DemuxParams 
     if ((threadIdx.x & 63) == 0 && undet) atomicAdd(reinterpret_cast<unsigned long long*>(&row[2 * S]), (unsigned long long)undet);
 }
 
-// sum the partial rows -> out[2S+1]
+// sum the partial rows -> out[ncnt] (out zeroed by the caller).  blockIdx.y = a group of
+// QD_REDUCE_ROWS rows, thread = one counter: row reads are coalesced across the threads and
+// independent across the rows; one 64-bit atomic per (row group, counter).
+#define QD_REDUCE_ROWS 32
 __global__ void reduce_partials(const u64* partial, uint32_t rows, uint32_t cnt_stride, uint32_t ncnt, u64* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ncnt) return;
+    const uint32_t r0 = blockIdx.y * QD_REDUCE_ROWS;
+    const uint32_t r1 = r0 + QD_REDUCE_ROWS < rows ? r0 + QD_REDUCE_ROWS : rows;
     u64 s = 0;
-    for (uint32_t r = 0; r < rows; ++r) s += partial[(size_t)r * cnt_stride + i];
-    out[i] = s;
+#pragma unroll 8
+    for (uint32_t r = r0; r < r1; ++r) s += partial[(size_t)r * cnt_stride + i];
+    if (s) atomicAdd(reinterpret_cast<unsigned long long*>(&out[i]), (unsigned long long)s);
 }
 
 template <int BLOCK, int SS1, int SS2, bool DUAL>
@@ -546,6 +552,9 @@ hipError_t qd_launch_generic(const DemuxParams& p, int grid, hipStream_t st) {
 hipError_t qd_launch_reduce(const uint64_t* partial, uint32_t rows, uint32_t cnt_stride,
                             uint32_t ncnt, uint64_t* out, hipStream_t st) {
     const int b = 256;
-    hipLaunchKernelGGL(reduce_partials, dim3((ncnt + b - 1) / b), dim3(b), 0, st, partial, rows, cnt_stride, ncnt, out);
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)ncnt * 8, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(reduce_partials, dim3((ncnt + b - 1) / b, (rows + QD_REDUCE_ROWS - 1) / QD_REDUCE_ROWS), dim3(b), 0,
+                       st, partial, rows, cnt_stride, ncnt, out);
     return hipGetLastError();
 }
