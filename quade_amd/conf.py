@@ -70,6 +70,8 @@ write_undetermined : True
 #slots : 3
 # zlib level of the output fastq.gz files (default 6)
 #gzip_level : 6
+# chunks processed concurrently by host threads (default 1); outputs are identical, chunk order kept
+#chunk_workers : 1
 
 ###################################################################################################
 # SAMPLES: one [sampleN] section per sample (N = 1, 2, 3 ...).  Names and barcodes must be unique.
@@ -152,6 +154,7 @@ class QuadeConf(object):
         self.batch_pairs = opt("batch_pairs", 4000000)
         self.slots = opt("slots", 3)
         self.gzip_level = opt("gzip_level", 6)
+        self.chunk_workers = opt("chunk_workers", 1)
 
         self._test_values()
 
@@ -171,8 +174,9 @@ class QuadeConf(object):
         for pos in [self.idx1_pos, self.idx2_pos, self.mol1_pos, self.mol2_pos]:
             assert pos["start"] >= 0
             assert pos["end"] >= pos["start"]
-        assert self.batch_pairs >= 1 and 1 <= self.slots <= 64 and 0 <= self.gzip_level <= 9, \
-            "[gpu] batch_pairs >= 1, 1 <= slots <= 64, 0 <= gzip_level <= 9"
+        assert self.batch_pairs >= 1 and 1 <= self.slots <= 64 and 0 <= self.gzip_level <= 9 and \
+            1 <= self.chunk_workers <= 64, \
+            "[gpu] batch_pairs >= 1, 1 <= slots <= 64, 0 <= gzip_level <= 9, 1 <= chunk_workers <= 64"
 
     def plan(self):
         """The qd_plan the HIP library takes (include/quade_hip.h)."""

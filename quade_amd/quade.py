@@ -119,12 +119,22 @@ class Quade(object):
             import torch  # only to count devices; nothing else of torch is used on this path
             devices = list(range(torch.cuda.device_count()))
         plan = cf.plan()
-        for d in devices:
-            eng = hb.Engine(int(d))  # raises when libquade_hip.so or the GPU is missing: no fallback
-            eng.set_plan(plan)
-            eng.set_barcodes(Sample.BARCODES())
-            eng.slots_create(cf.slots, cf.batch_pairs)
-            self.engines.append(eng)
+        # chunk workers (host threads) each drive their own contexts: a context is single-threaded
+        n_chunks = len(cf.seq_R1)
+        my_chunks = [c for c in range(n_chunks) if c % self.world == self.rank]
+        self.workers = max(1, min(cf.chunk_workers, len(my_chunks)))
+        self.parts = self.world > 1 or self.workers > 1  # per-chunk part files, merged in chunk order
+        self.engine_groups = []
+        for _ in range(self.workers):
+            group = []
+            for d in devices:
+                eng = hb.Engine(int(d))  # raises when libquade_hip.so or the GPU is missing: no fallback
+                eng.set_plan(plan)
+                eng.set_barcodes(Sample.BARCODES())
+                eng.slots_create(cf.slots, cf.batch_pairs)
+                group.append(eng)
+                self.engines.append(eng)
+            self.engine_groups.append(group)
         self.plan, self.layout = plan, self.engines[0].layout
 
         print("Start parsing files: {} chunks to be parsed".format(len(cf.seq_R1)))
@@ -142,14 +152,16 @@ class Quade(object):
         for eng in self.engines:
             eng.close()
         self.engines = []
+        from .dist import allreduce_counts, merge_parts
         if self.world > 1:
-            from .dist import allreduce_counts, merge_parts
             import torch
             dev = torch.device("cuda", int(devices[0])) if dist.get_backend() == "nccl" else None
             counts = allreduce_counts(counts, dist, device=dev)  # the only exchange of the run
             dist.barrier()  # every rank's part files are closed
-            if self.rank == 0:
-                merge_parts(self.outdir, len(cf.seq_R1))
+        if self.parts and self.rank == 0:
+            with _timed("merge chunk parts"):
+                merge_parts(self.outdir, n_chunks)
+        if self.world > 1:
             dist.barrier()
             dist.destroy_process_group()
             if self.rank != 0:
@@ -169,48 +181,80 @@ class Quade(object):
 
     def double_index_parser(self):
         cf = self.cf
-        chunks = list(zip(cf.seq_R1, cf.seq_R2, cf.index_R1, cf.index_R2))
-        for n, streams in self._open_ahead(chunks):
-            print("Start parsing chunk {}".format(n + 1))
-            self._parse_chunk(streams)
-            print("\tEnd of chunk {}".format(n + 1))
+        self._run_chunks(list(zip(cf.seq_R1, cf.seq_R2, cf.index_R1, cf.index_R2)), "Start parsing chunk {0}")
 
     def simple_index_parser(self):
         cf = self.cf
-        chunks = list(zip(cf.seq_R1, cf.seq_R2, cf.index_R1))
-        for n, streams in self._open_ahead(chunks):
-            print("Start parsing chunk {}/{}".format(n + 1, len(cf.seq_R1)))
-            self._parse_chunk(streams)
-            print("\tEnd of chunk {}".format(n + 1))
+        self._run_chunks(list(zip(cf.seq_R1, cf.seq_R2, cf.index_R1)), "Start parsing chunk {0}/{1}")
 
-    def _open_ahead(self, chunks, lookahead=2):
-        """Yields (chunk index, opened streams) for this rank's chunks in order, keeping the next
-        `lookahead` chunks' files open so that their read-ahead (gunzip) threads already run; chunks
-        are still consumed strictly in order (src/Quade.py:198,229).  In multi-process mode the
-        writers are pointed at the chunk's own part directory first."""
+    def _run_chunks(self, chunks, banner):
+        """This rank's chunks (chunk c belongs to rank c mod world).  One worker: chunks strictly in
+        order, with the next chunks' files already open so that their gunzip read-ahead runs
+        (src/Quade.py:198,229).  Several workers: host threads take chunks from a queue; every chunk's
+        records go to that chunk's own part directory and the parts are concatenated in chunk order
+        afterwards, so the outputs do not depend on which worker ran which chunk."""
         from .dist import chunk_owner, part_dir
+        from .sample import WriterSet
         mine = [c for c in range(len(chunks)) if chunk_owner(c, self.world) == self.rank]
-        opened = deque()
-        nxt = 0
-        try:
-            for i, c in enumerate(mine):
-                while nxt < len(mine) and nxt <= i + lookahead:
-                    opened.append([FastqStream(f) for f in chunks[mine[nxt]]])
-                    nxt += 1
-                if self.world > 1:
-                    d = part_dir(self.outdir, c)
-                    os.makedirs(d, exist_ok=True)
-                    Sample.RETARGET(d)
-                yield c, opened.popleft()
-        finally:
-            for streams in opened:
-                for st in streams:
-                    st.close()
+
+        def one_chunk(c, streams, engines):
+            print(banner.format(c + 1, len(chunks)))
+            writers = None
+            if self.parts:
+                d = part_dir(self.outdir, c)
+                os.makedirs(d, exist_ok=True)
+                writers = WriterSet(d, self.cf.gzip_level)
+            self._parse_chunk(streams, engines, writers)
+            if writers:
+                writers.close()
+            print("\tEnd of chunk {}".format(c + 1))
+
+        if self.workers == 1:
+            lookahead, opened, nxt = 2, deque(), 0
+            try:
+                for i, c in enumerate(mine):
+                    while nxt < len(mine) and nxt <= i + lookahead:
+                        opened.append([FastqStream(f) for f in chunks[mine[nxt]]])
+                        nxt += 1
+                    one_chunk(c, opened.popleft(), self.engine_groups[0])
+            finally:
+                for streams in opened:
+                    for st in streams:
+                        st.close()
+            return
+
+        import queue
+        import threading
+        todo = queue.Queue()
+        for c in mine:
+            todo.put(c)
+        errors = []
+
+        def worker(engines):
+            while not errors:
+                try:
+                    c = todo.get_nowait()
+                except queue.Empty:
+                    return
+                try:
+                    one_chunk(c, [FastqStream(f) for f in chunks[c]], engines)
+                except BaseException as e:  # surfaced in the main thread
+                    errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(g,), name="quade-chunk-%d" % i)
+                   for i, g in enumerate(self.engine_groups)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
 
     # ~~~~~~~ PRIVATE METHODS ~~~~~~~ #
-    def _parse_chunk(self, streams):
+    def _parse_chunk(self, streams, engines, writers=None):
         """One chunk = 3 or 4 files read in lock step; the chunk ends at the first exhausted
-        stream (src/Quade.py:210-224)."""
+        stream (src/Quade.py:210-224).  `engines`: the contexts this caller drives (round robin);
+        `writers`: a WriterSet for the chunk's part directory, or None for the run's own writers."""
         B = self.cf.batch_pairs
         L = self.layout
         r1s, r2s, idx = streams[0], streams[1], streams[2:]
@@ -219,11 +263,11 @@ class Quade(object):
         last = False
         try:
             while not last:
-                eng = self.engines[b % len(self.engines)]
-                slot = (b // len(self.engines)) % eng.n_slots
+                eng = engines[b % len(engines)]
+                slot = (b // len(engines)) % eng.n_slots
                 # the slot may still hold an older batch: consume in order until it is free
                 while any(e is eng and s == slot for e, s, *_ in inflight):
-                    self._finish(inflight.popleft())
+                    self._finish(inflight.popleft(), writers)
                 v = eng.slot(slot)
                 with _timed("scan insert reads"):
                     r1_text, r1_off = r1s.take(B)
@@ -242,12 +286,12 @@ class Quade(object):
                 inflight.append((eng, slot, n, has_len, r1_text, r1_off, r2_text, r2_off))
                 b += 1
             while inflight:
-                self._finish(inflight.popleft())
+                self._finish(inflight.popleft(), writers)
         finally:
             for st in streams:
                 st.close()
 
-    def _finish(self, item):
+    def _finish(self, item, writers=None):
         eng, slot, n, has_len, r1_text, r1_off, r2_text, r2_off = item
         with _timed("wait device"):
             eng.wait(slot)
@@ -256,7 +300,7 @@ class Quade(object):
             tags, tag_len = hb.build_tags(self.layout, self.plan, n, v["seq"], v["len"] if has_len else None,
                                           mol_rows=v["mol"])
         with _timed("route + format + queue gzip"):
-            Sample.FINDER(Batch(n, r1_text, r1_off, r2_text, r2_off, v["codes"], tags, tag_len))
+            Sample.FINDER(Batch(n, r1_text, r1_off, r2_text, r2_off, v["codes"], tags, tag_len), writers)
 
 
 def main(argv=None):

@@ -26,62 +26,29 @@ class Batch(object):
         self.codes, self.tags, self.tag_len = codes, tags, tag_len
 
 
-class Sample(object):
-    # Counters for the overall number of read at class level (src/Sample.py:32)
-    TOTAL = FAIL_QUAL = PASS_QUAL = UNDETERMINED = 0
-    WRITE_UNDETERMINED = WRITE_PASS = WRITE_FAIL = False
-    NAME_TO_SAMPLE = {}
-    INDEX_TO_SAMPLE = {}
-    SAMPLE_LIST = []
-    DNA = ["A", "T", "C", "G", "N"]
-    MIN_QUAL = 0
-    OUTDIR = "."
-    GZIP_LEVEL = 6
-    UNDETERMINED_WRITER = None
+class WriterSet(object):
+    """The pass / fail / Undetermined writers of one output directory, created on first use.
+    Sample owns one for the run's output directory; chunk workers and the multi-process mode use
+    one per chunk part directory."""
 
-    # ~~~~~~~ CLASS METHODS ~~~~~~~ #
-    @classmethod
-    def RESET(cls):
-        """Forget every sample and counter (the reference needs a fresh process for that)."""
-        cls.TOTAL = cls.FAIL_QUAL = cls.PASS_QUAL = cls.UNDETERMINED = 0
-        cls.NAME_TO_SAMPLE = {}
-        cls.INDEX_TO_SAMPLE = {}
-        cls.SAMPLE_LIST = []
-        cls.UNDETERMINED_WRITER = None
+    def __init__(self, outdir, gzip_level):
+        self.outdir, self.gzip_level = outdir, gzip_level
+        self._w = {}
 
-    @classmethod
-    def CLASS_INIT(cls, write_undetermined=False, write_pass=False, write_fail=False, min_qual=0,
-                   outdir=".", gzip_level=6):
-        """src/Sample.py:48-54 (+ output directory and gzip level, defaulted)"""
-        cls.WRITE_UNDETERMINED = write_undetermined
-        cls.WRITE_PASS = write_pass
-        cls.WRITE_FAIL = write_fail
-        cls.MIN_QUAL = min_qual
-        cls.OUTDIR = outdir
-        cls.GZIP_LEVEL = gzip_level
-        cls.UNDETERMINED_WRITER = FastqWriter("Undetermined", outdir, gzip_level)
+    def get(self, code):
+        """code: 0xFFFF, 2*ordinal (pass) or 2*ordinal+1 (fail)"""
+        w = self._w.get(code)
+        if w is None:
+            if code == hb.CODE_UNDETERMINED:
+                name = "Undetermined"
+            else:
+                name = "{}_{}".format(Sample.SAMPLE_LIST[code >> 1].name, "fail" if code & 1 else "pass")
+            w = self._w[code] = FastqWriter(name, self.outdir, self.gzip_level)
+        return w
 
-    @classmethod
-    def RETARGET(cls, outdir):
-        """Close every writer and point it at `outdir` (files are again created lazily there).
-        Used by the multi-process mode, where each chunk's records go to that chunk's own part
-        directory and the parts are concatenated in chunk order afterwards."""
-        cls.FLUSH_ALL()
-        cls.OUTDIR = outdir
-        cls.UNDETERMINED_WRITER = FastqWriter("Undetermined", outdir, cls.GZIP_LEVEL)
-        for s in cls.SAMPLE_LIST:
-            s.pass_writer = FastqWriter("{}_pass".format(s.name), outdir, cls.GZIP_LEVEL)
-            s.fail_writer = FastqWriter("{}_fail".format(s.name), outdir, cls.GZIP_LEVEL)
-
-    @classmethod
-    def BARCODES(cls):
-        """Upper-case barcodes in ordinal order: the table handed to qd_set_barcodes."""
-        return [s.index for s in cls.SAMPLE_LIST]
-
-    @classmethod
-    def FINDER(cls, batch: Batch):
-        """Route one batch (src/Sample.py:56-91 for every pair of it).  Codes: 0xFFFF undetermined,
-        2*ordinal pass, 2*ordinal+1 fail.  Within a destination the input order is kept."""
+    def route(self, batch):
+        """src/Sample.py:56-91 for every pair of the batch, counters excluded (they come from the
+        device).  Within a destination the input order is kept."""
         n = batch.n
         if n == 0:
             return
@@ -94,22 +61,71 @@ class Sample(object):
         for lo, hi in zip(starts, ends):
             code = int(sorted_codes[lo])
             if code == hb.CODE_UNDETERMINED:
-                if not cls.WRITE_UNDETERMINED:
+                if not Sample.WRITE_UNDETERMINED:
                     continue
-                writer = cls.UNDETERMINED_WRITER
-            else:
-                sample = cls.SAMPLE_LIST[code >> 1]
-                if code & 1:
-                    if not cls.WRITE_FAIL:
-                        continue
-                    writer = sample.fail_writer
-                else:
-                    if not cls.WRITE_PASS:
-                        continue
-                    writer = sample.pass_writer
+            elif code & 1:
+                if not Sample.WRITE_FAIL:
+                    continue
+            elif not Sample.WRITE_PASS:
+                continue
             sel = order[lo:hi]
-            writer(hb.format_records(batch.r1_text, batch.r1_off, sel, batch.tags, batch.tag_len),
-                   hb.format_records(batch.r2_text, batch.r2_off, sel, batch.tags, batch.tag_len), hi - lo)
+            self.get(code)(hb.format_records(batch.r1_text, batch.r1_off, sel, batch.tags, batch.tag_len),
+                           hb.format_records(batch.r2_text, batch.r2_off, sel, batch.tags, batch.tag_len), hi - lo)
+
+    def close(self):
+        for w in self._w.values():
+            w.close()
+
+
+class Sample(object):
+    # Counters for the overall number of read at class level (src/Sample.py:32)
+    TOTAL = FAIL_QUAL = PASS_QUAL = UNDETERMINED = 0
+    WRITE_UNDETERMINED = WRITE_PASS = WRITE_FAIL = False
+    NAME_TO_SAMPLE = {}
+    INDEX_TO_SAMPLE = {}
+    SAMPLE_LIST = []
+    DNA = ["A", "T", "C", "G", "N"]
+    MIN_QUAL = 0
+    OUTDIR = "."
+    GZIP_LEVEL = 6
+    UNDETERMINED_WRITER = None
+    WRITERS = None  # WriterSet of the run's output directory
+
+    # ~~~~~~~ CLASS METHODS ~~~~~~~ #
+    @classmethod
+    def RESET(cls):
+        """Forget every sample and counter (the reference needs a fresh process for that)."""
+        cls.TOTAL = cls.FAIL_QUAL = cls.PASS_QUAL = cls.UNDETERMINED = 0
+        cls.NAME_TO_SAMPLE = {}
+        cls.INDEX_TO_SAMPLE = {}
+        cls.SAMPLE_LIST = []
+        cls.UNDETERMINED_WRITER = None
+        cls.WRITERS = None
+
+    @classmethod
+    def CLASS_INIT(cls, write_undetermined=False, write_pass=False, write_fail=False, min_qual=0,
+                   outdir=".", gzip_level=6):
+        """src/Sample.py:48-54 (+ output directory and gzip level, defaulted)"""
+        cls.WRITE_UNDETERMINED = write_undetermined
+        cls.WRITE_PASS = write_pass
+        cls.WRITE_FAIL = write_fail
+        cls.MIN_QUAL = min_qual
+        cls.OUTDIR = outdir
+        cls.GZIP_LEVEL = gzip_level
+        cls.WRITERS = WriterSet(outdir, gzip_level)
+        cls.UNDETERMINED_WRITER = cls.WRITERS.get(hb.CODE_UNDETERMINED)
+
+    @classmethod
+    def BARCODES(cls):
+        """Upper-case barcodes in ordinal order: the table handed to qd_set_barcodes."""
+        return [s.index for s in cls.SAMPLE_LIST]
+
+    @classmethod
+    def FINDER(cls, batch: Batch, writers=None):
+        """Route one batch (src/Sample.py:56-91 for every pair of it).  Codes: 0xFFFF undetermined,
+        2*ordinal pass, 2*ordinal+1 fail.  `writers`: a WriterSet other than the run's own (chunk
+        part directories)."""
+        (writers or cls.WRITERS).route(batch)
 
     @classmethod
     def SET_COUNTS(cls, counts):
@@ -130,11 +146,8 @@ class Sample(object):
     @classmethod
     def FLUSH_ALL(cls):
         """src/Sample.py:93-102; also closes the files"""
-        for sample in cls.SAMPLE_LIST:
-            sample.pass_writer.close()
-            sample.fail_writer.close()
-        if cls.UNDETERMINED_WRITER:
-            cls.UNDETERMINED_WRITER.close()
+        if cls.WRITERS:
+            cls.WRITERS.close()
 
     @classmethod
     def REPORT(cls):
@@ -173,8 +186,6 @@ class Sample(object):
         assert self._is_dna(index), "{} : Non canonical DNA base in index".format(self.name)
         self.pass_qual = self.fail_qual = 0
         self.ordinal = len(cls.SAMPLE_LIST)
-        self.pass_writer = FastqWriter("{}_pass".format(self.name), cls.OUTDIR, cls.GZIP_LEVEL)
-        self.fail_writer = FastqWriter("{}_fail".format(self.name), cls.OUTDIR, cls.GZIP_LEVEL)
         cls.INDEX_TO_SAMPLE[self.index] = self
         cls.NAME_TO_SAMPLE[self.name] = self
         cls.SAMPLE_LIST.append(self)
@@ -182,6 +193,14 @@ class Sample(object):
     @property
     def total(self):
         return self.pass_qual + self.fail_qual
+
+    @property
+    def pass_writer(self):
+        return type(self).WRITERS.get(2 * self.ordinal)
+
+    @property
+    def fail_writer(self):
+        return type(self).WRITERS.get(2 * self.ordinal + 1)
 
     def __repr__(self):
         return "<Instance of {} from {} >\n".format(self.__class__.__name__, self.__module__)

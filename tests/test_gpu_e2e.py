@@ -149,6 +149,9 @@ SCENARIOS = {
     # two contexts (both on GPU 0 here) fed round-robin: output order must still equal input order
     "two_engines_round_robin": dict(dual=True, idx_len=8, pos=((1, 8), (1, 8), None, None), minq=25,
                                     gpu="[gpu]\ndevices : 0 0\nbatch_pairs : 23\nslots : 2\n"),
+    # three host threads take chunks from a queue; per-chunk parts merged in chunk order
+    "chunk_workers_threads": dict(dual=True, idx_len=14, pos=((1, 8), (1, 8), (9, 14), None), minq=25, malformed=True,
+                                  gpu="[gpu]\nchunk_workers : 3\nbatch_pairs : 31\nslots : 2\n"),
     "wide_window_generic": dict(dual=False, idx_len=24, pos=((1, 20), None, (21, 24), None), minq=10),
 }
 

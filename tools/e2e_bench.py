@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 level = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-n_chunks = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # the same files listed n_chunks times
+n_chunks = int(sys.argv[3]) if len(sys.argv) > 3 and not sys.argv[3].startswith("--") else 1  # same files listed n_chunks times
+workers = int(os.environ.get("E2E_WORKERS", "1"))
 prepare_only = "--prepare-only" in sys.argv
 rng = np.random.default_rng(5)
 S = 96
@@ -52,7 +53,7 @@ with open(conf, "w") as fh:
     fh.write("[quality]\nminimal_qual : 25\n[fastq]\n" + "".join("%s : %s\n" % (k, "  ".join([v] * n_chunks)) for k, v in paths.items()) +
              "[index]\nindex2 : True\nmolecular1 : False\nmolecular2 : False\nindex1_start : 1\nindex1_end : 8\n"
              "index2_start : 1\nindex2_end : 8\n[output]\nwrite_pass : True\nwrite_fail : True\nwrite_undetermined : True\n"
-             "[gpu]\nbatch_pairs : 1000000\ngzip_level : %d\n" % level +
+             "[gpu]\nbatch_pairs : 1000000\ngzip_level : %d\nchunk_workers : %d\n" % (level, workers) +
              "".join("[sample%d]\nname : S%d\nindex1_seq : %s\nindex2_seq : %s\n" % (i + 1, i + 1, a, b) for i, (a, b) in enumerate(bcs)))
 out = os.path.join(work, "out")
 os.mkdir(out)
@@ -67,4 +68,4 @@ q()
 dt = time.perf_counter() - t0
 n *= n_chunks
 print(json.dumps({"mode": "end-to-end fastq.gz -> fastq.gz", "chunks": n_chunks, "pairs": n, "seconds": dt, "pairs_per_s": n / dt,
-                  "gzip_level": level, "counts": Sample.COUNTS()[:4], "host_cores_used": 1}))
+                  "gzip_level": level, "counts": Sample.COUNTS()[:4], "chunk_workers": workers}))
