@@ -150,3 +150,55 @@ def test_error_returns(engine):
     with pytest.raises(hb.QuadeHipError) as ei:
         engine.set_plan(hb.make_plan(False, 25, (0, 6)))  # slots exist
     assert ei.value.code == hb.QD_ERR_STATE
+
+
+def test_random_plans_fuzz(engine):
+    """Random slice positions / widths / single-dual / molecular combinations (every branch of the
+    window and fusion logic of both kernels), random read lengths around the window: HIP == C oracle."""
+    from quade_amd.hip_backend import make_plan, plan_layout
+    rng = np.random.default_rng(2026)
+    kinds = {"fast": 0, "generic": 0}
+    for it in range(160):
+        dual = bool(rng.integers(0, 2))
+        def span(maxw):
+            s = int(rng.integers(0, 12))
+            return (s, s + int(rng.integers(0, maxw + 1)))
+        big = it % 5 == 4  # every fifth plan leaves the fast kernel's envelope (wide slices)
+        i1 = span(14 if big else 8)
+        i2 = span(14 if big else 8) if dual else (0, 0)
+        m1 = span(12 if big else 8) if rng.integers(0, 2) else (0, 0)
+        m2 = span(8) if dual and rng.integers(0, 2) else (0, 0)
+        if (i1[1] - i1[0]) + (i2[1] - i2[0]) == 0:
+            i1 = (i1[0], i1[0] + 5)
+        plan = make_plan(dual, int(rng.integers(0, 41)), i1, i2, m1, m2)
+        lay = plan_layout(plan)
+        K = lay.key_width
+        w1 = i1[1] - i1[0]
+        bcs = _barcodes(rng, min(int(rng.integers(1, 40)), 4 ** min(K, 8) // 2 + 1), K)
+        n = 2500
+        ragged = it % 3 == 0
+        reads = []
+        for k in range(lay.n_streams):
+            L = max(i1[1], m1[1]) if k == 0 else max(i2[1], m2[1])
+            L = max(L, 1) + int(rng.integers(0, 3))
+            part = [b[:w1] for b in bcs] if k == 0 else [b[w1:] for b in bcs]
+            s, q = _random_reads(rng, n, L, part, i1[0] if k == 0 else i2[0], frac_hit=0.0)
+            reads.append([s, q, L])
+        for i in range(0, n, 2):  # plant matching barcodes in half of the pairs
+            b = bcs[int(rng.integers(0, len(bcs)))].encode()
+            for k in range(lay.n_streams):
+                s, q, L = reads[k]
+                st, bb = (i1[0], b[:w1]) if k == 0 else (i2[0], b[w1:])
+                s[i] = s[i][:st] + bb + s[i][st + len(bb):]
+        if ragged:
+            for k in range(lay.n_streams):
+                s, q, L = reads[k]
+                for i in rng.integers(0, n, 200):
+                    c = int(rng.integers(0, L + 1))
+                    s[i], q[i] = s[i][:c], q[i][:c]
+        codes, counts = _run_vs_c_oracle(engine, plan, bcs, [(r[0], r[1]) for r in reads])
+        kinds[engine.kernel_kind(ragged)] += 1
+        assert counts[0] == n
+        if it % 20 == 19:
+            print("fuzz: %d plans done" % (it + 1), kinds, flush=True)
+    assert kinds["fast"] > 40 and kinds["generic"] > 40
