@@ -79,7 +79,8 @@ typedef struct qd_plan {
  *   len row  : optional uint8 per read = min(255, read length).  Omitted (NULL) when every read of
  *              the batch covers its whole window -- then the fast kernels run.
  * Outputs: codes = uint16 per pair; mol = mol_width bytes per pair (raw case, I1 part then I2 part
- * packed together, zero padded when reads are short) -- Quade.py:218.  Strides are powers of two.   */
+ * packed together, zero padded when reads are short) -- Quade.py:218.  A stride is its window's width
+ * rounded up to an even number of bytes (minimum 2), so rows carry at most one byte of padding.     */
 typedef struct qd_layout {
     int32_t n_streams;
     int32_t seq_off[2], seq_width[2], seq_stride[2];

@@ -49,10 +49,11 @@ inline void pack_row(const qd_layout* L, int k, const uint8_t* seq, const uint8_
     memset(qrow + avail, 0xFF, (size_t)(qs - avail));
 }
 
-int32_t pow2_at_least(int32_t v, int32_t lo) {
-    int32_t s = lo;
-    while (s < v) s <<= 1;
-    return s;
+// row stride of a window: its width rounded up to an even number of bytes (so that the rows of two
+// consecutive reads start 4-byte aligned), at least 2
+int32_t even_stride(int32_t width) {
+    const int32_t s = (width + 1) & ~1;
+    return s < 2 ? 2 : s;
 }
 
 }  // namespace
@@ -87,10 +88,10 @@ int qd_plan_layout(const qd_plan* P, qd_layout* L) {
         if (hi - lo > QD_MAX_WINDOW) return QD_ERR_UNSUPPORTED;
         L->seq_off[k] = lo;
         L->seq_width[k] = hi - lo;
-        L->seq_stride[k] = pow2_at_least(hi - lo, 8);
+        L->seq_stride[k] = even_stride(hi - lo);
         L->qual_off[k] = is[k];
         L->qual_width[k] = iw;
-        L->qual_stride[k] = pow2_at_least(iw, 8);
+        L->qual_stride[k] = even_stride(iw);
         L->key_width += iw;
         L->mol_width += mw;
     }

@@ -192,7 +192,8 @@ int rebuild(qd_ctx* c) {
     const qd_layout& L = c->lay;
     bool ok = (K >= 1 && K <= 16 && L.mol_width <= 16 && c->lds_bytes <= 150 * 1024);
     for (int k = 0; k < L.n_streams; ++k) {
-        ok = ok && (L.seq_stride[k] == 8 || L.seq_stride[k] == 16) && L.qual_stride[k] == 8;
+        // rows of two reads in at most two 16-byte loads; slices of at most 8 bytes
+        ok = ok && L.seq_stride[k] <= 16 && L.qual_stride[k] <= 8;
         const int mw = (k == 0 ? c->plan.mol1_end - c->plan.mol1_start : c->plan.mol2_end - c->plan.mol2_start);
         ok = ok && mw <= 8 && L.qual_width[k] <= 8;
     }

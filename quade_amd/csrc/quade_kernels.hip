@@ -7,9 +7,10 @@
 //
 // This is byte/integer work bound by HBM bandwidth; there is no contraction in it, so no MFMA.
 // Design (DESIGN.md has the numbers):
-//   * demux_fast<>: rows of 8 or 16 bytes are read as 16-byte-per-lane vector loads
-//     (global_load_dwordx4, lane i <-> consecutive 16 B: fully coalesced, 1 KiB per wave
-//     instruction); all loads of a tile are issued before any is consumed.
+//   * demux_fast<>: the rows of a lane's two pairs are read with 16-byte-per-lane vector loads
+//     (global_load_dwordx4 nt; 8-byte rows: lane i <-> consecutive 16 B, fully coalesced, 1 KiB per
+//     wave instruction; other even strides <= 16: 4-byte-aligned 16-byte loads over exact-width
+//     rows); all loads of a tile are issued before any is consumed, the next tile is in flight.
 //   * the barcode table (open-addressing slots + 16-byte canonical keys) and the per-sample
 //     histogram live in LDS, staged once per workgroup; workgroups are persistent (grid = a few per
 //     CU) and stride over tiles, so staging is amortised over >= 10^5 pairs.
@@ -39,23 +40,6 @@ __device__ __forceinline__ U128 ld16(const uint8_t* p) {
     return U128{v.x, v.y};
 }
 __device__ __forceinline__ u64 ld8(const uint8_t* p) { return *reinterpret_cast<const u64*>(p); }
-
-// bytes [off, off+w) of a row (w <= 8) as a little-endian integer. off, w are wave-uniform.
-template <int STRIDE>
-__device__ __forceinline__ u64 window(u64 lo, u64 hi, int off, u64 mask) {
-    u64 v;
-    if (STRIDE == 8) {
-        v = lo >> (8 * off);
-    } else {
-        if (off >= 8)
-            v = hi >> (8 * (off - 8));
-        else if (off == 0)
-            v = lo;
-        else
-            v = (lo >> (8 * off)) | (hi << (64 - 8 * off));
-    }
-    return v & mask;
-}
 
 // I1 part (w1 bytes) followed by I2 part: the canonical little-endian packing of the fused string.
 __device__ __forceinline__ void fuse(u64 a, u64 b, int w1, u64& lo, u64& hi) {
@@ -144,26 +128,20 @@ __device__ __forceinline__ void store_mol2(uint8_t* dst, u64 alo, u64 ahi, u64 b
     }
 }
 
-// One pair through the whole path.  Returns the routing code.
-template <int SS1, int SS2, bool DUAL>
-__device__ __forceinline__ uint32_t do_pair(const DemuxParams& p, const LdsTable& t, u64 s1lo, u64 s1hi,
-                                            u64 q1, u64 s2lo, u64 s2hi, u64 q2, u64& mlo, u64& mhi) {
-    // a1: barcode slice(s), fused (Quade.py:217 / :246)
-    u64 k1 = window<SS1>(s1lo, s1hi, p.idx_off[0], p.idx_mask[0]);
+// One pair from its extracted slices to its routing code: fuse, fold, match, gate, count.
+// k1/k2 = barcode slices of index read 1/2 (<= 8 bytes each, little-endian, masked), m1/m2 = molecular
+// slices, q1/q2 = quality bytes of the barcode slices (bytes beyond the slice = 0xFF).
+template <bool DUAL>
+__device__ __forceinline__ uint32_t match_pair(const DemuxParams& p, const LdsTable& t, u64 k1, u64 k2, u64 m1,
+                                               u64 m2, u64 q1, u64 q2, u64& mlo, u64& mhi) {
+    // a1: fused barcode (Quade.py:217 / :246)
     u64 klo = k1, khi = 0;
-    if (DUAL) {
-        u64 k2 = window<SS2>(s2lo, s2hi, p.idx_off[1], p.idx_mask[1]);
-        fuse(k1, k2, p.idx_w[0], klo, khi);
-    }
-    // a2: molecular slice(s), fused, raw case (Quade.py:218 / :247)
+    if (DUAL) fuse(k1, k2, p.idx_w[0], klo, khi);
+    // a2: fused molecular index, raw case (Quade.py:218 / :247)
     if (p.M > 0) {
-        u64 m1 = window<SS1>(s1lo, s1hi, p.mol_off[0], p.mol_mask[0]);
         mlo = m1;
         mhi = 0;
-        if (DUAL) {
-            u64 m2 = window<SS2>(s2lo, s2hi, p.mol_off[1], p.mol_mask[1]);
-            fuse(m1, m2, p.mol_w[0], mlo, mhi);
-        }
+        if (DUAL) fuse(m1, m2, p.mol_w[0], mlo, mhi);
     }
     // a3: fold for the lookup only (Sample.py:65)
     klo = qd_fold8(klo);
@@ -186,9 +164,29 @@ __device__ __forceinline__ uint32_t do_pair(const DemuxParams& p, const LdsTable
     return code;
 }
 
+// codes and molecular bytes of the lane's two pairs (p0 even): one dword, 64-bit molecular stores
+__device__ __forceinline__ void store_unit(const DemuxParams& p, int64_t p0, bool two, uint32_t c0, uint32_t c1,
+                                           u64 m0lo, u64 m0hi, u64 m1lo, u64 m1hi) {
+    // a7: routing codes, 2 x uint16 per lane = one dword store, coalesced
+    if (two)
+        *reinterpret_cast<uint32_t*>(p.codes + p0) = c0 | (c1 << 16);
+    else
+        p.codes[p0] = (uint16_t)c0;
+    if (p.M > 0) {
+        if (two)
+            store_mol2(p.mol + p0 * p.M, m0lo, m0hi, m1lo, m1hi, p.M);
+        else
+            store_mol(p.mol + p0 * p.M, m0lo, m0hi, p.M);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
-// Fast kernel.  Lane handles UNITS x 2 consecutive pairs per tile.  Row strides: seq SS1/SS2 in
-// {8,16}, qual rows 8 bytes.  Rows are read once and never again: loads are non-temporal.
+// Fast kernel.  A lane handles UNITS x 2 consecutive pairs per tile; rows are read once and never
+// again, so loads are non-temporal.  Two row forms (policy structs below):
+//   Rows8 : every stride is 8 (the 8 bp index configs): one aligned 16-byte load = the rows of 2 pairs
+//   RowsX : any even strides <= 16 (exact-width rows, e.g. 14-byte windows): the 2*stride bytes of
+//           the lane's 2 pairs are read with one or two 4-byte-aligned 16-byte loads and the slices
+//           are taken at run-time byte offsets
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ U128 ld16s(const uint8_t* p) {
 #if QD_FAST_NT
@@ -200,116 +198,217 @@ __device__ __forceinline__ U128 ld16s(const uint8_t* p) {
 #endif
 }
 
-template <int SS1, int SS2, bool DUAL, int UNITS>
-struct Tile {
-    U128 s1[UNITS][SS1 / 8], s2[UNITS][SS2 / 8], q1[UNITS], q2[UNITS];
+// 16 bytes from a 4-byte-aligned address (global_load_dwordx4 needs dword alignment only)
+__device__ __forceinline__ U128 ld16u(const uint8_t* p) {
+    typedef unsigned int v4u32a __attribute__((ext_vector_type(4), aligned(4)));
+#if QD_FAST_NT
+    const v4u32a v = __builtin_nontemporal_load(reinterpret_cast<const v4u32a*>(p));
+#else
+    const v4u32a v = *reinterpret_cast<const v4u32a*>(p);
+#endif
+    return U128{(u64)v.x | ((u64)v.y << 32), (u64)v.z | ((u64)v.w << 32)};
+}
+
+// exactly nbytes (even, <= 16*NW/2... ) from a 2-byte-aligned address, zero filled: used for the
+// batch's last tile only, where a 16-byte load could run past the end of the array
+template <int NW>
+__device__ __forceinline__ void ld_exact(u64 (&w)[NW], const uint8_t* p, int nbytes) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) w[j] = 0;
+#pragma unroll
+    for (int j = 0; j < 2 * NW; ++j) {
+        uint32_t d = 0;
+        if (4 * j + 4 <= nbytes)
+            d = *reinterpret_cast<const uint32_t*>(p + 4 * j);
+        else if (4 * j + 2 <= nbytes)
+            d = *reinterpret_cast<const uint16_t*>(p + 4 * j);
+        w[j >> 1] |= (u64)d << (32 * (j & 1));
+    }
+}
+
+// bytes [start, start+8) of a little-endian block of NW 64-bit words (beyond the block: zero);
+// `start` is wave-uniform, the word selects are uniform-condition moves (no dynamic register index)
+template <int NW>
+__device__ __forceinline__ u64 take8(const u64 (&w)[NW], int start) {
+    const int i = start >> 3, sh = (start & 7) * 8;
+    u64 a = 0, b = 0;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        a = (i == j) ? w[j] : a;
+        b = (i + 1 == j) ? w[j] : b;
+    }
+    return sh ? (a >> sh) | (b << (64 - sh)) : a;
+}
+
+// ---- Rows8: all strides 8 ------------------------------------------------------------------------
+template <int BLOCK_, bool DUAL, int UNITS>
+struct Rows8 {
+    static constexpr int BLOCK = BLOCK_;
+    static constexpr bool PREFETCH = QD_FAST_PREFETCH != 0;   // 64 B per lane per tile: double-buffer
+    static constexpr bool GUARD_LAST = false;                 // aligned loads never leave the rows
+    struct Tile {
+        U128 s1[UNITS], q1[UNITS], s2[UNITS], q2[UNITS];
+    };
+
+    template <bool FULL>
+    static __device__ __forceinline__ void load(Tile& T, const DemuxParams& p, int64_t base, uint32_t tid) {
+        const int64_t n = p.n;
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int64_t p0 = base + ((int64_t)u * BLOCK + tid) * 2;  // first pair of the unit
+            if (FULL || p0 + 1 < n) {
+                T.s1[u] = ld16s(p.seq[0] + p0 * 8);
+                T.q1[u] = ld16s(p.qual[0] + p0 * 8);
+                if (DUAL) {
+                    T.s2[u] = ld16s(p.seq[1] + p0 * 8);
+                    T.q2[u] = ld16s(p.qual[1] + p0 * 8);
+                }
+            } else if (p0 < n) {  // last, odd pair of the batch: never read past row n-1
+                T.s1[u] = U128{ld8(p.seq[0] + p0 * 8), 0};
+                T.q1[u] = U128{ld8(p.qual[0] + p0 * 8), 0};
+                if (DUAL) {
+                    T.s2[u] = U128{ld8(p.seq[1] + p0 * 8), 0};
+                    T.q2[u] = U128{ld8(p.qual[1] + p0 * 8), 0};
+                }
+            }
+        }
+    }
+
+    // TAG only makes the copies of this code distinct (an assembler comment), so that the compiler
+    // does not fold the copy that runs with younger loads in flight into the copy that runs without:
+    // a folded copy has to assume the younger loads are missing and waits for everything.
+    template <bool FULL, int TAG>
+    static __device__ __forceinline__ uint32_t compute(const Tile& T, const DemuxParams& p, const LdsTable& t,
+                                                       int64_t base, uint32_t tid) {
+        asm volatile("; demux tile copy %0" ::"i"(TAG));
+        const int64_t n = p.n;
+        uint32_t undet = 0;
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int64_t p0 = base + ((int64_t)u * BLOCK + tid) * 2;
+            if (!FULL && p0 >= n) continue;
+            const bool two = FULL || (p0 + 1 < n);
+            const int sh1 = 8 * p.idx_off[0], sh2 = 8 * p.idx_off[1];
+            const int mh1 = 8 * p.mol_off[0], mh2 = 8 * p.mol_off[1];
+            u64 m0lo = 0, m0hi = 0, m1lo = 0, m1hi = 0;
+            // pair p0 = low words, pair p0+1 = high words of the 16-byte loads
+            const uint32_t c0 = match_pair<DUAL>(
+                p, t, (T.s1[u].lo >> sh1) & p.idx_mask[0], DUAL ? (T.s2[u].lo >> sh2) & p.idx_mask[1] : 0,
+                (T.s1[u].lo >> mh1) & p.mol_mask[0], DUAL ? (T.s2[u].lo >> mh2) & p.mol_mask[1] : 0, T.q1[u].lo,
+                DUAL ? T.q2[u].lo : 0, m0lo, m0hi);
+            uint32_t c1 = 0;
+            if (two)
+                c1 = match_pair<DUAL>(
+                    p, t, (T.s1[u].hi >> sh1) & p.idx_mask[0], DUAL ? (T.s2[u].hi >> sh2) & p.idx_mask[1] : 0,
+                    (T.s1[u].hi >> mh1) & p.mol_mask[0], DUAL ? (T.s2[u].hi >> mh2) & p.mol_mask[1] : 0, T.q1[u].hi,
+                    DUAL ? T.q2[u].hi : 0, m1lo, m1hi);
+            undet += (c0 == QD_CODE_UNDET) + (two && c1 == QD_CODE_UNDET);
+            store_unit(p, p0, two, c0, c1, m0lo, m0hi, m1lo, m1hi);
+        }
+        return undet;
+    }
 };
 
-// issue every load of a tile (16 B per lane per instruction, coalesced); nothing is consumed here
-// FULL: the tile lies entirely inside the batch -- every lane loads unconditionally, so the loads are
-// plain straight-line code and the compiler can count them (s_waitcnt vmcnt(N)) when an older tile
-// is consumed while these are in flight.  !FULL: the batch's last, partial tile, lane-guarded.
-template <bool FULL, int BLOCK, int SS1, int SS2, bool DUAL, int UNITS>
-__device__ __forceinline__ void load_tile(Tile<SS1, SS2, DUAL, UNITS>& T, const DemuxParams& p, int64_t base,
-                                          uint32_t tid) {
-    const int64_t n = p.n;
-#pragma unroll
-    for (int u = 0; u < UNITS; ++u) {
-        const int64_t p0 = base + ((int64_t)u * BLOCK + tid) * 2;  // first pair of the unit
-        if (FULL || p0 + 1 < n) {
-#pragma unroll
-            for (int j = 0; j < SS1 / 8; ++j) T.s1[u][j] = ld16s(p.seq[0] + p0 * SS1 + 16 * j);
-            T.q1[u] = ld16s(p.qual[0] + p0 * 8);
-            if (DUAL) {
-#pragma unroll
-                for (int j = 0; j < SS2 / 8; ++j) T.s2[u][j] = ld16s(p.seq[1] + p0 * SS2 + 16 * j);
-                T.q2[u] = ld16s(p.qual[1] + p0 * 8);
-            }
-        } else if (p0 < n) {  // last, odd pair of the batch: never read past row n-1
-#pragma unroll
-            for (int j = 0; j < SS1 / 8; ++j) T.s1[u][j] = U128{0, 0};
-            T.s1[u][0].lo = ld8(p.seq[0] + p0 * SS1);
-            if (SS1 == 16) T.s1[u][0].hi = ld8(p.seq[0] + p0 * SS1 + 8);
-            T.q1[u] = U128{ld8(p.qual[0] + p0 * 8), 0};
-            if (DUAL) {
-#pragma unroll
-                for (int j = 0; j < SS2 / 8; ++j) T.s2[u][j] = U128{0, 0};
-                T.s2[u][0].lo = ld8(p.seq[1] + p0 * SS2);
-                if (SS2 == 16) T.s2[u][0].hi = ld8(p.seq[1] + p0 * SS2 + 8);
-                T.q2[u] = U128{ld8(p.qual[1] + p0 * 8), 0};
-            }
-        }
-    }
-}
+// ---- RowsX: even strides <= 16, NL1/NL2 = 16-byte loads per lane for the seq rows of read 1 / 2 -----
+template <int BLOCK_, int NL1, int NL2, bool DUAL, int UNITS>
+struct RowsX {
+    static constexpr int BLOCK = BLOCK_;
+    static constexpr bool PREFETCH = QD_FAST_PREFETCH != 0 && (NL1 + (DUAL ? NL2 : 0)) <= 2;
+    static constexpr bool GUARD_LAST = true;  // a 16-byte load of the batch's last rows could pass the array end
+    struct Tile {
+        u64 s1[UNITS][2 * NL1], q1[UNITS][2], s2[UNITS][2 * NL2], q2[UNITS][2];
+    };
 
-// TAG only makes the copies of this code distinct (an assembler comment), so that the compiler does
-// not fold the copy that runs with younger loads in flight into the copy that runs without: a folded
-// copy has to assume the younger loads are missing and waits for everything.
-template <bool FULL, int TAG, int BLOCK, int SS1, int SS2, bool DUAL, int UNITS>
-__device__ __forceinline__ uint32_t compute_tile(const Tile<SS1, SS2, DUAL, UNITS>& T, const DemuxParams& p,
-                                                 const LdsTable& t, int64_t base, uint32_t tid) {
-    asm volatile("; demux tile copy %0" ::"i"(TAG));
-    const int64_t n = p.n;
-    uint32_t undet = 0;
+    template <bool FULL, int NL>
+    static __device__ __forceinline__ void load_block(u64 (&w)[2 * NL], const uint8_t* rows, int64_t p0, int stride,
+                                                      int64_t n) {
+        const uint8_t* src = rows + p0 * stride;  // p0 even, stride even: 4-byte aligned
+        if (FULL) {
 #pragma unroll
-    for (int u = 0; u < UNITS; ++u) {
-        const int64_t p0 = base + ((int64_t)u * BLOCK + tid) * 2;
-        if (!FULL && p0 >= n) continue;
-        const bool two = FULL || (p0 + 1 < n);
-        u64 a_lo, a_hi, b_lo, b_hi;                   // rows of pair p0 (a) and p0+1 (b), stream 1
-        u64 c_lo = 0, c_hi = 0, d_lo = 0, d_hi = 0;  // stream 2
-        if (SS1 == 8) {
-            a_lo = T.s1[u][0].lo; a_hi = 0; b_lo = T.s1[u][0].hi; b_hi = 0;
+            for (int j = 0; j < NL; ++j) {
+                const U128 v = ld16u(src + 16 * j);
+                w[2 * j] = v.lo;
+                w[2 * j + 1] = v.hi;
+            }
         } else {
-            a_lo = T.s1[u][0].lo; a_hi = T.s1[u][0].hi; b_lo = T.s1[u][SS1 / 8 - 1].lo; b_hi = T.s1[u][SS1 / 8 - 1].hi;
-        }
-        if (DUAL) {
-            if (SS2 == 8) {
-                c_lo = T.s2[u][0].lo; d_lo = T.s2[u][0].hi;
-            } else {
-                c_lo = T.s2[u][0].lo; c_hi = T.s2[u][0].hi; d_lo = T.s2[u][SS2 / 8 - 1].lo; d_hi = T.s2[u][SS2 / 8 - 1].hi;
-            }
-        }
-        u64 m0lo = 0, m0hi = 0, m1lo = 0, m1hi = 0;
-        const uint32_t c0 = do_pair<SS1, SS2, DUAL>(p, t, a_lo, a_hi, T.q1[u].lo, c_lo, c_hi,
-                                                    DUAL ? T.q2[u].lo : 0, m0lo, m0hi);
-        uint32_t c1 = 0;
-        if (two)
-            c1 = do_pair<SS1, SS2, DUAL>(p, t, b_lo, b_hi, T.q1[u].hi, d_lo, d_hi, DUAL ? T.q2[u].hi : 0, m1lo, m1hi);
-        undet += (c0 == QD_CODE_UNDET) + (two && c1 == QD_CODE_UNDET);
-        // a7: routing codes, 2 x uint16 per lane = one dword store, coalesced
-        if (two)
-            *reinterpret_cast<uint32_t*>(p.codes + p0) = c0 | (c1 << 16);
-        else
-            p.codes[p0] = (uint16_t)c0;
-        if (p.M > 0) {
-            if (two)
-                store_mol2(p.mol + p0 * p.M, m0lo, m0hi, m1lo, m1hi, p.M);
-            else
-                store_mol(p.mol + p0 * p.M, m0lo, m0hi, p.M);
+            ld_exact(w, src, (p0 + 1 < n ? 2 : 1) * stride);
         }
     }
-    return undet;
-}
 
-template <int BLOCK, int SS1, int SS2, bool DUAL, int UNITS>
-__global__ __launch_bounds__(BLOCK) void demux_fast(const DemuxParams p) {
+    template <bool FULL>
+    static __device__ __forceinline__ void load(Tile& T, const DemuxParams& p, int64_t base, uint32_t tid) {
+        const int64_t n = p.n;
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int64_t p0 = base + ((int64_t)u * BLOCK + tid) * 2;
+            if (FULL || p0 < n) {
+                load_block<FULL, NL1>(T.s1[u], p.seq[0], p0, p.seq_stride[0], n);
+                load_block<FULL, 1>(T.q1[u], p.qual[0], p0, p.qual_stride[0], n);
+                if (DUAL) {
+                    load_block<FULL, NL2>(T.s2[u], p.seq[1], p0, p.seq_stride[1], n);
+                    load_block<FULL, 1>(T.q2[u], p.qual[1], p0, p.qual_stride[1], n);
+                }
+            }
+        }
+    }
+
+    template <bool FULL, int TAG>
+    static __device__ __forceinline__ uint32_t compute(const Tile& T, const DemuxParams& p, const LdsTable& t,
+                                                       int64_t base, uint32_t tid) {
+        asm volatile("; demux tile copy %0" ::"i"(TAG));
+        const int64_t n = p.n;
+        uint32_t undet = 0;
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int64_t p0 = base + ((int64_t)u * BLOCK + tid) * 2;
+            if (!FULL && p0 >= n) continue;
+            const bool two = FULL || (p0 + 1 < n);
+            u64 m0lo = 0, m0hi = 0, m1lo = 0, m1hi = 0;
+            uint32_t c[2] = {0, 0};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // h = 0: pair p0 (row at byte 0), h = 1: pair p0+1 (row at byte stride)
+                if (h == 1 && !two) break;
+                const int r1 = h * p.seq_stride[0], r2 = h * p.seq_stride[1];
+                const u64 k1 = take8(T.s1[u], r1 + p.idx_off[0]) & p.idx_mask[0];
+                const u64 m1 = take8(T.s1[u], r1 + p.mol_off[0]) & p.mol_mask[0];
+                const u64 q1 = take8(T.q1[u], h * p.qual_stride[0]) | ~p.idx_mask[0];  // beyond the slice: 0xFF
+                u64 k2 = 0, m2 = 0, q2 = 0;
+                if (DUAL) {
+                    k2 = take8(T.s2[u], r2 + p.idx_off[1]) & p.idx_mask[1];
+                    m2 = take8(T.s2[u], r2 + p.mol_off[1]) & p.mol_mask[1];
+                    q2 = take8(T.q2[u], h * p.qual_stride[1]) | ~p.idx_mask[1];
+                }
+                c[h] = match_pair<DUAL>(p, t, k1, k2, m1, m2, q1, q2, h ? m1lo : m0lo, h ? m1hi : m0hi);
+            }
+            undet += (c[0] == QD_CODE_UNDET) + (two && c[1] == QD_CODE_UNDET);
+            store_unit(p, p0, two, c[0], c[1], m0lo, m0hi, m1lo, m1hi);
+        }
+        return undet;
+    }
+};
+
+template <class OPS>
+__global__ __launch_bounds__(OPS::BLOCK) void demux_fast(const DemuxParams p) {
+    constexpr int BLOCK = OPS::BLOCK;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint32_t* slots = reinterpret_cast<uint32_t*>(lds_raw);
     u64* bk = reinterpret_cast<u64*>(lds_raw + p.lds_bk_off);
     uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw + p.lds_hist_off);
     const uint32_t tid = threadIdx.x;
     const uint32_t S = p.n_samples;
-    constexpr int64_t TILE = (int64_t)BLOCK * 2 * UNITS;  // pairs per workgroup iteration
-    typedef Tile<SS1, SS2, DUAL, UNITS> TileT;
+    constexpr int64_t TILE = (int64_t)BLOCK * 2 * QD_FAST_UNITS;  // pairs per workgroup iteration
+    typedef typename OPS::Tile TileT;
 
-    // Full tiles [0, nfull) are strided over the grid; the partial last tile (if any) is done by one
-    // workgroup after its full tiles.  The first tile's rows are requested before anything else, so
-    // HBM latency overlaps the staging of the table.
-    const int64_t nfull = p.n / TILE;
+    // Tiles [0, nfull) are loaded without lane guards and strided over the grid; the batch's last
+    // tile(s) -- the partial one, and for exact-width rows every tile within 8 pairs (>= 16 bytes) of
+    // the end of the arrays, since an unguarded 16-byte load may reach that far past a lane's rows --
+    // are lane-guarded and done afterwards.  The first tile's rows are requested before anything
+    // else, so HBM latency overlaps the staging of the table.
+    const int64_t ntiles = (p.n + TILE - 1) / TILE;
+    const int64_t nfull = OPS::GUARD_LAST ? (p.n >= 8 ? (p.n - 8) / TILE : 0) : p.n / TILE;
     int64_t tile = blockIdx.x;
     TileT A, B;
-    if (tile < nfull) load_tile<true, BLOCK>(A, p, tile * TILE, tid);
+    if (tile < nfull) OPS::template load<true>(A, p, tile * TILE, tid);
 
     // stage the table: global (L2) -> LDS, once per workgroup
     for (uint32_t i = tid; i <= p.slot_mask; i += BLOCK) slots[i] = p.slots[i];
@@ -319,44 +418,44 @@ __global__ __launch_bounds__(BLOCK) void demux_fast(const DemuxParams p) {
     const LdsTable t{slots, bk, hist};
 
     uint32_t undet = 0;
-    // Register double buffering (tile k+1 in flight while tile k is matched) for the 8-byte-row
-    // instantiations; 16-byte rows already hold 96 B per lane per tile and run single-buffered.
-    // Every "load next, then match current" pair is straight-line code with its own copy of the match
-    // (no control-flow join between issuing the younger loads and consuming the older ones): with a
-    // join the compiler must assume the younger loads may be missing and waits for them too
-    // (s_waitcnt vmcnt(3..0) instead of vmcnt(4+)), which serialises the two tiles.
-    constexpr bool PREFETCH = QD_FAST_PREFETCH && (SS1 + (DUAL ? SS2 : 0) <= QD_FAST_PREFETCH_MAXROW);
+    // Register double buffering (tile k+1 in flight while tile k is matched) when a tile is 64 B per
+    // lane; wider tiles run single-buffered.  Every "load next, then match current" pair is
+    // straight-line code with its own copy of the match (no control-flow join between issuing the
+    // younger loads and consuming the older ones): with a join the compiler must assume the younger
+    // loads may be missing and waits for them too (s_waitcnt vmcnt(3..0) instead of vmcnt(4+)),
+    // which serialises the two tiles.
     const int64_t G = gridDim.x;
     if (tile < nfull) {
-        if (PREFETCH) {
+        if (OPS::PREFETCH) {
             for (;;) {
                 const int64_t next = tile + G;
                 if (next >= nfull) {
-                    undet += compute_tile<true, 0, BLOCK>(A, p, t, tile * TILE, tid);
+                    undet += OPS::template compute<true, 0>(A, p, t, tile * TILE, tid);
                     break;
                 }
-                load_tile<true, BLOCK>(B, p, next * TILE, tid);
-                undet += compute_tile<true, 1, BLOCK>(A, p, t, tile * TILE, tid);
+                OPS::template load<true>(B, p, next * TILE, tid);
+                undet += OPS::template compute<true, 1>(A, p, t, tile * TILE, tid);
                 tile = next + G;
                 if (tile >= nfull) {
-                    undet += compute_tile<true, 2, BLOCK>(B, p, t, next * TILE, tid);
+                    undet += OPS::template compute<true, 2>(B, p, t, next * TILE, tid);
                     break;
                 }
-                load_tile<true, BLOCK>(A, p, tile * TILE, tid);
-                undet += compute_tile<true, 3, BLOCK>(B, p, t, next * TILE, tid);
+                OPS::template load<true>(A, p, tile * TILE, tid);
+                undet += OPS::template compute<true, 3>(B, p, t, next * TILE, tid);
             }
         } else {
             for (;;) {
-                undet += compute_tile<true, 4, BLOCK>(A, p, t, tile * TILE, tid);
+                undet += OPS::template compute<true, 4>(A, p, t, tile * TILE, tid);
                 tile += G;
                 if (tile >= nfull) break;
-                load_tile<true, BLOCK>(A, p, tile * TILE, tid);
+                OPS::template load<true>(A, p, tile * TILE, tid);
             }
         }
     }
-    if (nfull * TILE < p.n && (int64_t)blockIdx.x == nfull % G) {  // the partial tile, lane-guarded
-        load_tile<false, BLOCK>(A, p, nfull * TILE, tid);
-        undet += compute_tile<false, 5, BLOCK>(A, p, t, nfull * TILE, tid);
+    for (int64_t last = nfull; last < ntiles; ++last) {  // at most two lane-guarded tiles
+        if ((int64_t)blockIdx.x != last % G) continue;
+        OPS::template load<false>(A, p, last * TILE, tid);
+        undet += OPS::template compute<false, 5>(A, p, t, last * TILE, tid);
     }
 
     // undetermined count: wavefront shuffle-reduce (64 lanes), then one LDS add per wave
@@ -472,9 +571,10 @@ __global__ void reduce_partials(const u64* partial, uint32_t rows, uint32_t cnt_
     if (s) atomicAdd(reinterpret_cast<unsigned long long*>(&out[i]), (unsigned long long)s);
 }
 
-template <int BLOCK, int SS1, int SS2, bool DUAL>
+template <class OPS>
 hipError_t launch_fast_t(const DemuxParams& p, int cus, int wg_per_cu, size_t lds, hipStream_t st) {
-    auto k = demux_fast<BLOCK, SS1, SS2, DUAL, QD_FAST_UNITS>;
+    constexpr int BLOCK = OPS::BLOCK;
+    auto k = demux_fast<OPS>;
     static bool attr_set = false;  // per instantiation
     static size_t occ_lds = ~(size_t)0;
     static int occ_blocks = 1;
@@ -518,18 +618,29 @@ hipError_t launch_fast_t(const DemuxParams& p, int cus, int wg_per_cu, size_t ld
 
 template <int BLOCK>
 hipError_t launch_fast_b(const DemuxParams& p, int cus, int wg_per_cu, size_t lds_bytes, hipStream_t st) {
-    const int ss1 = p.seq_stride[0], ss2 = p.seq_stride[1];
-#ifdef QD_SWEEP_BUILD  // tuning builds instantiate the dual 8+8 kernel only
-    return launch_fast_t<BLOCK, 8, 8, true>(p, cus, wg_per_cu, lds_bytes, st);
+    constexpr int U = QD_FAST_UNITS;
+    const bool dual = p.n_streams > 1;
+    const bool all8 = p.seq_stride[0] == 8 && p.qual_stride[0] == 8 &&
+                      (!dual || (p.seq_stride[1] == 8 && p.qual_stride[1] == 8));
+    if (all8) {
+        if (dual) return launch_fast_t<Rows8<BLOCK, true, U>>(p, cus, wg_per_cu, lds_bytes, st);
+#ifndef QD_SWEEP_BUILD  // tuning builds instantiate the dual 8+8 kernel only
+        return launch_fast_t<Rows8<BLOCK, false, U>>(p, cus, wg_per_cu, lds_bytes, st);
 #endif
-    if (p.n_streams == 1) {
-        if (ss1 == 8) return launch_fast_t<BLOCK, 8, 8, false>(p, cus, wg_per_cu, lds_bytes, st);
-        return launch_fast_t<BLOCK, 16, 8, false>(p, cus, wg_per_cu, lds_bytes, st);
     }
-    if (ss1 == 8 && ss2 == 8) return launch_fast_t<BLOCK, 8, 8, true>(p, cus, wg_per_cu, lds_bytes, st);
-    if (ss1 == 8 && ss2 == 16) return launch_fast_t<BLOCK, 8, 16, true>(p, cus, wg_per_cu, lds_bytes, st);
-    if (ss1 == 16 && ss2 == 8) return launch_fast_t<BLOCK, 16, 8, true>(p, cus, wg_per_cu, lds_bytes, st);
-    return launch_fast_t<BLOCK, 16, 16, true>(p, cus, wg_per_cu, lds_bytes, st);
+#ifndef QD_SWEEP_BUILD
+    const int nl1 = p.seq_stride[0] > 8 ? 2 : 1, nl2 = p.seq_stride[1] > 8 ? 2 : 1;
+    if (!dual) {
+        if (nl1 == 1) return launch_fast_t<RowsX<BLOCK, 1, 1, false, U>>(p, cus, wg_per_cu, lds_bytes, st);
+        return launch_fast_t<RowsX<BLOCK, 2, 1, false, U>>(p, cus, wg_per_cu, lds_bytes, st);
+    }
+    if (nl1 == 1 && nl2 == 1) return launch_fast_t<RowsX<BLOCK, 1, 1, true, U>>(p, cus, wg_per_cu, lds_bytes, st);
+    if (nl1 == 1 && nl2 == 2) return launch_fast_t<RowsX<BLOCK, 1, 2, true, U>>(p, cus, wg_per_cu, lds_bytes, st);
+    if (nl1 == 2 && nl2 == 1) return launch_fast_t<RowsX<BLOCK, 2, 1, true, U>>(p, cus, wg_per_cu, lds_bytes, st);
+    return launch_fast_t<RowsX<BLOCK, 2, 2, true, U>>(p, cus, wg_per_cu, lds_bytes, st);
+#else
+    return hipErrorInvalidValue;
+#endif
 }
 
 }  // namespace

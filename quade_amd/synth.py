@@ -88,8 +88,9 @@ class Workload(object):
         return [bytes(r.tolist()).decode() for r in self.barcodes.cpu()]
 
 
-def generate(name, n, seed=None, device="cpu", chunk=8_000_000):
-    """Builds `n` pairs of config `name`.  Deterministic for a given (name, n, seed, device type)."""
+def generate(name, n, seed=None, device="cpu", chunk=8_000_000, layout=None):
+    """Builds `n` pairs of config `name`.  Deterministic for a given (name, n, seed, device type).
+    layout: row layout to build for (default: the library's qd_plan_layout of the config's plan)."""
     c = CONFIGS[name]
     cfg_no = int(name[3:])
     seed = 20260000 + cfg_no if seed is None else seed
@@ -101,7 +102,7 @@ def generate(name, n, seed=None, device="cpu", chunk=8_000_000):
     S = c["S"]
     L = c["read_len"]
     plan = config_plan(name)
-    lay = plan_layout(plan)
+    lay = layout if layout is not None else plan_layout(plan)
     bcs_cpu = make_barcodes(S, K, gcpu)
     bcs = bcs_cpu.to(dev)
     table_h = _mix(_key64(bcs))

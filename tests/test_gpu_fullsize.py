@@ -46,7 +46,7 @@ def test_full_size_properties(name):
             assert torch.equal(mol, exp)
             del exp
         # 3. linearity: counts(A ++ B) = counts(A) + counts(B) at an odd, unaligned split
-        cut = (n // 3) * 2  # even -> 16-byte aligned row offsets for 8-byte rows
+        cut = (n // 3) // 8 * 8  # multiple of 8 pairs -> 16-byte aligned row offsets for every even stride
         a = _run(eng, torch, [t[:cut] for t in w.seq], [t[:cut] for t in w.qual], cut, M)[2]
         b = _run(eng, torch, [t[cut:] for t in w.seq], [t[cut:] for t in w.qual], n - cut, M)[2]
         assert (a + b == counts).all()

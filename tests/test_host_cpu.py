@@ -47,10 +47,13 @@ def test_missing_library_fails_loudly(tmp_path):
 
 def test_plan_layout_envelope():
     lay = hb.plan_layout(hb.make_plan(True, 25, (0, 4), (0, 4), (3, 6), (3, 6)))
-    assert (lay.n_streams, list(lay.seq_off), list(lay.seq_width), list(lay.seq_stride)) == (2, [0, 0], [6, 6], [8, 8])
-    assert (list(lay.qual_off), list(lay.qual_width), lay.key_width, lay.mol_width) == ([0, 0], [4, 4], 8, 6)
+    assert (lay.n_streams, list(lay.seq_off), list(lay.seq_width), list(lay.seq_stride)) == (2, [0, 0], [6, 6], [6, 6])
+    assert (list(lay.qual_off), list(lay.qual_width), list(lay.qual_stride), lay.key_width, lay.mol_width) == \
+        ([0, 0], [4, 4], [4, 4], 8, 6)
     lay = hb.plan_layout(hb.make_plan(False, 0, (2, 10), (0, 0), (12, 20)))
-    assert (lay.n_streams, lay.seq_off[0], lay.seq_width[0], lay.seq_stride[0], lay.qual_off[0]) == (1, 2, 18, 32, 2)
+    assert (lay.n_streams, lay.seq_off[0], lay.seq_width[0], lay.seq_stride[0], lay.qual_off[0]) == (1, 2, 18, 18, 2)
+    lay = hb.plan_layout(hb.make_plan(True, 0, (0, 7), (0, 0), (0, 0), (3, 4)))  # odd widths round up to even
+    assert (list(lay.seq_stride), list(lay.qual_stride)) == ([8, 2], [8, 2])
     for bad in [hb.make_plan(False, 41, (0, 8)), hb.make_plan(False, 0, (5, 4)), hb.make_plan(False, 0, (-1, 4))]:
         with pytest.raises(hb.QuadeHipError):
             hb.plan_layout(bad)

@@ -21,16 +21,20 @@ wgs = [int(x) for x in os.environ.get("TUNE_WG", "0,4,16,64").split(",")]
 libs = [LIB_PATH] + [p for p in os.environ.get("TUNE_LIBS", "").split(",") if p]
 rounds, reps = 3, 4
 
-w = synth.generate(cfg, n, device="cuda")
+engines, loads = [], {}
+for lp in libs:
+    e = Engine(0, lib_path=lp)
+    lay = e.set_plan(synth.config_plan(cfg))
+    key = (tuple(lay.seq_stride), tuple(lay.qual_stride))
+    if key not in loads:  # each library gets rows in its own layout
+        loads[key] = synth.generate(cfg, n, device="cuda", layout=lay)
+    e.workload = loads[key]
+    e.set_barcodes(e.workload.barcode_strings())
+    engines.append(e)
+w = engines[0].workload
 M = w.layout.mol_width
 codes = torch.empty(n, dtype=torch.int16, device="cuda")
 mol = torch.empty((n, max(M, 1)), dtype=torch.uint8, device="cuda")
-engines = []
-for lp in libs:
-    e = Engine(0, lib_path=lp)
-    e.set_plan(w.plan)
-    e.set_barcodes(w.barcode_strings())
-    engines.append(e)
 st = torch.cuda.Stream()
 res = {}
 with torch.cuda.stream(st):
@@ -43,6 +47,7 @@ with torch.cuda.stream(st):
                     for i in range(reps + 1):
                         a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         a.record(st)
+                        w = e.workload
                         e.demux_device(n, [t.data_ptr() for t in w.seq], [t.data_ptr() for t in w.qual],
                                        codes.data_ptr(), mol.data_ptr() if M else None, stream=st.cuda_stream)
                         z.record(st)
