@@ -18,8 +18,8 @@
 #ifndef QD_FAST_PREFETCH
 #define QD_FAST_PREFETCH 1 /* register double buffering of tiles       */
 #endif
-#ifndef QD_FAST_PREFETCH_MAXROW
-#define QD_FAST_PREFETCH_MAXROW 16 /* double-buffer only when seq row bytes per pair <= this */
+#ifndef QD_FASTX_PREFETCH_MAXNL
+#define QD_FASTX_PREFETCH_MAXNL 2 /* RowsX: double-buffer when the seq rows take <= this many 16-byte loads per lane */
 #endif
 #ifndef QD_FAST_BIG_LDS
 #define QD_FAST_BIG_LDS (32 * 1024) /* LDS image above which 1024-thread workgroups are used */

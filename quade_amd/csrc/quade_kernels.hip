@@ -313,7 +313,7 @@ struct Rows8 {
 template <int BLOCK_, int NL1, int NL2, bool DUAL, int UNITS>
 struct RowsX {
     static constexpr int BLOCK = BLOCK_;
-    static constexpr bool PREFETCH = QD_FAST_PREFETCH != 0 && (NL1 + (DUAL ? NL2 : 0)) <= 2;
+    static constexpr bool PREFETCH = QD_FAST_PREFETCH != 0 && (NL1 + (DUAL ? NL2 : 0)) <= QD_FASTX_PREFETCH_MAXNL;
     static constexpr bool GUARD_LAST = true;  // a 16-byte load of the batch's last rows could pass the array end
     struct Tile {
         u64 s1[UNITS][2 * NL1], q1[UNITS][2], s2[UNITS][2 * NL2], q2[UNITS][2];
