@@ -1,0 +1,53 @@
+"""bench.py's one-line JSON contract, on the GPU box (small sizes)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None, launcher=None):
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    if launcher is None:
+        assert len(lines) == 1, "bench.py must print exactly one line on stdout"
+    # (the gloo backend of the rehearsal prints its own connection banner on stdout)
+    js = [ln for ln in lines if ln.startswith("{")]
+    assert len(js) == 1
+    return json.loads(js[0])
+
+
+def test_single_gpu_line():
+    j = _run(["--steps", "3", "--warmup", "1", "--pairs", "3000000", "--cpu-sample", "20000"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert (j["n_gpus"], j["steps"], j["warmup"], j["higher_is_better"], j["scaling"], j["vs_baseline"]) == \
+        (1, 3, 1, True, "weak", None)
+    assert j["dtype"] == "u8" and j["data"] == "synthetic" and j["unit"] == "read-pairs/s"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    assert j["verified"] is True
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    assert abs(r["achieved"] - 3000000 * 34 / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["matches_gpu_codes"] is True
+    assert abs(j["value"] - 3000000 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
+
+
+def test_two_rank_rehearsal_line():
+    """torch.distributed.run with 2 ranks; both on GPU 0 and gloo for the count reduce (this box has
+    one GPU) -- the driver's multi-GPU runs use one GPU per rank and the nccl (RCCL) backend."""
+    env = dict(os.environ, QUADE_BENCH_DEVICE="0", QUADE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", "29577"]
+    j = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "2000000"], env=env, launcher=launcher)
+    assert j["n_gpus"] == 2 and j["verified"] is True and "cpu_baseline" not in j
+    assert abs(j["value"] - 2 * 2000000 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
