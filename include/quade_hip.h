@@ -143,6 +143,7 @@ int qd_kernel_kind(const qd_ctx* ctx, int has_len);
 /* Tuning / test knobs (no reference counterpart).  Names:
  *   "fast_workgroups_per_cu"  0 = automatic (default), 1..4096 = fixed
  *   "fast_block"              0 = automatic (default), 256 / 512 / 1024 threads per workgroup
+ *   "mol_strips"              1 = stage molecular bytes through LDS for 16-byte stores (default), 0 = off
  *   "force_generic"           1 = always launch the generic kernel */
 int qd_set_option(qd_ctx* ctx, const char* name, int64_t value);
 

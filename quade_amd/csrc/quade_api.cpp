@@ -55,11 +55,13 @@ struct qd_ctx {
     uint8_t* d_blen = nullptr;
     uint32_t mask_fast = 0, mask_gen = 0, seed_fast = 0, seed_gen = 0;
     bool fast_ok = false;
-    uint32_t lds_bk_off = 0, lds_hist_off = 0;
-    size_t lds_bytes = 0;
+    uint32_t lds_bk_off = 0, lds_hist_off = 0, lds_strip_off = 0;
+    size_t lds_bytes = 0;       // table image + histogram
+    size_t lds_strip_bytes = 0; // per wave: 128*M bytes of molecular staging (M % 4 == 0), else 0
     int opt_wg_per_cu = 0;    // 0 = occupancy query
     int opt_force_generic = 0;
     int opt_block = 0;        // 0 = automatic
+    int opt_mol_strips = 1;   // LDS-staged molecular stores in the fast kernel
 
     // counters
     u64* d_partial = nullptr;
@@ -188,6 +190,9 @@ int rebuild(qd_ctx* c) {
     c->lds_bk_off = (uint32_t)(((size_t)(c->mask_fast + 1) * 4 + 15) & ~(size_t)15);
     c->lds_hist_off = c->lds_bk_off + (uint32_t)S * 16;
     c->lds_bytes = ((size_t)c->lds_hist_off + (size_t)(2 * S + 1) * 4 + 15) & ~(size_t)15;
+    c->lds_strip_off = (uint32_t)c->lds_bytes;
+    c->lds_strip_bytes = (c->lay.mol_width > 0 && c->lay.mol_width % 4 == 0 && c->opt_mol_strips) ? (size_t)128 * c->lay.mol_width : 0;
+    if (c->lds_bytes + 16 * c->lds_strip_bytes > 150 * 1024) c->lds_strip_bytes = 0;  // 16 waves per workgroup at most
 
     const qd_layout& L = c->lay;
     bool ok = (K >= 1 && K <= 16 && L.mol_width <= 16 && c->lds_bytes <= 150 * 1024);
@@ -226,6 +231,7 @@ void fill_params(const qd_ctx* c, DemuxParams& p, bool fast) {
     p.partial_rows = c->partial_rows;
     p.lds_bk_off = c->lds_bk_off;
     p.lds_hist_off = c->lds_hist_off;
+    p.mol_strip_off = (fast && c->lds_strip_bytes) ? c->lds_strip_off : 0;
     p.thr = (uint32_t)(P.min_qual + 33);
     p.n_streams = L.n_streams;
     p.K = L.key_width;
@@ -274,7 +280,7 @@ int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* 
     p.n = n;
     hipError_t e;
     if (fast) {
-        e = qd_launch_fast(p, c->cu, c->opt_wg_per_cu, c->opt_block, c->lds_bytes, st);
+        e = qd_launch_fast(p, c->cu, c->opt_wg_per_cu, c->opt_block, c->lds_bytes, c->lds_strip_bytes, st);
     } else {
         const int64_t nb = (n + QD_GEN_BLOCK - 1) / QD_GEN_BLOCK;
         const int grid = (int)std::min<int64_t>(nb, (int64_t)c->cu * 8);
@@ -406,6 +412,10 @@ int qd_set_option(qd_ctx* c, const char* name, int64_t value) {
             return fail(c, QD_ERR_INVALID, "fast_block must be 0, 256, 512 or 1024");
         c->opt_block = (int)value;
         return QD_OK;
+    }
+    if (!strcmp(name, "mol_strips")) {
+        c->opt_mol_strips = value != 0;
+        return c->have_table ? rebuild(c) : QD_OK;
     }
     if (!strcmp(name, "force_generic")) {
         c->opt_force_generic = value != 0;

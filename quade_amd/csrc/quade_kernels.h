@@ -18,6 +18,9 @@
 #ifndef QD_FAST_PREFETCH
 #define QD_FAST_PREFETCH 1 /* register double buffering of tiles       */
 #endif
+#ifndef QD_FAST_WT_STORES
+#define QD_FAST_WT_STORES 1 /* write-through (sc1) output stores */
+#endif
 #ifndef QD_FASTX_PREFETCH_MAXNL
 #define QD_FASTX_PREFETCH_MAXNL 2 /* RowsX: double-buffer when the seq rows take <= this many 16-byte loads per lane */
 #endif
@@ -43,6 +46,7 @@ struct DemuxParams {
     int64_t n;
     uint32_t slot_mask, seed, n_samples, cnt_stride, partial_rows;
     uint32_t lds_bk_off, lds_hist_off;
+    uint32_t mol_strip_off;  // LDS offset of the per-wave molecular staging strips, 0 = not used
     uint32_t thr;  // minimal_qual + 33, compared with raw quality bytes
     int32_t n_streams, K, M;
     int32_t seq_stride[2], qual_stride[2];
@@ -54,7 +58,7 @@ struct DemuxParams {
 
 // wg_per_cu <= 0: automatic (see launch_fast_t); block_override: 0 = automatic, else 256/512/1024
 hipError_t qd_launch_fast(const DemuxParams& p, int cus, int wg_per_cu, int block_override, size_t lds_bytes,
-                          hipStream_t st);
+                          size_t strip_bytes_per_wave, hipStream_t st);
 hipError_t qd_launch_generic(const DemuxParams& p, int grid, hipStream_t st);
 hipError_t qd_launch_reduce(const uint64_t* partial, uint32_t rows, uint32_t cnt_stride,
                             uint32_t ncnt, uint64_t* out, hipStream_t st);

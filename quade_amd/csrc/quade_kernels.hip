@@ -57,8 +57,9 @@ __device__ __forceinline__ void fuse(u64 a, u64 b, int w1, u64& lo, u64& hi) {
 
 struct LdsTable {
     const uint32_t* slots;
-    const u64* bk;   // [S][2]
-    uint32_t* hist;  // [2S + 1]
+    const u64* bk;    // [S][2]
+    uint32_t* hist;   // [2S + 1]
+    uint8_t* strips;  // per-wave staging strips of the molecular bytes (128*M bytes each), or unused
 };
 
 // exact match of the folded key (lo,hi) of length K against the LDS table: ordinal or 0xFFFF
@@ -84,6 +85,21 @@ __device__ __forceinline__ uint32_t probe_lds(const LdsTable& t, u64 lo, u64 hi,
         s = (s + 1) & mask;
     }
     return found;
+}
+
+// The routing codes are stored write-through (`global_store_dword ... sc1`, the lowering of a relaxed
+// agent-scope atomic store): a wave writes 256 contiguous bytes that this kernel never reads again,
+// and not keeping them in L2 measures 2-5 % faster than plain or nt stores
+// (profiles/r01_hbm_probe_store_policy.txt).  Not for the molecular bytes: their 8-byte pieces are
+// 24 bytes apart across lanes and each write-through piece becomes its own fabric write (measured
+// 1.3x slower on cfg4).
+template <typename T>
+__device__ __forceinline__ void st_wt(T* p, T v) {
+#if QD_FAST_WT_STORES
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *p = v;
+#endif
 }
 
 __device__ __forceinline__ void store_mol(uint8_t* dst, u64 lo, u64 hi, int M) {
@@ -169,7 +185,7 @@ __device__ __forceinline__ void store_unit(const DemuxParams& p, int64_t p0, boo
                                            u64 m0lo, u64 m0hi, u64 m1lo, u64 m1hi) {
     // a7: routing codes, 2 x uint16 per lane = one dword store, coalesced
     if (two)
-        *reinterpret_cast<uint32_t*>(p.codes + p0) = c0 | (c1 << 16);
+        st_wt(reinterpret_cast<uint32_t*>(p.codes + p0), c0 | (c1 << 16));
     else
         p.codes[p0] = (uint16_t)c0;
     if (p.M > 0) {
@@ -178,6 +194,46 @@ __device__ __forceinline__ void store_unit(const DemuxParams& p, int64_t p0, boo
         else
             store_mol(p.mol + p0 * p.M, m0lo, m0hi, p.M);
     }
+}
+
+// Full tiles, M % 4 == 0: the 64 lanes of a wave own 64 x 2M contiguous molecular bytes.  Each lane
+// drops its 2M bytes into the wave's private LDS strip, then the wave writes the strip out as
+// 16-byte pieces, lane i <-> consecutive 16 B: full-line, coalesced, write-through stores instead of
+// 8-byte pieces 2M bytes apart.  No workgroup barrier: a wave's LDS operations execute in order and
+// no other wave touches its strip.
+__device__ __forceinline__ void store_mol_wave(const DemuxParams& p, uint8_t* strip, int64_t p0, u64 m0lo, u64 m0hi,
+                                               u64 m1lo, u64 m1hi) {
+    const int M = p.M;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t* mine = reinterpret_cast<uint32_t*>(strip + lane * 2 * M);
+    const uint32_t w0[4] = {(uint32_t)m0lo, (uint32_t)(m0lo >> 32), (uint32_t)m0hi, (uint32_t)(m0hi >> 32)};
+    const uint32_t w1[4] = {(uint32_t)m1lo, (uint32_t)(m1lo >> 32), (uint32_t)m1hi, (uint32_t)(m1hi >> 32)};
+    const int nd = M >> 2;  // dwords per pair, wave-uniform
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < nd) {
+            mine[j] = w0[j];
+            mine[nd + j] = w1[j];
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // the wave's first pair is p0 - 2*lane; its strip starts 16-byte aligned in `mol`
+    uint8_t* dst = p.mol + (p0 - 2 * (int64_t)lane) * M;
+    const int pieces = 8 * M;  // 64 lanes x 2M bytes / 16
+    typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int piece = r * 64 + (int)lane;
+        if (piece < pieces) {
+            const v4u32 v = *reinterpret_cast<const v4u32*>(strip + 16 * piece);
+#if QD_FAST_WT_STORES
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + 16 * piece), "v"(v) : "memory");
+#else
+            *reinterpret_cast<v4u32*>(dst + 16 * piece) = v;
+#endif
+        }
+    }
+    __builtin_amdgcn_wave_barrier();  // the strip is reused by the wave's next unit
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -303,7 +359,12 @@ struct Rows8 {
                     (T.s1[u].hi >> mh1) & p.mol_mask[0], DUAL ? (T.s2[u].hi >> mh2) & p.mol_mask[1] : 0, T.q1[u].hi,
                     DUAL ? T.q2[u].hi : 0, m1lo, m1hi);
             undet += (c0 == QD_CODE_UNDET) + (two && c1 == QD_CODE_UNDET);
-            store_unit(p, p0, two, c0, c1, m0lo, m0hi, m1lo, m1hi);
+            if (FULL && p.mol_strip_off) {
+                st_wt(reinterpret_cast<uint32_t*>(p.codes + p0), c0 | (c1 << 16));
+                store_mol_wave(p, t.strips + (tid >> 6) * (128 * p.M), p0, m0lo, m0hi, m1lo, m1hi);
+            } else {
+                store_unit(p, p0, two, c0, c1, m0lo, m0hi, m1lo, m1hi);
+            }
         }
         return undet;
     }
@@ -381,7 +442,12 @@ struct RowsX {
                 c[h] = match_pair<DUAL>(p, t, k1, k2, m1, m2, q1, q2, h ? m1lo : m0lo, h ? m1hi : m0hi);
             }
             undet += (c[0] == QD_CODE_UNDET) + (two && c[1] == QD_CODE_UNDET);
-            store_unit(p, p0, two, c[0], c[1], m0lo, m0hi, m1lo, m1hi);
+            if (FULL && p.mol_strip_off) {
+                st_wt(reinterpret_cast<uint32_t*>(p.codes + p0), c[0] | (c[1] << 16));
+                store_mol_wave(p, t.strips + (tid >> 6) * (128 * p.M), p0, m0lo, m0hi, m1lo, m1hi);
+            } else {
+                store_unit(p, p0, two, c[0], c[1], m0lo, m0hi, m1lo, m1hi);
+            }
         }
         return undet;
     }
@@ -415,7 +481,7 @@ __global__ __launch_bounds__(OPS::BLOCK) void demux_fast(const DemuxParams p) {
     for (uint32_t i = tid; i < 2 * S; i += BLOCK) bk[i] = p.bk16[i];
     for (uint32_t i = tid; i < 2 * S + 1; i += BLOCK) hist[i] = 0;
     __syncthreads();
-    const LdsTable t{slots, bk, hist};
+    const LdsTable t{slots, bk, hist, lds_raw + p.mol_strip_off};
 
     uint32_t undet = 0;
     // Register double buffering (tile k+1 in flight while tile k is matched) when a tile is 64 B per
@@ -571,8 +637,10 @@ __global__ void reduce_partials(const u64* partial, uint32_t rows, uint32_t cnt_
     if (s) atomicAdd(reinterpret_cast<unsigned long long*>(&out[i]), (unsigned long long)s);
 }
 
+// lds = dynamic LDS of the launch (table image + histogram + molecular strips); table_lds = the part
+// every workgroup has to stage and flush (decides the grid form)
 template <class OPS>
-hipError_t launch_fast_t(const DemuxParams& p, int cus, int wg_per_cu, size_t lds, hipStream_t st) {
+hipError_t launch_fast_t(const DemuxParams& p, int cus, int wg_per_cu, size_t lds, size_t table_lds, hipStream_t st) {
     constexpr int BLOCK = OPS::BLOCK;
     auto k = demux_fast<OPS>;
     static bool attr_set = false;  // per instantiation
@@ -595,17 +663,17 @@ hipError_t launch_fast_t(const DemuxParams& p, int cus, int wg_per_cu, size_t ld
     const int64_t ntiles = (p.n + tile - 1) / tile;
     // Grid (automatic), from the measurements in profiles/r01_tune*_*.txt:
     //  * small table image (<= 24 KB of LDS): oversubscribe -- up to 64 workgroups per CU, at least 8
-    //    tiles each; surplus workgroups start as earlier ones retire, which keeps the streams'
+    //    tiles each (16 with molecular output); surplus workgroups start as earlier ones retire, which keeps the streams'
     //    active window compact and evens out the tail; re-staging a few KB per workgroup is free;
     //  * large table image: a persistent grid of at most 2 co-resident workgroups per CU (staging
     //    tens of KB and flushing thousands of counters per workgroup is not free).
     int64_t grid;
     if (wg_per_cu > 0) {
         grid = (int64_t)cus * wg_per_cu;
-    } else if (lds > 24 * 1024) {
+    } else if (table_lds > 24 * 1024) {
         grid = (int64_t)cus * (occ_blocks < 2 ? occ_blocks : 2);
     } else {
-        grid = ntiles / 8;
+        grid = ntiles / (p.M > 0 ? 16 : 8);  // molecular output: fewer, longer-lived workgroups measured better
         const int64_t lo = (int64_t)cus * (occ_blocks < 2 ? occ_blocks : 2), hi = (int64_t)cus * 64;
         if (grid < lo) grid = lo;
         if (grid > hi) grid = hi;
@@ -617,27 +685,28 @@ hipError_t launch_fast_t(const DemuxParams& p, int cus, int wg_per_cu, size_t ld
 }
 
 template <int BLOCK>
-hipError_t launch_fast_b(const DemuxParams& p, int cus, int wg_per_cu, size_t lds_bytes, hipStream_t st) {
+hipError_t launch_fast_b(const DemuxParams& p, int cus, int wg_per_cu, size_t lds_bytes, size_t table_lds,
+                         hipStream_t st) {
     constexpr int U = QD_FAST_UNITS;
     const bool dual = p.n_streams > 1;
     const bool all8 = p.seq_stride[0] == 8 && p.qual_stride[0] == 8 &&
                       (!dual || (p.seq_stride[1] == 8 && p.qual_stride[1] == 8));
     if (all8) {
-        if (dual) return launch_fast_t<Rows8<BLOCK, true, U>>(p, cus, wg_per_cu, lds_bytes, st);
+        if (dual) return launch_fast_t<Rows8<BLOCK, true, U>>(p, cus, wg_per_cu, lds_bytes, table_lds, st);
 #ifndef QD_SWEEP_BUILD  // tuning builds instantiate the dual 8+8 kernel only
-        return launch_fast_t<Rows8<BLOCK, false, U>>(p, cus, wg_per_cu, lds_bytes, st);
+        return launch_fast_t<Rows8<BLOCK, false, U>>(p, cus, wg_per_cu, lds_bytes, table_lds, st);
 #endif
     }
 #ifndef QD_SWEEP_BUILD
     const int nl1 = p.seq_stride[0] > 8 ? 2 : 1, nl2 = p.seq_stride[1] > 8 ? 2 : 1;
     if (!dual) {
-        if (nl1 == 1) return launch_fast_t<RowsX<BLOCK, 1, 1, false, U>>(p, cus, wg_per_cu, lds_bytes, st);
-        return launch_fast_t<RowsX<BLOCK, 2, 1, false, U>>(p, cus, wg_per_cu, lds_bytes, st);
+        if (nl1 == 1) return launch_fast_t<RowsX<BLOCK, 1, 1, false, U>>(p, cus, wg_per_cu, lds_bytes, table_lds, st);
+        return launch_fast_t<RowsX<BLOCK, 2, 1, false, U>>(p, cus, wg_per_cu, lds_bytes, table_lds, st);
     }
-    if (nl1 == 1 && nl2 == 1) return launch_fast_t<RowsX<BLOCK, 1, 1, true, U>>(p, cus, wg_per_cu, lds_bytes, st);
-    if (nl1 == 1 && nl2 == 2) return launch_fast_t<RowsX<BLOCK, 1, 2, true, U>>(p, cus, wg_per_cu, lds_bytes, st);
-    if (nl1 == 2 && nl2 == 1) return launch_fast_t<RowsX<BLOCK, 2, 1, true, U>>(p, cus, wg_per_cu, lds_bytes, st);
-    return launch_fast_t<RowsX<BLOCK, 2, 2, true, U>>(p, cus, wg_per_cu, lds_bytes, st);
+    if (nl1 == 1 && nl2 == 1) return launch_fast_t<RowsX<BLOCK, 1, 1, true, U>>(p, cus, wg_per_cu, lds_bytes, table_lds, st);
+    if (nl1 == 1 && nl2 == 2) return launch_fast_t<RowsX<BLOCK, 1, 2, true, U>>(p, cus, wg_per_cu, lds_bytes, table_lds, st);
+    if (nl1 == 2 && nl2 == 1) return launch_fast_t<RowsX<BLOCK, 2, 1, true, U>>(p, cus, wg_per_cu, lds_bytes, table_lds, st);
+    return launch_fast_t<RowsX<BLOCK, 2, 2, true, U>>(p, cus, wg_per_cu, lds_bytes, table_lds, st);
 #else
     return hipErrorInvalidValue;
 #endif
@@ -648,11 +717,12 @@ hipError_t launch_fast_b(const DemuxParams& p, int cus, int wg_per_cu, size_t ld
 // Workgroup size: 512 threads; 1024 when the LDS image of the table is large (few workgroups fit a
 // CU then, and bigger ones keep the wave count up).  block_override: 0 = this rule.
 hipError_t qd_launch_fast(const DemuxParams& p, int cus, int wg_per_cu, int block_override, size_t lds_bytes,
-                          hipStream_t st) {
+                          size_t strip_bytes_per_wave, hipStream_t st) {
     int block = block_override ? block_override : (lds_bytes > QD_FAST_BIG_LDS ? 1024 : QD_FAST_BLOCK);
-    if (block == 1024) return launch_fast_b<1024>(p, cus, wg_per_cu, lds_bytes, st);
-    if (block == 256) return launch_fast_b<256>(p, cus, wg_per_cu, lds_bytes, st);
-    return launch_fast_b<512>(p, cus, wg_per_cu, lds_bytes, st);
+    const size_t lds = lds_bytes + strip_bytes_per_wave * (size_t)(block / 64);  // table | histogram | strips
+    if (block == 1024) return launch_fast_b<1024>(p, cus, wg_per_cu, lds, lds_bytes, st);
+    if (block == 256) return launch_fast_b<256>(p, cus, wg_per_cu, lds, lds_bytes, st);
+    return launch_fast_b<512>(p, cus, wg_per_cu, lds, lds_bytes, st);
 }
 
 hipError_t qd_launch_generic(const DemuxParams& p, int grid, hipStream_t st) {
