@@ -12,15 +12,17 @@
 //     wave instruction; other even strides <= 16: 4-byte-aligned 16-byte loads over exact-width
 //     rows); all loads of a tile are issued before any is consumed, the next tile is in flight.
 //   * the barcode table (open-addressing slots + 16-byte canonical keys) and the per-sample
-//     histogram live in LDS, staged once per workgroup; workgroups are persistent (grid = a few per
-//     CU) and stride over tiles, so staging is amortised over >= 10^5 pairs.
+//     histogram live in LDS, staged once per workgroup; every workgroup strides over >= 8 tiles
+//     (a few co-resident workgroups per CU for large tables, an oversubscribed grid otherwise).
 //   * case fold and quality gate are SWAR on 64-bit registers (8 bases per operation);
 //     the undetermined count is reduced across the wavefront with DPP/shuffle before one LDS add.
 //   * counters: LDS histogram -> one global atomic per non-zero bin per workgroup into that
 //     workgroup's own row of a partial-count matrix (no cross-workgroup contention);
 //     rows are summed when the host asks for the counts.
-//   * demux_generic: any power-of-two stride, optional per-read lengths (truncated index reads),
-//     barcodes up to 32 bytes, table in global memory (L2 resident).  Correctness path.
+//   * outputs: routing codes as coalesced write-through dword stores; molecular bytes staged per
+//     wave through LDS and written as 16-byte pieces.
+//   * demux_generic: any stride, optional per-read lengths (truncated index reads), barcodes up to
+//     32 bytes, table in global memory (L2 resident).  Correctness path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
