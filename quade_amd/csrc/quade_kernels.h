@@ -18,6 +18,9 @@
 #ifndef QD_FAST_PREFETCH
 #define QD_FAST_PREFETCH 1 /* register double buffering of tiles       */
 #endif
+#ifndef QD_FAST_PROBE2
+#define QD_FAST_PROBE2 1 /* probe the table for a lane's two pairs in lockstep (full tiles) */
+#endif
 #ifndef QD_FAST_WT_STORES
 #define QD_FAST_WT_STORES 1 /* write-through (sc1) output stores */
 #endif

@@ -89,6 +89,53 @@ __device__ __forceinline__ uint32_t probe_lds(const LdsTable& t, u64 lo, u64 hi,
     return found;
 }
 
+// Two independent keys probed in lockstep: both slot reads, then both candidate-key reads, are in
+// flight together (2 dependent LDS round trips per step instead of 3 per key, one key after the
+// other).  The candidate key is read unconditionally (ordinal clamped), compared only if the slot is
+// occupied and its fingerprint matches.
+__device__ __forceinline__ void probe_lds2(const LdsTable& t, u64 lo0, u64 hi0, u64 lo1, u64 hi1, uint32_t K,
+                                           uint32_t seed, uint32_t mask, uint32_t last_id, uint32_t& f0,
+                                           uint32_t& f1) {
+    uint32_t h0 = qd_hash_init(K, seed), h1 = h0;
+    h0 = qd_hash_step(h0, lo0);
+    h1 = qd_hash_step(h1, lo1);
+    if (K > 8) {
+        h0 = qd_hash_step(h0, hi0);
+        h1 = qd_hash_step(h1, hi1);
+    }
+    h0 = qd_hash_fini(h0);
+    h1 = qd_hash_fini(h1);
+    const uint32_t fp0 = h0 >> 16, fp1 = h1 >> 16;
+    uint32_t s0 = h0 & mask, s1 = h1 & mask;
+    bool d0 = false, d1 = false;
+    f0 = f1 = QD_CODE_UNDET;
+    while (!(d0 && d1)) {
+        const uint32_t e0 = t.slots[s0], e1 = t.slots[s1];
+        const uint32_t i0 = min(e0 & 0xFFFFu, last_id), i1 = min(e1 & 0xFFFFu, last_id);
+        const u64 a0 = t.bk[2 * i0], b0 = t.bk[2 * i0 + 1], a1 = t.bk[2 * i1], b1 = t.bk[2 * i1 + 1];
+        if (!d0) {
+            if (e0 == QD_EMPTY_SLOT) {
+                d0 = true;
+            } else if ((e0 >> 16) == fp0 && a0 == lo0 && b0 == hi0) {
+                f0 = i0;
+                d0 = true;
+            } else {
+                s0 = (s0 + 1) & mask;
+            }
+        }
+        if (!d1) {
+            if (e1 == QD_EMPTY_SLOT) {
+                d1 = true;
+            } else if ((e1 >> 16) == fp1 && a1 == lo1 && b1 == hi1) {
+                f1 = i1;
+                d1 = true;
+            } else {
+                s1 = (s1 + 1) & mask;
+            }
+        }
+    }
+}
+
 // The routing codes are stored write-through (`global_store_dword ... sc1`, the lowering of a relaxed
 // agent-scope atomic store): a wave writes 256 contiguous bytes that this kernel never reads again,
 // and not keeping them in L2 measures 2-5 % faster than plain or nt stores
@@ -180,6 +227,41 @@ __device__ __forceinline__ uint32_t match_pair(const DemuxParams& p, const LdsTa
     atomicAdd(&t.hist[code], 1u);
 #endif
     return code;
+}
+
+// Both pairs of a lane at once (full tiles): same steps as match_pair, the two table probes interleaved.
+template <bool DUAL>
+__device__ __forceinline__ void match_two(const DemuxParams& p, const LdsTable& t, const u64 (&k1)[2], const u64 (&k2)[2],
+                                          const u64 (&m1)[2], const u64 (&m2)[2], const u64 (&q1)[2], const u64 (&q2)[2],
+                                          uint32_t (&code)[2], u64 (&mlo)[2], u64 (&mhi)[2]) {
+    u64 klo[2], khi[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        klo[h] = k1[h];
+        khi[h] = 0;
+        if (DUAL) fuse(k1[h], k2[h], p.idx_w[0], klo[h], khi[h]);
+        if (p.M > 0) {
+            mlo[h] = m1[h];
+            mhi[h] = 0;
+            if (DUAL) fuse(m1[h], m2[h], p.mol_w[0], mlo[h], mhi[h]);
+        }
+        klo[h] = qd_fold8(klo[h]);
+        khi[h] = qd_fold8(khi[h]);
+    }
+    uint32_t id[2];
+    probe_lds2(t, klo[0], khi[0], klo[1], khi[1], (uint32_t)p.K, p.seed, p.slot_mask,
+               p.n_samples ? p.n_samples - 1 : 0, id[0], id[1]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (id[h] == QD_CODE_UNDET) {
+            code[h] = QD_CODE_UNDET;
+            continue;
+        }
+        uint32_t pass = qd_all_ge8(q1[h], p.thr);
+        if (DUAL) pass &= qd_all_ge8(q2[h], p.thr);
+        code[h] = id[h] * 2u + (pass ^ 1u);
+        atomicAdd(&t.hist[code[h]], 1u);
+    }
 }
 
 // codes and molecular bytes of the lane's two pairs (p0 even): one dword, 64-bit molecular stores
@@ -349,17 +431,37 @@ struct Rows8 {
             const int sh1 = 8 * p.idx_off[0], sh2 = 8 * p.idx_off[1];
             const int mh1 = 8 * p.mol_off[0], mh2 = 8 * p.mol_off[1];
             u64 m0lo = 0, m0hi = 0, m1lo = 0, m1hi = 0;
+            uint32_t c0, c1 = 0;
             // pair p0 = low words, pair p0+1 = high words of the 16-byte loads
-            const uint32_t c0 = match_pair<DUAL>(
-                p, t, (T.s1[u].lo >> sh1) & p.idx_mask[0], DUAL ? (T.s2[u].lo >> sh2) & p.idx_mask[1] : 0,
-                (T.s1[u].lo >> mh1) & p.mol_mask[0], DUAL ? (T.s2[u].lo >> mh2) & p.mol_mask[1] : 0, T.q1[u].lo,
-                DUAL ? T.q2[u].lo : 0, m0lo, m0hi);
-            uint32_t c1 = 0;
-            if (two)
-                c1 = match_pair<DUAL>(
-                    p, t, (T.s1[u].hi >> sh1) & p.idx_mask[0], DUAL ? (T.s2[u].hi >> sh2) & p.idx_mask[1] : 0,
-                    (T.s1[u].hi >> mh1) & p.mol_mask[0], DUAL ? (T.s2[u].hi >> mh2) & p.mol_mask[1] : 0, T.q1[u].hi,
-                    DUAL ? T.q2[u].hi : 0, m1lo, m1hi);
+            if (FULL && QD_FAST_PROBE2) {
+                const u64 k1[2] = {(T.s1[u].lo >> sh1) & p.idx_mask[0], (T.s1[u].hi >> sh1) & p.idx_mask[0]};
+                const u64 m1[2] = {(T.s1[u].lo >> mh1) & p.mol_mask[0], (T.s1[u].hi >> mh1) & p.mol_mask[0]};
+                const u64 q1[2] = {T.q1[u].lo, T.q1[u].hi};
+                u64 k2[2] = {0, 0}, m2[2] = {0, 0}, q2[2] = {0, 0};
+                if (DUAL) {
+                    k2[0] = (T.s2[u].lo >> sh2) & p.idx_mask[1];
+                    k2[1] = (T.s2[u].hi >> sh2) & p.idx_mask[1];
+                    m2[0] = (T.s2[u].lo >> mh2) & p.mol_mask[1];
+                    m2[1] = (T.s2[u].hi >> mh2) & p.mol_mask[1];
+                    q2[0] = T.q2[u].lo;
+                    q2[1] = T.q2[u].hi;
+                }
+                uint32_t cc[2];
+                u64 ml[2] = {0, 0}, mh[2] = {0, 0};
+                match_two<DUAL>(p, t, k1, k2, m1, m2, q1, q2, cc, ml, mh);
+                c0 = cc[0]; c1 = cc[1];
+                m0lo = ml[0]; m0hi = mh[0]; m1lo = ml[1]; m1hi = mh[1];
+            } else {
+                c0 = match_pair<DUAL>(
+                    p, t, (T.s1[u].lo >> sh1) & p.idx_mask[0], DUAL ? (T.s2[u].lo >> sh2) & p.idx_mask[1] : 0,
+                    (T.s1[u].lo >> mh1) & p.mol_mask[0], DUAL ? (T.s2[u].lo >> mh2) & p.mol_mask[1] : 0, T.q1[u].lo,
+                    DUAL ? T.q2[u].lo : 0, m0lo, m0hi);
+                if (two)
+                    c1 = match_pair<DUAL>(
+                        p, t, (T.s1[u].hi >> sh1) & p.idx_mask[0], DUAL ? (T.s2[u].hi >> sh2) & p.idx_mask[1] : 0,
+                        (T.s1[u].hi >> mh1) & p.mol_mask[0], DUAL ? (T.s2[u].hi >> mh2) & p.mol_mask[1] : 0, T.q1[u].hi,
+                        DUAL ? T.q2[u].hi : 0, m1lo, m1hi);
+            }
             undet += (c0 == QD_CODE_UNDET) + (two && c1 == QD_CODE_UNDET);
             if (FULL && p.mol_strip_off) {
                 st_wt(reinterpret_cast<uint32_t*>(p.codes + p0), c0 | (c1 << 16));
