@@ -13,8 +13,8 @@
  *   - a qd_ctx is bound to one HIP device and must be driven by one thread at a time;
  *     different contexts may be driven concurrently from different threads.
  *   - there is NO CPU fallback: qd_create() fails with QD_ERR_NO_DEVICE when no gfx950 device is
- *     usable.  The host-only helpers (qd_plan_layout, qd_pack_*, qd_fastq_*, qd_route_*,
- *     qd_version, qd_strerror) never touch the GPU.
+ *     usable.  The host-only helpers (qd_plan_layout, qd_pack_*, qd_fastq_*, qd_build_tags,
+ *     qd_format_records, qd_version, qd_strerror) never touch the GPU.
  *
  * Routing code (uint16) written per pair -- src/Sample.py:65-91:
  *     0xFFFF            index matches no sample            (Sample.py:86-91, "Undetermined")
