@@ -60,3 +60,28 @@ def test_full_size_properties(name):
         c1 = _run(eng, torch, seq_p, qual_p, m, M)
         assert (c0[2] == c1[2]).all()
         assert torch.equal(c1[0], c0[0][perm])
+
+
+def test_more_than_2_31_pairs_in_one_launch():
+    """Index arithmetic beyond 32 bits: 2^31 + 4099 pairs of the single-index config in one launch
+    (34 GB of rows, 4.3 GB of codes), every code against the construction truth."""
+    import torch
+    from quade_amd import synth
+    from quade_amd.hip_backend import Engine
+    n = (1 << 31) + 4099
+    w = synth.generate("cfg2", n, device="cuda", seed=5)
+    with Engine(0) as eng:
+        eng.set_plan(w.plan)
+        eng.set_barcodes(w.barcode_strings())
+        codes = torch.empty(n, dtype=torch.int16, device="cuda")
+        st = torch.cuda.Stream()
+        eng.demux_device(n, [t.data_ptr() for t in w.seq], [t.data_ptr() for t in w.qual], codes.data_ptr(), None,
+                         stream=st.cuda_stream)
+        eng.synchronize()
+        counts = eng.counts().astype(np.int64)
+    step = 1 << 28
+    for a in range(0, n, step):  # compare in slices to bound temporaries
+        got = codes[a:a + step].to(torch.int32) & 0xFFFF
+        assert torch.equal(got, w.expected[a:a + step]), a
+    assert counts[0] == n == counts[1] + counts[2] + counts[3]
+    assert counts[3] == int((w.expected == 0xFFFF).sum())
