@@ -18,6 +18,9 @@
 #ifndef QD_FAST_PREFETCH
 #define QD_FAST_PREFETCH 1 /* register double buffering of tiles       */
 #endif
+#ifndef QD_FAST_MINWAVES
+#define QD_FAST_MINWAVES 0 /* 2nd argument of __launch_bounds__ (waves per SIMD); 0 = unset */
+#endif
 #ifndef QD_FAST_PROBE2
 #define QD_FAST_PROBE2 1 /* probe the table for a lane's two pairs in lockstep (full tiles) */
 #endif

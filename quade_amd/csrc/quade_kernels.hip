@@ -557,8 +557,13 @@ struct RowsX {
     }
 };
 
+#if QD_FAST_MINWAVES
+#define QD_FAST_BOUNDS __launch_bounds__(OPS::BLOCK, QD_FAST_MINWAVES)
+#else
+#define QD_FAST_BOUNDS __launch_bounds__(OPS::BLOCK)
+#endif
 template <class OPS>
-__global__ __launch_bounds__(OPS::BLOCK) void demux_fast(const DemuxParams p) {
+__global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p) {
     constexpr int BLOCK = OPS::BLOCK;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint32_t* slots = reinterpret_cast<uint32_t*>(lds_raw);
