@@ -6,7 +6,6 @@ import json
 import os
 import sys
 
-import numpy as np
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

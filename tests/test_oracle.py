@@ -8,7 +8,6 @@ import gzip
 import os
 import shutil
 
-import pytest
 
 from oracle import quade_oracle as qo
 
