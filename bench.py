@@ -39,6 +39,21 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+class stdout_to_stderr(object):
+    """RCCL prints a version banner on stdout when a communicator is created; stdout of this script
+    carries exactly one JSON line, so file descriptor 1 points at stderr while communicators come up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def cpu_baseline(w_cpu_rows, plan, layout, barcodes, hip_codes, sample_pairs):
     """Times oracle.demux_reads (pure-Python restatement of src/Quade.py:210-221 +
     src/Sample.py:56-91, one thread) on the first `sample_pairs` pairs of the GPU workload and
@@ -102,13 +117,15 @@ def main():
     backend = os.environ.get("QUADE_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("QUADE_BENCH_FORCE_DIST"):  # FORCE_DIST: 1-rank rehearsal of the RCCL calls
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        with stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
+            dist.barrier()
 
     from quade_amd import synth
     from quade_amd.hip_backend import Engine
@@ -146,7 +163,11 @@ def main():
     torch.cuda.synchronize()
     if dist:  # warm the communicator up too: its first collective builds the rings
         red_dev0 = torch.device("cuda", local_rank) if backend == "nccl" else None
-        allreduce_counts(eng.counts(), dist, device=red_dev0)
+        with stdout_to_stderr():
+            allreduce_counts(eng.counts(), dist, device=red_dev0)
+            warm = torch.zeros(1, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(warm, op=dist.ReduceOp.MAX)
+            dist.barrier()
     eng.reset_counts()
 
     # ---- timed region: barrier + sync on both sides, exactly K steps, then the count reduce

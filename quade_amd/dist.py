@@ -23,7 +23,7 @@ def allreduce_counts(counts, dist=None, device=None):
     import torch
     if dist is None:
         import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return np.asarray(counts, dtype=np.uint64).copy()
     t = torch.from_numpy(np.asarray(counts, dtype=np.uint64).astype(np.int64))  # NCCL has no uint64 sum
     if device is not None:

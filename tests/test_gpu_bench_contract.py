@@ -15,12 +15,8 @@ def _run(args, env=None, launcher=None):
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    if launcher is None:
-        assert len(lines) == 1, "bench.py must print exactly one line on stdout"
-    # (the gloo backend of the rehearsal prints its own connection banner on stdout)
-    js = [ln for ln in lines if ln.startswith("{")]
-    assert len(js) == 1
-    return json.loads(js[0])
+    assert len(lines) == 1, "bench.py must print exactly one line on stdout: %r" % lines[:5]
+    return json.loads(lines[0])
 
 
 def test_single_gpu_line():
@@ -51,3 +47,14 @@ def test_two_rank_rehearsal_line():
     j = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "2000000"], env=env, launcher=launcher)
     assert j["n_gpus"] == 2 and j["verified"] is True and "cpu_baseline" not in j
     assert abs(j["value"] - 2 * 2000000 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
+
+
+def test_single_rank_rccl_path():
+    """The calls of the N > 1 path (process group on the nccl = RCCL backend, barrier, int64 SUM and
+    float64 MAX all-reduce) with one rank, and a clean stdout despite RCCL's banner."""
+    env = dict(os.environ, QUADE_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                "--master-addr", "127.0.0.1", "--master-port", "29578"]
+    j = _run(["--gpus", "1", "--steps", "3", "--warmup", "1", "--pairs", "2000000", "--no-cpu-baseline"], env=env,
+             launcher=launcher)
+    assert j["n_gpus"] == 1 and j["verified"] is True
