@@ -79,7 +79,8 @@ __device__ __forceinline__ uint32_t probe_lds(const LdsTable& t, u64 lo, u64 hi,
         if (e == QD_EMPTY_SLOT) break;
         if ((e >> 16) == fp) {
             const uint32_t id = e & 0xFFFFu;
-            if (t.bk[2 * id] == lo && t.bk[2 * id + 1] == hi) {
+            const ulong2 k = reinterpret_cast<const ulong2*>(t.bk)[id];
+            if (k.x == lo && k.y == hi) {
                 found = id;
                 break;
             }
@@ -112,7 +113,9 @@ __device__ __forceinline__ void probe_lds2(const LdsTable& t, u64 lo0, u64 hi0, 
     while (!(d0 && d1)) {
         const uint32_t e0 = t.slots[s0], e1 = t.slots[s1];
         const uint32_t i0 = min(e0 & 0xFFFFu, last_id), i1 = min(e1 & 0xFFFFu, last_id);
-        const u64 a0 = t.bk[2 * i0], b0 = t.bk[2 * i0 + 1], a1 = t.bk[2 * i1], b1 = t.bk[2 * i1 + 1];
+        // one 16-byte LDS read per key (ds_read_b128: 4 LDS cycles; two 8-byte reads take 8)
+        const ulong2 ka = reinterpret_cast<const ulong2*>(t.bk)[i0], kb = reinterpret_cast<const ulong2*>(t.bk)[i1];
+        const u64 a0 = ka.x, b0 = ka.y, a1 = kb.x, b1 = kb.y;
         if (!d0) {
             if (e0 == QD_EMPTY_SLOT) {
                 d0 = true;
