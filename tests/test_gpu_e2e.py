@@ -255,3 +255,51 @@ def test_pinned_slots_streaming_vs_oracle():
         assert (np.concatenate(got_codes) == codes_o).all()
         assert H.mol_rows_to_str(np.concatenate(got_mol)) == mol_o
         assert (eng.counts() == counts_o).all()
+
+
+def test_random_conf_end_to_end_fuzz(tmp_path):
+    """Random configurations (single/dual, slice positions, molecular parts, quality threshold, write
+    flags, batch size, slots, chunk workers, ragged and malformed input): CLI outputs == oracle's."""
+    import os as _os
+    rng = np.random.default_rng(int(_os.environ.get("FUZZ_SEED", "7")))
+    from quade_amd.sample import Sample
+    seen = np.zeros(4, dtype=np.int64)
+    for it in range(int(_os.environ.get("E2E_FUZZ_CASES", "24"))):
+        d = tmp_path / ("case%02d" % it)
+        d.mkdir()
+        dual = bool(rng.integers(0, 2))
+        idx_len = int(rng.integers(6, 15))
+        def span(maxw):
+            s = int(rng.integers(1, idx_len - 2))
+            return (s, min(idx_len, s + int(rng.integers(1, maxw))))
+        i1 = span(8)
+        i2 = span(8) if dual else None
+        m1 = span(6) if rng.integers(0, 2) else None
+        m2 = span(6) if dual and rng.integers(0, 2) else None
+        w1 = i1[1] - i1[0] + 1
+        w2 = (i2[1] - i2[0] + 1) if dual else 0
+        S = int(rng.integers(1, 9))
+        bcs = set()
+        while len(bcs) < S:
+            bcs.add(("".join(rng.choice(list("ACGT"), w1)), "".join(rng.choice(list("ACGT"), w2)) if dual else ""))
+        bcs = sorted(bcs)
+        emb = [("A" * (i1[0] - 1) + b1, ("C" * (i2[0] - 1) + b2) if dual else "") for b1, b2 in bcs]
+        data = d / "data"
+        data.mkdir()
+        files = _make_dataset(str(data), rng, int(rng.integers(1, 5)), int(rng.integers(1, 90)), dual, idx_len, emb,
+                              trunc=bool(rng.integers(0, 3) == 0), malformed=bool(rng.integers(0, 3) == 0),
+                              plain=bool(rng.integers(0, 4) == 0))
+        flags = tuple(bool(rng.integers(0, 4) > 0) for _ in range(3))
+        gpu = "[gpu]\nbatch_pairs : %d\nslots : %d\nchunk_workers : %d\n" % (
+            int(rng.integers(1, 60)), int(rng.integers(1, 4)), int(rng.integers(1, 4)))
+        samples = [("S%d" % i, b1, b2) for i, (b1, b2) in enumerate(bcs)]
+        conf = d / "conf.txt"
+        _conf(str(conf), files, dual, (i1, i2, m1, m2), int(rng.integers(0, 41)), samples, flags, gpu)
+        ref_dir, my_dir = d / "ref", d / "mine"
+        ref_dir.mkdir(); my_dir.mkdir()
+        sset, _ = qo.run_quade(str(conf), outdir=str(ref_dir))
+        _run_cli(str(conf), str(my_dir))
+        assert Sample.COUNTS() == sset.counts(), it
+        _compare_dirs(str(my_dir), str(ref_dir))
+        seen += np.array(sset.counts()[:4])
+    assert seen[1] > 0 and seen[2] > 0 and seen[3] > 0, seen  # passes, fails and undetermined all occurred
