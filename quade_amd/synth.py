@@ -92,7 +92,7 @@ def generate(name, n, seed=None, device="cpu", chunk=8_000_000, layout=None):
     """Builds `n` pairs of config `name`.  Deterministic for a given (name, n, seed, device type).
     layout: row layout to build for (default: the library's qd_plan_layout of the config's plan)."""
     c = CONFIGS[name]
-    cfg_no = int(name[3:])
+    cfg_no = int(name[3:]) if name[3:].isdigit() else 9
     seed = 20260000 + cfg_no if seed is None else seed
     gcpu = torch.Generator(device="cpu").manual_seed(seed)
     dev = torch.device(device)
