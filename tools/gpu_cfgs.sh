@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q > gpurun_out/gputests.txt 2>&1 || { tail -30 gpurun_out/gputests.txt; exit 1; }
 tail -2 gpurun_out/gputests.txt
 for c in cfg2 cfg3 cfg4 cfg5; do
-  python bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+  python bench.py --config $c --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 j = json.loads(sys.stdin.read())
 r = j['roofline']

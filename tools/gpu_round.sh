@@ -5,10 +5,10 @@ mkdir -p gpurun_out/prof
 python -m pytest tests -m gpu -x -q > gpurun_out/gputests.txt 2>&1 || { tail -30 gpurun_out/gputests.txt; exit 1; }
 tail -2 gpurun_out/gputests.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-python bench.py --steps 20 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err || { tail -20 gpurun_out/bench.err; exit 1; }
+python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err || { tail -20 gpurun_out/bench.err; exit 1; }
 cat gpurun_out/bench.json
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 100 --warmup 30 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace -- $BENCH > gpurun_out/prof/trace.log 2>&1 || tail -5 gpurun_out/prof/trace.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/pmc_fetch -- $BENCH > gpurun_out/prof/pmc_fetch.log 2>&1 || tail -5 gpurun_out/prof/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/pmc_write -- $BENCH > gpurun_out/prof/pmc_write.log 2>&1 || tail -5 gpurun_out/prof/pmc_write.log

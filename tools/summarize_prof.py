@@ -26,7 +26,7 @@ with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, cfg)), "w", newline
     w = csv.writer(fh)
     w.writerow(rows[0])
     w.writerows(ours)
-    w.writerow(["# command: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 2 "
+    w.writerow(["# command: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 100 --warmup 30 "
                 "--no-cpu-baseline (config %s, %d pairs); other rows (torch data generation) omitted" % (cfg, pairs)])
 avg_ns = None
 for r in ours:
