@@ -130,6 +130,12 @@ def main():
                 dist.init_process_group(backend)
             dist.barrier()
 
+    if not os.path.exists(os.path.join(ROOT, "quade_amd", "lib", "libquade_hip.so")):
+        if rank == 0:  # fresh checkout: build the HIP library first (stdout stays clean)
+            import subprocess
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "quade_amd", "csrc")], stdout=sys.stderr)
+        if dist:
+            dist.barrier()
     from quade_amd import synth
     from quade_amd.hip_backend import Engine
     from quade_amd.dist import allreduce_counts
