@@ -101,6 +101,7 @@ const char* qd_last_error(const qd_ctx* ctx);
 /* ---- context --------------------------------------------------------------------------------------
  * qd_create replaces the implicit process-global state of src/Sample.py:32-44 (one run per
  * process) with an explicit context bound to HIP device `device_id`. */
+int qd_device_count(int32_t* n_devices); /* gfx950 or not; QD_ERR_NO_DEVICE when the runtime finds none */
 int qd_create(int device_id, qd_ctx** out);
 int qd_destroy(qd_ctx* ctx);
 /* name: >= 64 bytes.  Any output pointer may be NULL. */

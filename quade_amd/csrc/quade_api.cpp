@@ -313,6 +313,18 @@ const char* qd_strerror(int code) {
 
 const char* qd_last_error(const qd_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+int qd_device_count(int32_t* n_devices) {
+    if (!n_devices) return fail(nullptr, QD_ERR_INVALID, "n_devices is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        *n_devices = 0;
+        return fail(nullptr, QD_ERR_NO_DEVICE, std::string("no HIP device visible (") + hipGetErrorString(e) + ")");
+    }
+    *n_devices = n;
+    return QD_OK;
+}
+
 int qd_create(int device_id, qd_ctx** out) {
     if (!out) return fail(nullptr, QD_ERR_INVALID, "out is NULL");
     *out = nullptr;

@@ -58,6 +58,7 @@ SYMBOLS = [
     ("qd_version", C.c_int, []),
     ("qd_strerror", C.c_char_p, [C.c_int]),
     ("qd_last_error", C.c_char_p, [_P]),
+    ("qd_device_count", C.c_int, [C.POINTER(C.c_int32)]),
     ("qd_create", C.c_int, [C.c_int, C.POINTER(_P)]),
     ("qd_destroy", C.c_int, [_P]),
     ("qd_device_info", C.c_int, [_P, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
@@ -236,6 +237,16 @@ def format_records(text, rec_off, sel, tags, tag_len):
     if n < 0:
         raise QuadeHipError(int(n), "qd_format_records failed")
     return out[:n].tobytes()
+
+
+def device_count():
+    """Number of HIP devices the library sees; raises when there is none (no CPU fallback)."""
+    lib = load_library()
+    n = C.c_int32(0)
+    r = lib.qd_device_count(C.byref(n))
+    if r != QD_OK:
+        raise QuadeHipError(r, lib.qd_last_error(None).decode())
+    return n.value
 
 
 # ---- device context -------------------------------------------------------------------------------------

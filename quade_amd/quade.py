@@ -116,8 +116,7 @@ class Quade(object):
         if self.world > 1:
             devices = [os.environ.get("QUADE_DEVICE", os.environ.get("LOCAL_RANK", "0"))]
         elif devices == ["all"]:
-            import torch  # only to count devices; nothing else of torch is used on this path
-            devices = list(range(torch.cuda.device_count()))
+            devices = list(range(hb.device_count()))
         plan = cf.plan()
         # chunk workers (host threads) each drive their own contexts: a context is single-threaded
         n_chunks = len(cf.seq_R1)

@@ -152,6 +152,8 @@ SCENARIOS = {
     # three host threads take chunks from a queue; per-chunk parts merged in chunk order
     "chunk_workers_threads": dict(dual=True, idx_len=14, pos=((1, 8), (1, 8), (9, 14), None), minq=25, malformed=True,
                                   gpu="[gpu]\nchunk_workers : 3\nbatch_pairs : 31\nslots : 2\n"),
+    # "all": every device the library sees (one on this box)
+    "devices_all": dict(dual=False, idx_len=8, pos=((1, 8), None, None, None), minq=20, gpu="[gpu]\ndevices : all\n"),
     "wide_window_generic": dict(dual=False, idx_len=24, pos=((1, 20), None, (21, 24), None), minq=10),
 }
 
