@@ -224,19 +224,20 @@ def build_tags(layout: qd_layout, plan: qd_plan, n, seq_rows, len_rows=None, mol
 
 
 def format_records(text, rec_off, sel, tags, tag_len):
-    """Output text (bytes) of the records `sel` (int64 indices) of `text` with their name tags."""
+    """Output text of the records `sel` (int64 indices) of `text` with their name tags, as a numpy
+    uint8 array (buffer protocol: zlib and file.write take it without another copy)."""
     lib = load_library()
     buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else text
     sel = np.ascontiguousarray(sel, dtype=np.int64)
     if sel.size == 0:
-        return b""
+        return np.empty(0, dtype=np.uint8)
     cap = int((rec_off[sel + 1] - rec_off[sel]).sum() + tag_len[sel].astype(np.int64).sum() + 8 * sel.size)
     out = np.empty(cap, dtype=np.uint8)
     n = lib.qd_format_records(_ptr(buf), _ptr(rec_off), _ptr(sel), sel.size, _ptr(tags), tags.shape[1],
                               _ptr(tag_len), _ptr(out), cap)
     if n < 0:
         raise QuadeHipError(int(n), "qd_format_records failed")
-    return out[:n].tobytes()
+    return out[:n]
 
 
 def device_count():

@@ -257,16 +257,33 @@ class Quade(object):
         B = self.cf.batch_pairs
         L = self.layout
         r1s, r2s, idx = streams[0], streams[1], streams[2:]
-        inflight = deque()
+        # Three stages overlap: this thread scans / packs / submits batch b (and makes every call on
+        # the contexts); the device works on it; a router thread tags, formats and queues for gzip
+        # batch b-1, strictly in batch order.  A slot's pinned buffers are reused only after the
+        # router is done with them.
+        from concurrent.futures import ThreadPoolExecutor
+        router = ThreadPoolExecutor(max_workers=1, thread_name_prefix="quade-route")
+        pending = deque()  # submitted to the device, not yet handed to the router
+        jobs = {}          # (context, slot) -> future of the routing job that reads that slot
+
+        def hand_over(item):
+            eng, slot = item[0], item[1]
+            with _timed("wait device"):
+                eng.wait(slot)
+            jobs[(id(eng), slot)] = router.submit(self._route, item, writers)
+
         b = 0
         last = False
         try:
             while not last:
                 eng = engines[b % len(engines)]
                 slot = (b // len(engines)) % eng.n_slots
-                # the slot may still hold an older batch: consume in order until it is free
-                while any(e is eng and s == slot for e, s, *_ in inflight):
-                    self._finish(inflight.popleft(), writers)
+                while any(it[0] is eng and it[1] == slot for it in pending):  # only with very few slots
+                    hand_over(pending.popleft())
+                job = jobs.pop((id(eng), slot), None)
+                if job is not None:
+                    with _timed("wait router"):
+                        job.result()
                 v = eng.slot(slot)
                 with _timed("scan insert reads"):
                     r1_text, r1_off = r1s.take(B)
@@ -282,18 +299,24 @@ class Quade(object):
                 last = n < B
                 has_len = not full
                 eng.submit(slot, n, has_len)
-                inflight.append((eng, slot, n, has_len, r1_text, r1_off, r2_text, r2_off))
+                pending.append((eng, slot, n, has_len, r1_text, r1_off, r2_text, r2_off))
+                while len(pending) > 1:  # the newest batch stays with the device while we read on
+                    hand_over(pending.popleft())
                 b += 1
-            while inflight:
-                self._finish(inflight.popleft(), writers)
+            while pending:
+                hand_over(pending.popleft())
+            with _timed("wait router"):
+                for job in jobs.values():
+                    job.result()
         finally:
+            router.shutdown(wait=True)
             for st in streams:
                 st.close()
 
-    def _finish(self, item, writers=None):
+    def _route(self, item, writers=None):
+        """Router thread: name tags from the slot's rows and the device's molecular bytes, then
+        Sample.FINDER (format + queue for gzip) -- host memory only, no context calls."""
         eng, slot, n, has_len, r1_text, r1_off, r2_text, r2_off = item
-        with _timed("wait device"):
-            eng.wait(slot)
         v = eng.slot(slot)
         with _timed("build tags"):
             tags, tag_len = hb.build_tags(self.layout, self.plan, n, v["seq"], v["len"] if has_len else None,

@@ -103,7 +103,7 @@ def test_fastq_index_and_pack_match_oracle_reader(tmp_path):
         exp = ":" + idx + (":" + mol if mol else "")
         assert bytes(tags[r, :tl[r]]).decode("latin-1") == exp
     # formatted records = oracle's fastqstr with the tag appended to the name
-    out = hb.format_records(data, off, np.arange(n), tags, tl).decode("latin-1")
+    out = bytes(hb.format_records(data, off, np.arange(n), tags, tl)).decode("latin-1")
     exp = ""
     for r, rec in enumerate(recs):
         rec.name += bytes(tags[r, :tl[r]]).decode("latin-1")

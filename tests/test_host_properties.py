@@ -54,7 +54,7 @@ def test_pack_tags_format_equal_oracle(tmp_path_factory, recs, crlf, final_nl, i
     got, full, _ = hb.pack_index_fastq(lay, 0, buf, sr, qr, lr, n + 1)
     assert got == n
     tags, tl = hb.build_tags(lay, plan, n, [sr], [lr])
-    text = hb.format_records(buf, off, np.arange(n), tags, tl).decode("latin-1")
+    text = bytes(hb.format_records(buf, off, np.arange(n), tags, tl)).decode("latin-1")
     exp = ""
     for r, rec in enumerate(want):
         idx = rec[i0:i0 + iw]
