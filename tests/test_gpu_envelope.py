@@ -203,3 +203,32 @@ def test_random_plans_fuzz(engine):
         if it % 20 == 19:
             print("fuzz: %d plans done" % (it + 1), kinds, flush=True)
     assert kinds["fast"] > 40 and kinds["generic"] > 40
+
+
+def test_arbitrary_bytes_in_reads_and_qualities(engine):
+    """Every byte value except newline may sit in a sequence or quality line: bytes >= 0x80 are never
+    folded and never match, quality bytes >= 0x80 pass the gate, bytes below '!' fail it."""
+    from quade_amd.hip_backend import make_plan
+    rng = np.random.default_rng(99)
+    bcs = ["ACGTACGT", "TTTTNNNN", "GGGGCCCC"]
+    n = 20000
+    allowed = np.array([b for b in range(256) if b != 10], dtype=np.uint8)
+    seq = allowed[rng.integers(0, allowed.size, (n, 8))]
+    qual = allowed[rng.integers(0, allowed.size, (n, 8))]
+    which = rng.integers(0, 3, n)
+    for i in range(0, n, 2):  # half of the reads carry a barcode, some lower-cased, random qualities
+        b = np.frombuffer(bcs[which[i]].encode(), dtype=np.uint8).copy()
+        if i % 6 == 0:
+            b |= 0x20
+        seq[i] = b
+    reads = [([bytes(r) for r in seq], [bytes(r) for r in qual])]
+    for mq in (0, 20, 40):
+        codes, counts = _run_vs_c_oracle(engine, make_plan(False, mq, (0, 8)), bcs, reads)
+        assert counts[1] > 0 and counts[2] > 0 and counts[3] > 0
+    # the Python oracle agrees with the C oracle on this input as well
+    from tests import helpers as H2
+    s = [r.decode("latin-1") for r in reads[0][0][:3000]]
+    q = [r.decode("latin-1") for r in reads[0][1][:3000]]
+    codes_p, _, _, _ = H2.oracle_on_reads(bcs, make_plan(False, 20, (0, 8)), s, q)
+    codes_c, _ = _run_vs_c_oracle(engine, make_plan(False, 20, (0, 8)), bcs, [(reads[0][0][:3000], reads[0][1][:3000])])
+    assert (codes_p == codes_c).all()
