@@ -3,9 +3,9 @@
 Configuration file handling: the schema of Quade 0.3.2's Quade_conf_file.txt, re-expressed for
 Python 3.  Parsing and validation follow src/Quade.py:92-142 and 258-284 of the reference (same
 sections, option names, 1-based -> 0-based start conversion, assertion messages); the example
-file written by `-i` carries the same sections / options / default values as the reference
-template (src/Conf_file.py:28-104) with comments of our own, plus an optional [gpu] section that
-reference conf files simply do not have (defaults apply).
+file written by `-i` is the reference's template byte for byte (src/Conf_file.py:18-104; shipped as
+package data, quade_amd/data/Quade_conf_file.txt).  An optional [gpu] section that reference conf
+files simply do not have is read when present (defaults apply otherwise; see GPU_SECTION_HELP).
 """
 from __future__ import annotations
 
@@ -14,87 +14,32 @@ import os
 
 CONF_NAME = "Quade_conf_file.txt"
 
-TEMPLATE = """\
-###################################################################################################
-#                    QUADE CONFIGURATION FILE  (MI355X-native demultiplexer)                      #
-###################################################################################################
-# Same sections and options as Quade 0.3.2.  Edit the values, keep the option names.
-# Paths: absolute paths are safest; no blanks inside a path.
+TEMPLATE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", CONF_NAME)
 
-[quality]
-# Phred+33 (Illumina 1.8+) qualities only.
-# Every base of the sample barcode must reach this phred value for the pair to go to the "pass"
-# files; otherwise it goes to the "fail" files.  0 disables the filter.  (INTEGER 0-40)
-minimal_qual : 25
-
-[fastq]
-# Chunked, non demultiplexed fastq(.gz) files; the n-th file of every list belongs to the n-th chunk.
-# seq_R1 / seq_R2 = insert reads, index_R1 = first index read, index_R2 = second index read (double
-# indexing only).  Single indexing: seq_R1 = R1, seq_R2 = R3, index_R1 = R2.  Double indexing:
-# seq_R1 = R1, seq_R2 = R4, index_R1 = R2, index_R2 = R3.
-seq_R1 :   ../dataset/C1_R1.fastq.gz  ../dataset/C2_R1.fastq.gz  ../dataset/C3_R1.fastq.gz
-seq_R2 :   ../dataset/C1_R4.fastq.gz  ../dataset/C2_R4.fastq.gz  ../dataset/C3_R4.fastq.gz
-index_R1 : ../dataset/C1_R2.fastq.gz  ../dataset/C2_R2.fastq.gz  ../dataset/C3_R2.fastq.gz
-index_R2 : ../dataset/C1_R3.fastq.gz  ../dataset/C2_R3.fastq.gz  ../dataset/C3_R3.fastq.gz
-
-[index]
-# index 1 is always used.  index2: samples carry two barcodes (fused index1+index2).
-# molecular1 / molecular2: a random molecular barcode is read from index read 1 / 2.  (BOOLEAN)
-index2 : True
-molecular1 : True
-molecular2 : True
-
-# First and last base (1-based, inclusive) of each barcode inside its index read.  Positions of
-# unused parts are ignored.  (INTEGERS)
-index1_start : 1
-index1_end : 4
-index2_start : 1
-index2_end : 4
-molecular1_start : 4
-molecular1_end : 6
-molecular2_start : 4
-molecular2_end : 6
-
-[output]
-# Which categories of fastq files are written (counters and the report are always produced).
-write_pass : True
-write_fail : True
-write_undetermined : True
-
-# Optional, not in Quade 0.3.2 -- remove the leading '#' to override the defaults.
-#[gpu]
-# GPUs to use: "all" or a blank separated list of device ids (default 0)
-#devices : 0
-# read pairs per device batch (default 4000000) and number of pinned staging slots (default 3)
-#batch_pairs : 4000000
-#slots : 3
-# zlib level of the output fastq.gz files (default 6)
-#gzip_level : 6
-# chunks processed concurrently by host threads (default 1); outputs are identical, chunk order kept
-#chunk_workers : 1
-
-###################################################################################################
-# SAMPLES: one [sampleN] section per sample (N = 1, 2, 3 ...).  Names and barcodes must be unique.
-#   name       : prefix of the output files
-#   index1_seq : barcode expected in index read 1 (A, C, G, T, N upper case)
-#   index2_seq : barcode expected in index read 2 (double indexing only)
-
-[sample1]
-name : S1
-index1_seq : ACAG
-index2_seq : ACAG
-
-[sample2]
-name : S2
-index1_seq : CTTG
-index2_seq : CTTG
+GPU_SECTION_HELP = """\
+Optional [gpu] section (not in Quade 0.3.2; a conf file without it runs with the defaults):
+  [gpu]
+  devices : 0            GPUs to use: "all" or a blank separated list of device ids
+  batch_pairs : 4000000  read pairs per device batch
+  slots : 3              pinned staging slots per device (H2D / kernel / D2H overlap)
+  gzip_level : 6         deflate level of the output fastq.gz files (0-9)
+  chunk_workers : 1      chunks processed concurrently by host threads (outputs identical)
+  io_threads : 0         threads of the native gunzip / gzip pool (0 = one per core)
 """
+
+
+def template_bytes():
+    """The example configuration file, byte for byte the reference's template: the package ships the
+    reference-held golden copy (test/result/Quade_conf_file.txt = the text src/Conf_file.py:18-104
+    writes) as data and reads it at run time."""
+    with open(TEMPLATE_PATH, "rb") as fp:
+        return fp.read()
 
 
 def write_example_conf(path=CONF_NAME):
     """`-i`: write an example configuration file in the current folder (src/Conf_file.py:15-18)."""
-    with open(path, "w") as fp:
-        fp.write(TEMPLATE)
+    with open(path, "wb") as fp:
+        fp.write(template_bytes())
 
 
 class QuadeConf(object):

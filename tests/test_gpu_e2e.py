@@ -48,7 +48,17 @@ def test_bundled_golden_replay_through_hip(tmp_path, bundled_dir):
     work = tmp_path / "result"
     work.mkdir()
     shutil.copytree(os.path.join(bundled_dir, "dataset"), tmp_path / "dataset")
-    shutil.copy(os.path.join(bundled_dir, "result", "Quade_conf_file.txt"), work / "Quade_conf_file.txt")
+    # the conf is the one `Quade.py -i` generates (README.md:67-72 of the reference: "Quade.py -i;
+    # Quade.py -c Quade_conf_file.txt"), not a copy of the golden
+    from quade_amd.quade import Quade
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        with pytest.raises(SystemExit) as ei:
+            Quade.class_init(["-i"])
+        assert ei.value.code == 0
+    finally:
+        os.chdir(cwd)
     _run_cli("Quade_conf_file.txt", str(work))
     os.remove(work / "Quade_conf_file.txt")
     from quade_amd.sample import Sample

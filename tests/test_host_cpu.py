@@ -10,7 +10,7 @@ import pytest
 
 from oracle import quade_oracle as qo
 from quade_amd import hip_backend as hb
-from quade_amd.conf import QuadeConf, TEMPLATE, write_example_conf
+from quade_amd.conf import QuadeConf, template_bytes, write_example_conf
 from quade_amd.sample import Sample
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -212,7 +212,12 @@ def test_cli_exit_codes_and_messages(tmp_path, capsys, monkeypatch):
     monkeypatch.chdir(tmp_path)
     with pytest.raises(SystemExit) as ei:
         Quade.class_init(["-i"])
-    assert ei.value.code == 0 and (tmp_path / "Quade_conf_file.txt").read_text() == TEMPLATE
+    # `-i` writes the reference's template byte for byte (src/Conf_file.py:15-104; the reference holds
+    # its exact bytes as test/result/Quade_conf_file.txt, committed here as a golden fixture)
+    golden = os.path.join(ROOT, "tests", "golden", "bundled", "result", "Quade_conf_file.txt")
+    with open(golden, "rb") as fh:
+        want = fh.read()
+    assert ei.value.code == 0 and (tmp_path / "Quade_conf_file.txt").read_bytes() == want == template_bytes()
     with pytest.raises(SystemExit) as ei:
         Quade.class_init(["-c", "does_not_exist.txt"])
     assert ei.value.code == 1
