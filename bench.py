@@ -90,6 +90,34 @@ def cpu_baseline(w_cpu_rows, plan, layout, barcodes, hip_codes, sample_pairs):
             "matches_gpu_codes": ok}
 
 
+def spawn_ranks(n):
+    """python bench.py --gpus N without WORLD_SIZE: one child process per GPU via torch.distributed.run
+    (127.0.0.1 rendezvous on a free port).  stdout of the children is captured so that exactly one
+    JSON line reaches our stdout; their stderr passes through."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", QUADE_BENCH_SPAWNED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    log("bench.py --gpus %d without a launcher: starting %s" % (n, " ".join(cmd[1:9])))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in r.stdout.splitlines():
+        if ln not in lines and ln.strip():
+            log("[child stdout] " + ln)
+    if lines:
+        print(lines[-1], flush=True)
+    elif r.returncode == 0:
+        log("bench.py: the ranks exited 0 without printing the JSON line")
+        return 1
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +130,12 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started without a launcher (python bench.py --gpus N): this process has not touched the GPU
+        # (torch is not even imported yet) and never will -- it starts the N ranks as CHILD processes
+        # under torch.distributed.run, relays rank 0's JSON line and exits with the children's code.
+        sys.exit(spawn_ranks(args.gpus))
+
     import numpy as np
     import torch
 
@@ -109,7 +143,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d; start it as `python bench.py --gpus N` "
+                         "or with --nproc-per-node equal to --gpus" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     # Rehearsal knobs (a 1-GPU box cannot give every rank its own device): QUADE_BENCH_DEVICE pins all
@@ -195,9 +230,11 @@ def main():
         step()
     ev1.record(stream)
     counts = eng.counts()                      # waits for the device, sums the partial rows
+    t_counts = time.perf_counter()
     red_dev = torch.device("cuda", local_rank) if backend == "nccl" else None
     total_counts = allreduce_counts(counts, dist, device=red_dev) if dist else counts
     torch.cuda.synchronize()
+    t_reduced = time.perf_counter()
     if dist:
         dist.barrier()
     t1 = time.perf_counter()
@@ -207,6 +244,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     kern_ms_mean = float(ev0.elapsed_time(ev1)) / args.steps
+    # what ran where: every rank reports its device and its own kernel time (outside the timed region)
+    props = torch.cuda.get_device_properties(local_rank)
+    mine = {"rank": rank, "device": local_rank, "name": props.name,
+            "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
+            "kernel_ms": kern_ms_mean, "elapsed_ms": (t1 - t0) * 1e3, "allreduce_ms": (t_reduced - t_counts) * 1e3}
+    per_rank = [mine]
+    comm_world = 1
+    if dist:
+        comm_world = dist.get_world_size()
+        per_rank = [None] * comm_world
+        dist.all_gather_object(per_rank, mine)
 
     # ---- verification outside the timed region (every pair, by construction; counts identities)
     verified = None
@@ -226,13 +274,17 @@ def main():
 
     algo_bytes = synth.ALGO_BYTES[args.config]
     achieved = n * algo_bytes / (kern_ms_mean * 1e-3) / 1e9
-    traffic = None
+    # HBM bytes per launch from the PMC counters: a separate rocprofv3 --pmc run of this same command
+    # (tools/gpu_prof_cfg.sh), committed under profiles/ -- replayed here, not observed in this run
+    traffic, traffic_source = None, None
     tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
     if os.path.exists(tfile):
         with open(tfile) as fh:
             tj = json.load(fh)
         if tj.get("n_pairs") == n:
             traffic = tj.get("hbm_bytes_per_launch")
+            traffic_source = "profiles/%s (earlier rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \
+                             "replayed, not measured in this run)" % tj.get("source", os.path.basename(tfile))
 
     out = {
         "metric": "read-pairs/sec demultiplexed (2x150 bp, dual 8 bp index)",
@@ -241,6 +293,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "untimed_launches": max(args.warmup, 50),  # W topped up to 50 for the clock ramp (outside the timed region)
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
@@ -257,7 +310,14 @@ def main():
         "verified": verified,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "traffic_source": traffic_source,
                      "kernel_ms": kern_ms_mean, "algorithmic_bytes_per_pair": algo_bytes},
+        "world": comm_world,  # as the communicator reports it (1 = no process group)
+        "count_reduce": {"backend": ("rccl" if backend == "nccl" else backend) if dist else None,
+                         "ms_max_over_ranks": max(r["allreduce_ms"] for r in per_rank) if dist else 0.0},
+        "ranks": per_rank,
+        "launched_by": "self-spawn" if os.environ.get("QUADE_BENCH_SPAWNED") else
+                       ("external launcher" if "WORLD_SIZE" in os.environ else "single process"),
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

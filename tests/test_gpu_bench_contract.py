@@ -26,6 +26,8 @@ def test_single_gpu_line():
         assert k in j, k
     assert (j["n_gpus"], j["steps"], j["warmup"], j["higher_is_better"], j["scaling"], j["vs_baseline"]) == \
         (1, 3, 1, True, "weak", None)
+    assert j["untimed_launches"] == 50 and j["world"] == 1 and j["launched_by"] == "single process"
+    assert len(j["ranks"]) == 1 and j["ranks"][0]["device"] == 0
     assert j["dtype"] == "u8" and j["data"] == "synthetic" and j["unit"] == "read-pairs/s"
     assert "workload" in j["config"] and "model" not in j["config"]
     assert j["verified"] is True
@@ -38,6 +40,20 @@ def test_single_gpu_line():
     assert abs(j["value"] - 3000000 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
 
 
+def test_two_ranks_self_spawned():
+    """`python bench.py --gpus 2` with NO launcher (how the driver may start it): bench.py starts its
+    own two ranks as child processes and relays one line with n_gpus 2.  Both ranks on GPU 0 and gloo
+    for the count reduce here (one GPU on this box; RCCL refuses two ranks on one device)."""
+    env = dict(os.environ, QUADE_BENCH_DEVICE="0", QUADE_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    j = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "2000000"], env=env)
+    assert j["n_gpus"] == 2 and j["world"] == 2 and j["verified"] is True and j["launched_by"] == "self-spawn"
+    assert [r["rank"] for r in j["ranks"]] == [0, 1] and all(r["kernel_ms"] > 0 for r in j["ranks"])
+    assert j["count_reduce"]["backend"] == "gloo" and j["count_reduce"]["ms_max_over_ranks"] > 0
+    assert abs(j["value"] - 2 * 2000000 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
+
+
 def test_two_rank_rehearsal_line():
     """torch.distributed.run with 2 ranks; both on GPU 0 and gloo for the count reduce (this box has
     one GPU) -- the driver's multi-GPU runs use one GPU per rank and the nccl (RCCL) backend."""
@@ -46,6 +62,7 @@ def test_two_rank_rehearsal_line():
                 "--master-addr", "127.0.0.1", "--master-port", "29577"]
     j = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "2000000"], env=env, launcher=launcher)
     assert j["n_gpus"] == 2 and j["verified"] is True and "cpu_baseline" not in j
+    assert j["launched_by"] == "external launcher" and j["world"] == 2
     assert abs(j["value"] - 2 * 2000000 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
 
 
