@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 1
+#define QD_ABI_VERSION 2
 
 #define QD_OK 0
 #define QD_ERR_INVALID (-1)     /* bad argument (NULL pointer, misaligned buffer, size out of range)   */
@@ -127,8 +127,10 @@ int qd_set_barcodes(qd_ctx* ctx, int32_t n_samples, const uint8_t* barcodes, con
  * 246-247) + Sample.FINDER (src/Sample.py:56-91).  All pointers are DEVICE pointers, 16-byte
  * aligned, laid out as qd_layout says.  seq[1]/qual[1]/len[1] are ignored for a single-index plan.
  * codes_dev: n_pairs uint16.  mol_dev: n_pairs*mol_width bytes, may be NULL when mol_width == 0.
- * `stream` is a hipStream_t (NULL = the context's own stream).  Asynchronous: returns after the
- * launch.  Counters accumulate in the context. */
+ * `stream` is a hipStream_t: NULL is HIP's null (default) stream, ordered with the caller's other
+ * default-stream work; QD_STREAM_CONTEXT is the context's own non-blocking stream.  Asynchronous:
+ * returns after the launch.  Counters accumulate in the context. */
+#define QD_STREAM_CONTEXT ((void*)(intptr_t)-1)
 typedef struct qd_rows {
     const uint8_t* seq[2];
     const uint8_t* qual[2];
@@ -137,22 +139,38 @@ typedef struct qd_rows {
 int qd_demux_device(qd_ctx* ctx, int64_t n_pairs, const qd_rows* rows, uint16_t* codes_dev,
                     uint8_t* mol_dev, void* stream);
 
+/* Ragged batch: some reads are shorter than their window (Python slice clamping of a short index
+ * read, src/Quade.py:217-218), and the caller knows which.  rows->len must be given;
+ * short_idx_dev[0..n_short) = the pair indices (device memory, unique, any order) at which ANY stream's
+ * read is shorter than seq_off+seq_width of that stream.  When the plan is eligible for the fast
+ * kernels, the whole batch runs on them and only the listed pairs are redone with the length-aware
+ * byte-granular path (results and counters are those of running every pair that way); otherwise, or
+ * when more than half of the pairs are listed, the generic kernel takes the batch. */
+int qd_demux_device_ragged(qd_ctx* ctx, int64_t n_pairs, const qd_rows* rows, uint16_t* codes_dev, uint8_t* mol_dev,
+                           int64_t n_short, const uint32_t* short_idx_dev, void* stream);
+
 /* Which kernel qd_demux_device would launch for a batch: 1 = fast (LDS table, vector rows),
- * 2 = generic.  Informational (tests, bench). */
+ * 2 = generic, 3 = wave-span (LDS table, aligned span loads, rows redistributed through LDS).
+ * Informational (tests, bench). */
 int qd_kernel_kind(const qd_ctx* ctx, int has_len);
 
 /* Tuning / test knobs (no reference counterpart).  Names:
  *   "fast_workgroups_per_cu"  0 = automatic (default), 1..4096 = fixed
  *   "fast_block"              0 = automatic (default), 256 / 512 / 1024 threads per workgroup
  *   "mol_strips"              1 = stage molecular bytes through LDS for 16-byte stores (default), 0 = off
- *   "force_generic"           1 = always launch the generic kernel */
+ *   "force_generic"           1 = always launch the generic kernel
+ *   "kernel"                  0 = automatic (default), 1 = fast, 2 = generic, 3 = wave-span (when the row
+ *                             shape has an instantiation, else the automatic choice)
+ *   "wave_block"              0 = automatic, 256 / 512 threads per workgroup of the wave-span kernel
+ *   "wave_quads"              0 = automatic, 1..65536 quads (512 pairs) per wave of the wave-span kernel */
 int qd_set_option(qd_ctx* ctx, const char* name, int64_t value);
 
 /* ---- counters: replace the class counters of src/Sample.py:32,144 and feed Sample.REPORT ---------
- * qd_get_counts waits for outstanding work of this context, then writes 2*S+4 values. */
+ * qd_get_counts waits for outstanding work of this context (only), then writes 2*S+4 values. */
 int qd_get_counts(qd_ctx* ctx, uint64_t* out, int32_t n_values);
 int qd_reset_counts(qd_ctx* ctx);
-/* Waits for every outstanding launch / copy of this context's device. */
+/* Waits for every outstanding launch / copy this context issued (on its own stream, its slots'
+ * streams and the caller's streams it was handed) -- not for other contexts' work on the device. */
 int qd_synchronize(qd_ctx* ctx);
 
 /* ---- host-staged streaming: pinned slots, H2D || kernel || D2H -------------------------------------
@@ -167,12 +185,19 @@ typedef struct qd_slot_buffers {
     uint16_t* codes; /* valid after qd_wait */
     uint8_t* mol;    /* valid after qd_wait; NULL when mol_width == 0 */
     int64_t max_pairs;
+    uint32_t* short_idx[2]; /* per stream: indices of the reads shorter than their window (qd_submit_ragged) */
+    int64_t short_cap;      /* entries each short_idx array holds */
 } qd_slot_buffers;
 int qd_slots_create(qd_ctx* ctx, int32_t n_slots, int64_t max_pairs);
 int qd_slots_destroy(qd_ctx* ctx);
 int qd_slot_get(qd_ctx* ctx, int32_t slot, qd_slot_buffers* out);
 /* has_len != 0: the len rows were filled and the generic kernel runs. Non-blocking. */
 int qd_submit(qd_ctx* ctx, int32_t slot, int64_t n_pairs, int32_t has_len);
+/* The len rows were filled and stream k's short reads are listed (ascending) in the slot's
+ * short_idx[k][0..n_short[k]) -- what qd_pack_index_fastq writes.  Indices >= n_pairs are ignored.
+ * Runs like qd_demux_device_ragged; a count above short_cap means "too many to list": the generic
+ * kernel takes the batch.  Non-blocking. */
+int qd_submit_ragged(qd_ctx* ctx, int32_t slot, int64_t n_pairs, const int64_t n_short[2]);
 int qd_wait(qd_ctx* ctx, int32_t slot);
 
 /* ---- host helpers: fastq text -> rows (replace what the path consumed from pyFastq, a9) -----------
@@ -187,11 +212,13 @@ int64_t qd_fastq_index(const uint8_t* text, int64_t text_len, int64_t max_record
 
 /* Packs stream `k` (0/1) of `layout` from fastq text: for kept record r writes seq row r, qual row
  * r and len row r (len_rows may be NULL).  *all_full is set to 0 when any read is shorter than its
- * window (then the caller must pass len rows to the device).  Same skipping rule and return value
- * as qd_fastq_index. */
+ * window (then the caller must pass len rows to the device).  short_idx (may be NULL): the indices
+ * r of those short reads, ascending, at most short_cap of them stored; *n_short = how many there
+ * were (may exceed short_cap).  Same skipping rule and return value as qd_fastq_index. */
 int64_t qd_pack_index_fastq(const qd_layout* layout, int32_t k, const uint8_t* text, int64_t text_len,
                             int64_t max_records, uint8_t* seq_rows, uint8_t* qual_rows,
-                            uint8_t* len_rows, int32_t* all_full, int64_t* consumed);
+                            uint8_t* len_rows, int32_t* all_full, int64_t* consumed,
+                            uint32_t* short_idx, int64_t short_cap, int64_t* n_short);
 
 /* Packs rows from already separated reads (concatenated sequence and quality bytes + offsets):
  * used by tests and by callers that hold records rather than text. */

@@ -116,12 +116,13 @@ int64_t qd_fastq_index(const uint8_t* text, int64_t text_len, int64_t max_record
 
 int64_t qd_pack_index_fastq(const qd_layout* L, int32_t k, const uint8_t* text, int64_t text_len,
                             int64_t max_records, uint8_t* seq_rows, uint8_t* qual_rows, uint8_t* len_rows,
-                            int32_t* all_full, int64_t* consumed) {
+                            int32_t* all_full, int64_t* consumed, uint32_t* short_idx, int64_t short_cap,
+                            int64_t* n_short) {
     if (!L || k < 0 || k >= L->n_streams || !text || text_len < 0 || max_records < 0 || !seq_rows || !qual_rows)
         return QD_ERR_INVALID;
     const int ss = L->seq_stride[k], qs = L->qual_stride[k];
     const int64_t need = (int64_t)L->seq_off[k] + L->seq_width[k];
-    int64_t pos = 0, n = 0;
+    int64_t pos = 0, n = 0, ns = 0;
     int32_t full = 1;
     Rec r;
     while (n < max_records && next_record(text, text_len, pos, r)) {
@@ -129,13 +130,18 @@ int64_t qd_pack_index_fastq(const qd_layout* L, int32_t k, const uint8_t* text, 
         if (len == r.qual_end - r.qual) {
             pack_row(L, k, text + r.seq, text + r.qual, len, seq_rows + n * ss, qual_rows + n * qs);
             if (len_rows) len_rows[n] = (uint8_t)(len > 255 ? 255 : len);
-            if (len < need) full = 0;
+            if (len < need) {
+                full = 0;
+                if (short_idx && ns < short_cap) short_idx[ns] = (uint32_t)n;
+                ++ns;
+            }
             ++n;
         }
         pos = r.next;
     }
     if (all_full) *all_full = full;
     if (consumed) *consumed = pos;
+    if (n_short) *n_short = ns;
     return n;
 }
 

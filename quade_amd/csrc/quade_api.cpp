@@ -25,8 +25,12 @@ struct Slot {
     uint8_t* d_base = nullptr;
     qd_slot_buffers h{};        // host views
     qd_slot_buffers d{};        // device views (same struct, device pointers)
+    uint32_t* h_short = nullptr;  // pinned: the two streams' lists merged (unique, ascending), 2 * short_cap
+    uint32_t* d_short = nullptr;
     bool busy = false;
 };
+
+enum { K_FAST = 1, K_GENERIC = 2, K_WAVE = 3 };
 
 }  // namespace
 
@@ -62,6 +66,14 @@ struct qd_ctx {
     int opt_force_generic = 0;
     int opt_block = 0;        // 0 = automatic
     int opt_mol_strips = 1;   // LDS-staged molecular stores in the fast kernel
+    int opt_kernel = 0;       // 0 = automatic, K_FAST / K_GENERIC / K_WAVE
+    bool auto_wave = false;   // automatic choice: the wave-span kernel where it is instantiated (set by measurement)
+    int opt_wave_block = 0, opt_wave_quads = 0;
+    bool wave_ok = false;     // the row shape has a wave-span instantiation that fits LDS
+    QdKernelCache kcache;     // per-context launch memo (attribute set, occupancy)
+    // streams this context has work on (its own, its slots', the caller's) with an event recorded after
+    // the last operation issued on each: waits are scoped to the context, never the whole device
+    std::vector<std::pair<hipStream_t, hipEvent_t>> tracked;
 
     // counters
     u64* d_partial = nullptr;
@@ -87,6 +99,49 @@ int fail(const qd_ctx* c, int code, const std::string& msg) {
         if (e_ != hipSuccess)                                                                    \
             return fail((c), QD_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
     } while (0)
+
+hipStream_t resolve_stream(const qd_ctx* c, void* stream) {
+    return stream == QD_STREAM_CONTEXT ? c->stream : (hipStream_t)stream;  // NULL = HIP's null stream
+}
+
+// remember that `st` carries work of this context up to now
+hipError_t track(qd_ctx* c, hipStream_t st) {
+    for (auto& t : c->tracked)
+        if (t.first == st) return hipEventRecord(t.second, st);
+    hipEvent_t ev;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+    c->tracked.emplace_back(st, ev);
+    return hipEventRecord(ev, st);
+}
+
+// host waits for everything this context issued
+hipError_t wait_all(qd_ctx* c) {
+    for (auto& t : c->tracked) {
+        hipError_t e = hipEventSynchronize(t.second);
+        if (e != hipSuccess) return e;
+    }
+    return hipStreamSynchronize(c->stream);
+}
+
+// the context's own stream waits (on the device) for everything this context issued elsewhere
+hipError_t join_into_own_stream(qd_ctx* c) {
+    for (auto& t : c->tracked) {
+        if (t.first == c->stream) continue;
+        hipError_t e = hipStreamWaitEvent(c->stream, t.second, 0);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+void forget_stream(qd_ctx* c, hipStream_t st) {
+    for (size_t i = 0; i < c->tracked.size(); ++i)
+        if (c->tracked[i].first == st) {
+            (void)hipEventDestroy(c->tracked[i].second);
+            c->tracked.erase(c->tracked.begin() + (long)i);
+            return;
+        }
+}
 
 // canonical key of a byte string: little-endian packed, zero padded
 void canon(const uint8_t* b, int len, u64 w[QD_KEY_WORDS]) {
@@ -144,7 +199,7 @@ void free_table(qd_ctx* c) {
 // (re)build the device table from the host barcodes and the current plan
 int rebuild(qd_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, wait_all(c));  // nothing of this context may still read the old table
     free_table(c);
     const int S = c->S;
     const int K = c->lay.key_width;
@@ -203,6 +258,18 @@ int rebuild(qd_ctx* c) {
         ok = ok && mw <= 8 && L.qual_width[k] <= 8;
     }
     c->fast_ok = ok;
+    c->wave_ok = false;
+    if (ok) {
+        DemuxParams wp;
+        memset(&wp, 0, sizeof wp);
+        wp.n_streams = L.n_streams;
+        wp.M = L.mol_width;
+        for (int k = 0; k < 2; ++k) {
+            wp.seq_stride[k] = L.seq_stride[k];
+            wp.qual_stride[k] = L.qual_stride[k];
+        }
+        c->wave_ok = qd_wave_supported(wp) && c->lds_bytes + 4 * qd_wave_lds_per_wave(wp) <= 160 * 1024;
+    }
 
     c->cnt_stride = (uint32_t)((2 * S + 1 + 3) & ~3);
     // one counter row per workgroup (modulo), capped at 64 MiB of rows for very large tables
@@ -223,6 +290,9 @@ void fill_params(const qd_ctx* c, DemuxParams& p, bool fast) {
     p.slots = fast ? c->d_slots_fast : c->d_slots_gen;
     p.slot_mask = fast ? c->mask_fast : c->mask_gen;
     p.seed = fast ? c->seed_fast : c->seed_gen;
+    p.gslots = c->d_slots_gen;
+    p.gmask = c->mask_gen;
+    p.gseed = c->seed_gen;
     p.bk16 = c->d_bk16;
     p.bk32 = c->d_bk32;
     p.blen = c->d_blen;
@@ -255,7 +325,17 @@ void fill_params(const qd_ctx* c, DemuxParams& p, bool fast) {
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* mol, hipStream_t st) {
+// which kernel takes a batch: dense = per-read lengths apply to (potentially) every pair
+int pick_kernel(const qd_ctx* c, bool dense_len) {
+    if (!c->fast_ok || dense_len || c->opt_force_generic || c->opt_kernel == K_GENERIC) return K_GENERIC;
+    if (c->opt_kernel == K_FAST) return K_FAST;
+    if (c->opt_kernel == K_WAVE) return c->wave_ok ? K_WAVE : K_FAST;
+    return c->wave_ok && c->auto_wave ? K_WAVE : K_FAST;
+}
+
+// n_short < 0: no exception list (len rows, if any, apply to every pair -> generic kernel)
+int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* mol, hipStream_t st,
+           int64_t n_short = -1, const uint32_t* short_idx = nullptr) {
     const qd_layout& L = c->lay;
     bool has_len = false;
     for (int k = 0; k < L.n_streams; ++k) {
@@ -267,9 +347,12 @@ int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* 
     if (!codes || !aligned16(codes)) return fail(c, QD_ERR_INVALID, "codes buffer NULL or not 16-byte aligned");
     if (L.mol_width > 0 && (!mol || !aligned16(mol)))
         return fail(c, QD_ERR_INVALID, "mol buffer NULL or not 16-byte aligned");
-    const bool fast = c->fast_ok && !has_len && !c->opt_force_generic;
+    if (n > (int64_t)0xFFFFFFFF) return fail(c, QD_ERR_INVALID, "more than 2^32-1 pairs in one batch");
+    // a listed minority of short reads: fast kernel for everybody, the listed pairs redone afterwards
+    const bool sparse = has_len && n_short >= 0 && n_short <= n / 2;
+    const int kind = pick_kernel(c, has_len && !sparse);
     DemuxParams p;
-    fill_params(c, p, fast);
+    fill_params(c, p, kind != K_GENERIC);
     for (int k = 0; k < L.n_streams; ++k) {
         p.seq[k] = rows->seq[k];
         p.qual[k] = rows->qual[k];
@@ -279,15 +362,39 @@ int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* 
     p.mol = mol;
     p.n = n;
     hipError_t e;
-    if (fast) {
-        e = qd_launch_fast(p, c->cu, c->opt_wg_per_cu, c->opt_block, c->lds_bytes, c->lds_strip_bytes, st);
+    if (kind == K_WAVE) {
+        int block = c->opt_wave_block ? c->opt_wave_block : 256;
+        const size_t per_wave = qd_wave_lds_per_wave(p);
+        if (c->lds_bytes + (size_t)(block / 64) * per_wave > 160 * 1024) block = 256;
+        const int waves = block / 64;
+        int quads = c->opt_wave_quads;
+        if (quads <= 0) {
+            // small table image: short-lived workgroups (the grid is oversubscribed and evens itself out);
+            // large image: stage it once per resident workgroup
+            quads = 4;
+            if (c->lds_bytes > 24 * 1024) {
+                const int64_t resident = (int64_t)c->cu * std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)(c->lds_bytes + waves * per_wave));
+                quads = (int)std::max<int64_t>(4, ((n >> 9) + resident * waves - 1) / (resident * waves));
+            }
+        }
+        e = qd_launch_wave(p, c->kcache, c->cu, block, quads, c->lds_bytes, st);
+    } else if (kind == K_FAST) {
+        e = qd_launch_fast(p, c->kcache, c->cu, c->opt_wg_per_cu, c->opt_block, c->lds_bytes, c->lds_strip_bytes, st);
     } else {
         const int64_t nb = (n + QD_GEN_BLOCK - 1) / QD_GEN_BLOCK;
         const int grid = (int)std::min<int64_t>(nb, (int64_t)c->cu * 8);
         e = qd_launch_generic(p, grid, st);
     }
     if (e != hipSuccess) return fail(c, QD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    if (kind != K_GENERIC && sparse && n_short > 0) {
+        p.exc = short_idx;
+        p.n_exc = (uint32_t)n_short;
+        e = qd_launch_fixup(p, st);
+        if (e != hipSuccess) return fail(c, QD_ERR_HIP, std::string("fixup launch: ") + hipGetErrorString(e));
+    }
     c->total_pairs += (uint64_t)n;
+    e = track(c, st);
+    if (e != hipSuccess) return fail(c, QD_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e));
     return QD_OK;
 }
 
@@ -357,9 +464,11 @@ int qd_create(int device_id, qd_ctx** out) {
 int qd_destroy(qd_ctx* c) {
     if (!c) return QD_OK;
     (void)hipSetDevice(c->device);
-    (void)hipDeviceSynchronize();
+    (void)wait_all(c);
     qd_slots_destroy(c);
     free_table(c);
+    for (auto& t : c->tracked) (void)hipEventDestroy(t.second);
+    c->tracked.clear();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return QD_OK;
@@ -409,7 +518,7 @@ int qd_set_barcodes(qd_ctx* c, int32_t S, const uint8_t* barcodes, const int32_t
 
 int qd_kernel_kind(const qd_ctx* c, int has_len) {
     if (!c || !c->have_table) return QD_ERR_STATE;
-    return (c->fast_ok && !has_len && !c->opt_force_generic) ? 1 : 2;
+    return pick_kernel(c, has_len != 0);
 }
 
 int qd_set_option(qd_ctx* c, const char* name, int64_t value) {
@@ -433,6 +542,21 @@ int qd_set_option(qd_ctx* c, const char* name, int64_t value) {
         c->opt_force_generic = value != 0;
         return QD_OK;
     }
+    if (!strcmp(name, "kernel")) {
+        if (value < 0 || value > 3) return fail(c, QD_ERR_INVALID, "kernel must be 0 (automatic), 1 (fast), 2 (generic) or 3 (wave-span)");
+        c->opt_kernel = (int)value;
+        return QD_OK;
+    }
+    if (!strcmp(name, "wave_block")) {
+        if (value != 0 && value != 256 && value != 512) return fail(c, QD_ERR_INVALID, "wave_block must be 0, 256 or 512");
+        c->opt_wave_block = (int)value;
+        return QD_OK;
+    }
+    if (!strcmp(name, "wave_quads")) {
+        if (value < 0 || value > 65536) return fail(c, QD_ERR_INVALID, "wave_quads must be 0..65536");
+        c->opt_wave_quads = (int)value;
+        return QD_OK;
+    }
     return fail(c, QD_ERR_INVALID, std::string("unknown option ") + name);
 }
 
@@ -441,13 +565,24 @@ int qd_demux_device(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, 
     if (!c->have_plan || !c->have_table) return fail(c, QD_ERR_STATE, "qd_set_plan and qd_set_barcodes first");
     if (n == 0) return QD_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    return launch(c, n, rows, codes, mol, stream ? (hipStream_t)stream : c->stream);
+    return launch(c, n, rows, codes, mol, resolve_stream(c, stream));
+}
+
+int qd_demux_device_ragged(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* mol, int64_t n_short,
+                           const uint32_t* short_idx, void* stream) {
+    if (!c || !rows || n < 0 || n_short < 0 || (n_short > 0 && !short_idx)) return fail(c, QD_ERR_INVALID, "bad arguments");
+    if (!c->have_plan || !c->have_table) return fail(c, QD_ERR_STATE, "qd_set_plan and qd_set_barcodes first");
+    for (int k = 0; k < c->lay.n_streams; ++k)
+        if (!rows->len[k]) return fail(c, QD_ERR_INVALID, "qd_demux_device_ragged needs the len rows of every stream");
+    if (n == 0) return QD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    return launch(c, n, rows, codes, mol, resolve_stream(c, stream), n_short, short_idx);
 }
 
 int qd_synchronize(qd_ctx* c) {
     if (!c) return QD_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, wait_all(c));
     return QD_OK;
 }
 
@@ -456,7 +591,7 @@ int qd_get_counts(qd_ctx* c, uint64_t* out, int32_t n_values) {
     if (!c->have_table) return fail(c, QD_ERR_STATE, "qd_set_barcodes first");
     if (n_values != 2 * c->S + 4) return fail(c, QD_ERR_INVALID, "n_values must be 2*S+4");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, join_into_own_stream(c));  // the reduce runs behind this context's launches, whatever stream they used
     const uint32_t ncnt = (uint32_t)(2 * c->S + 1);
     hipError_t e = qd_launch_reduce(c->d_partial, c->partial_rows, c->cnt_stride, ncnt, c->d_counts, c->stream);
     if (e != hipSuccess) return fail(c, QD_ERR_HIP, std::string("reduce launch: ") + hipGetErrorString(e));
@@ -481,8 +616,10 @@ int qd_reset_counts(qd_ctx* c) {
     if (!c) return QD_ERR_INVALID;
     if (!c->have_table) return QD_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipDeviceSynchronize());
-    HIPCHK(c, hipMemset(c->d_partial, 0, (size_t)c->partial_rows * c->cnt_stride * 8));
+    HIPCHK(c, join_into_own_stream(c));
+    HIPCHK(c, hipMemsetAsync(c->d_partial, 0, (size_t)c->partial_rows * c->cnt_stride * 8, c->stream));
+    HIPCHK(c, track(c, c->stream));  // later launches on other streams are not ordered behind this: wait here
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->total_pairs = 0;
     return QD_OK;
 }
@@ -504,6 +641,8 @@ static size_t carve(qd_slot_buffers& v, uint8_t* base, const qd_layout& L, int64
     v.codes = (uint16_t*)take((size_t)n * 2);
     v.mol = L.mol_width ? take((size_t)n * L.mol_width) : nullptr;
     v.max_pairs = n;
+    v.short_cap = n / 8 + 64;
+    for (int k = 0; k < 2; ++k) v.short_idx[k] = (k < L.n_streams) ? (uint32_t*)take((size_t)v.short_cap * 4) : nullptr;
     return off;
 }
 
@@ -522,6 +661,8 @@ int qd_slots_create(qd_ctx* c, int32_t n_slots, int64_t max_pairs) {
         HIPCHK(c, hipMalloc((void**)&s.d_base, bytes));
         carve(s.h, s.h_base, c->lay, max_pairs);
         carve(s.d, s.d_base, c->lay, max_pairs);
+        HIPCHK(c, hipHostMalloc((void**)&s.h_short, (size_t)s.h.short_cap * 8, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc((void**)&s.d_short, (size_t)s.h.short_cap * 8));
     }
     return QD_OK;
 }
@@ -532,10 +673,13 @@ int qd_slots_destroy(qd_ctx* c) {
     for (auto& s : c->slots) {
         if (s.stream) {
             (void)hipStreamSynchronize(s.stream);
+            forget_stream(c, s.stream);
             (void)hipStreamDestroy(s.stream);
         }
         if (s.h_base) (void)hipHostFree(s.h_base);
         if (s.d_base) (void)hipFree(s.d_base);
+        if (s.h_short) (void)hipHostFree(s.h_short);
+        if (s.d_short) (void)hipFree(s.d_short);
     }
     c->slots.clear();
     return QD_OK;
@@ -547,7 +691,8 @@ int qd_slot_get(qd_ctx* c, int32_t slot, qd_slot_buffers* out) {
     return QD_OK;
 }
 
-int qd_submit(qd_ctx* c, int32_t slot, int64_t n, int32_t has_len) {
+// n_short: NULL = no exception lists (has_len decides between the fast and the generic kernel)
+static int submit_impl(qd_ctx* c, int32_t slot, int64_t n, int32_t has_len, const int64_t* n_short) {
     if (!c || slot < 0 || slot >= (int)c->slots.size()) return fail(c, QD_ERR_INVALID, "bad slot");
     if (n < 0 || n > c->slot_pairs) return fail(c, QD_ERR_INVALID, "n_pairs exceeds the slot capacity");
     if (!c->have_table) return fail(c, QD_ERR_STATE, "qd_set_barcodes first");
@@ -557,6 +702,30 @@ int qd_submit(qd_ctx* c, int32_t slot, int64_t n, int32_t has_len) {
     s.busy = true;
     if (n == 0) return QD_OK;
     const qd_layout& L = c->lay;
+    // exception lists of the streams -> one ascending list without duplicates (a pair short in both
+    // index reads is redone once), indices beyond the batch dropped
+    int64_t m = -1;
+    if (n_short) {
+        bool listed = true;
+        for (int k = 0; k < L.n_streams; ++k) listed = listed && n_short[k] >= 0 && n_short[k] <= s.h.short_cap;
+        if (listed) {
+            const uint32_t* a = s.h.short_idx[0];
+            const uint32_t* b = L.n_streams > 1 ? s.h.short_idx[1] : nullptr;
+            int64_t na = n_short[0], nb = b ? n_short[1] : 0, i = 0, j = 0;
+            m = 0;
+            while (i < na || j < nb) {
+                uint32_t v;
+                if (j >= nb || (i < na && a[i] <= b[j])) {
+                    v = a[i++];
+                    if (j < nb && b[j] == v) ++j;
+                } else {
+                    v = b[j++];
+                }
+                if ((int64_t)v < n) s.h_short[m++] = v;
+            }
+            if (m == 0) has_len = 0;  // every short read lies beyond the batch
+        }
+    }
     qd_rows rows{};
     for (int k = 0; k < L.n_streams; ++k) {
         HIPCHK(c, hipMemcpyAsync(s.d.seq[k], s.h.seq[k], (size_t)n * L.seq_stride[k], hipMemcpyHostToDevice, s.stream));
@@ -568,12 +737,22 @@ int qd_submit(qd_ctx* c, int32_t slot, int64_t n, int32_t has_len) {
             rows.len[k] = s.d.len[k];
         }
     }
-    const int r = launch(c, n, &rows, s.d.codes, s.d.mol, s.stream);
+    if (has_len && m > 0)
+        HIPCHK(c, hipMemcpyAsync(s.d_short, s.h_short, (size_t)m * 4, hipMemcpyHostToDevice, s.stream));
+    const int r = launch(c, n, &rows, s.d.codes, s.d.mol, s.stream, has_len ? m : -1, s.d_short);
     if (r != QD_OK) return r;
     HIPCHK(c, hipMemcpyAsync(s.h.codes, s.d.codes, (size_t)n * 2, hipMemcpyDeviceToHost, s.stream));
     if (L.mol_width)
         HIPCHK(c, hipMemcpyAsync(s.h.mol, s.d.mol, (size_t)n * L.mol_width, hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(c, track(c, s.stream));
     return QD_OK;
+}
+
+int qd_submit(qd_ctx* c, int32_t slot, int64_t n, int32_t has_len) { return submit_impl(c, slot, n, has_len, nullptr); }
+
+int qd_submit_ragged(qd_ctx* c, int32_t slot, int64_t n, const int64_t n_short[2]) {
+    if (!n_short) return fail(c, QD_ERR_INVALID, "n_short is NULL");
+    return submit_impl(c, slot, n, 1, n_short);
 }
 
 int qd_wait(qd_ctx* c, int32_t slot) {

@@ -107,21 +107,23 @@ class FastqStream(object):
             self._avg = consumed / n
         return text, off
 
-    def take_packed(self, max_records, layout, k, seq_rows, qual_rows, len_rows):
+    def take_packed(self, max_records, layout, k, seq_rows, qual_rows, len_rows, short_idx=None):
         """Same scan, but the records' index windows are packed straight into the given
-        (pinned) row buffers.  Returns (n, all_full)."""
+        (pinned) row buffers; the indices of reads shorter than their window go to short_idx.
+        Returns (n, all_full, n_short)."""
         want = int(max_records * (self._avg or 64) * 1.05) + 4096
         while True:
             self._fill(want)
             buf = np.frombuffer(self._buf, dtype=np.uint8)
-            n, full, consumed = hb.pack_index_fastq(layout, k, buf, seq_rows, qual_rows, len_rows, max_records)
+            n, full, consumed, n_short = hb.pack_index_fastq(layout, k, buf, seq_rows, qual_rows, len_rows,
+                                                             max_records, short_idx)
             if n == max_records or self._eof:
                 break
             want = max(want * 2, len(self._buf) + self._read_bytes)
         self._buf = self._buf[consumed:]
         if n:
             self._avg = consumed / n
-        return n, full
+        return n, full, n_short
 
     def close(self):
         self._stop = True

@@ -48,7 +48,11 @@ class qd_rows(C.Structure):
 
 class qd_slot_buffers(C.Structure):
     _fields_ = [("seq", C.c_void_p * 2), ("qual", C.c_void_p * 2), ("len", C.c_void_p * 2),
-                ("codes", C.c_void_p), ("mol", C.c_void_p), ("max_pairs", C.c_int64)]
+                ("codes", C.c_void_p), ("mol", C.c_void_p), ("max_pairs", C.c_int64),
+                ("short_idx", C.c_void_p * 2), ("short_cap", C.c_int64)]
+
+
+STREAM_CONTEXT = C.c_void_p(-1)  # QD_STREAM_CONTEXT: the context's own stream (None/0 = HIP's null stream)
 
 
 # every symbol include/quade_hip.h declares: (name, restype, argtypes)
@@ -66,6 +70,7 @@ SYMBOLS = [
     ("qd_get_layout", C.c_int, [_P, C.POINTER(qd_layout)]),
     ("qd_set_barcodes", C.c_int, [_P, C.c_int32, _P, _P]),
     ("qd_demux_device", C.c_int, [_P, C.c_int64, C.POINTER(qd_rows), _P, _P, _P]),
+    ("qd_demux_device_ragged", C.c_int, [_P, C.c_int64, C.POINTER(qd_rows), _P, _P, C.c_int64, _P, _P]),
     ("qd_kernel_kind", C.c_int, [_P, C.c_int]),
     ("qd_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("qd_get_counts", C.c_int, [_P, _P, C.c_int32]),
@@ -75,10 +80,12 @@ SYMBOLS = [
     ("qd_slots_destroy", C.c_int, [_P]),
     ("qd_slot_get", C.c_int, [_P, C.c_int32, C.POINTER(qd_slot_buffers)]),
     ("qd_submit", C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32]),
+    ("qd_submit_ragged", C.c_int, [_P, C.c_int32, C.c_int64, C.POINTER(C.c_int64)]),
     ("qd_wait", C.c_int, [_P, C.c_int32]),
     ("qd_fastq_index", C.c_int64, [_P, C.c_int64, C.c_int64, _P, C.POINTER(C.c_int64)]),
     ("qd_pack_index_fastq", C.c_int64, [C.POINTER(qd_layout), C.c_int32, _P, C.c_int64, C.c_int64, _P, _P, _P,
-                                        C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_int64), _P, C.c_int64,
+                                        C.POINTER(C.c_int64)]),
     ("qd_pack_index_reads", C.c_int, [C.POINTER(qd_layout), C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P,
                                       C.POINTER(C.c_int32)]),
     ("qd_build_tags", C.c_int, [C.POINTER(qd_layout), C.POINTER(qd_plan), C.c_int64, C.POINTER(_P), C.POINTER(_P), _P,
@@ -172,18 +179,21 @@ def fastq_index(text: bytes | np.ndarray, max_records=None):
     return off[:n + 1], consumed.value
 
 
-def pack_index_fastq(layout: qd_layout, k: int, text, seq_rows, qual_rows, len_rows, max_records):
+def pack_index_fastq(layout: qd_layout, k: int, text, seq_rows, qual_rows, len_rows, max_records, short_idx=None):
     """Packs stream k from fastq text into the given row arrays (numpy uint8, C-contiguous, or raw
-    addresses).  Returns (n_records, all_full, consumed)."""
+    addresses).  short_idx: uint32 array that receives the indices of the reads shorter than their
+    window.  Returns (n_records, all_full, consumed, n_short)."""
     lib = load_library()
     buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else text
     full = C.c_int32(1)
     consumed = C.c_int64(0)
+    n_short = C.c_int64(0)
     n = lib.qd_pack_index_fastq(C.byref(layout), k, _ptr(buf), buf.size, max_records, _ptr(seq_rows),
-                                _ptr(qual_rows), _ptr(len_rows), C.byref(full), C.byref(consumed))
+                                _ptr(qual_rows), _ptr(len_rows), C.byref(full), C.byref(consumed),
+                                _ptr(short_idx), 0 if short_idx is None else short_idx.size, C.byref(n_short))
     if n < 0:
         raise QuadeHipError(int(n), lib.qd_strerror(int(n)).decode())
-    return int(n), bool(full.value), consumed.value
+    return int(n), bool(full.value), consumed.value, n_short.value
 
 
 def pack_index_reads(layout: qd_layout, k: int, seqs, quals):
@@ -318,16 +328,30 @@ class Engine(object):
         self._chk(self.lib.qd_set_option(self._h, name.encode(), int(value)))
 
     def kernel_kind(self, has_len=False):
-        return {1: "fast", 2: "generic"}[self.lib.qd_kernel_kind(self._h, int(has_len))]
+        return {1: "fast", 2: "generic", 3: "wave"}[self.lib.qd_kernel_kind(self._h, int(has_len))]
 
     # -- device-resident batches (pointers are device addresses, e.g. torch tensor .data_ptr())
-    def demux_device(self, n_pairs, seq, qual, codes, mol=None, lens=(None, None), stream=None):
+    @staticmethod
+    def _rows(seq, qual, lens):
         rows = qd_rows()
         for k in range(2):
             rows.seq[k] = seq[k] if k < len(seq) else None
             rows.qual[k] = qual[k] if k < len(qual) else None
             rows.len[k] = lens[k] if k < len(lens) else None
-        self._chk(self.lib.qd_demux_device(self._h, int(n_pairs), C.byref(rows), codes, mol, stream))
+        return rows
+
+    def demux_device(self, n_pairs, seq, qual, codes, mol=None, lens=(None, None), stream=None):
+        """stream: a hipStream_t handle (0 = HIP's null stream); None = the context's own stream."""
+        rows = self._rows(seq, qual, lens)
+        st = STREAM_CONTEXT if stream is None else stream
+        self._chk(self.lib.qd_demux_device(self._h, int(n_pairs), C.byref(rows), codes, mol, st))
+
+    def demux_device_ragged(self, n_pairs, seq, qual, codes, mol, lens, n_short, short_idx, stream=None):
+        """short_idx: device address of n_short unique uint32 pair indices (the short reads)."""
+        rows = self._rows(seq, qual, lens)
+        st = STREAM_CONTEXT if stream is None else stream
+        self._chk(self.lib.qd_demux_device_ragged(self._h, int(n_pairs), C.byref(rows), codes, mol, int(n_short),
+                                                  short_idx, st))
 
     def synchronize(self):
         self._chk(self.lib.qd_synchronize(self._h))
@@ -372,11 +396,17 @@ class Engine(object):
             v["len"].append(view(sb.len[k], (n,)))
         v["codes"] = view(sb.codes, (n,), np.uint16)
         v["mol"] = view(sb.mol, (n, L.mol_width)) if L.mol_width else None
+        v["short"] = [view(sb.short_idx[k], (sb.short_cap,), np.uint32) for k in range(L.n_streams)]
         self._slot_views[i] = v
         return v
 
     def submit(self, slot, n_pairs, has_len=False):
         self._chk(self.lib.qd_submit(self._h, int(slot), int(n_pairs), int(bool(has_len))))
+
+    def submit_ragged(self, slot, n_pairs, n_short):
+        """n_short: per stream, how many short reads the packer listed in the slot's `short` arrays."""
+        ns = (C.c_int64 * 2)(*(list(n_short) + [0, 0])[:2])
+        self._chk(self.lib.qd_submit_ragged(self._h, int(slot), int(n_pairs), ns))
 
     def wait(self, slot):
         self._chk(self.lib.qd_wait(self._h, int(slot)))

@@ -290,15 +290,20 @@ class Quade(object):
                     r2_text, r2_off = r2s.take(B)
                 counts = [r1_off.size - 1, r2_off.size - 1]
                 full = True
+                n_short = []
                 with _timed("pack index reads"):
                     for k, st in enumerate(idx):
-                        nk, fk = st.take_packed(B, L, k, v["seq"][k], v["qual"][k], v["len"][k])
+                        nk, fk, sk = st.take_packed(B, L, k, v["seq"][k], v["qual"][k], v["len"][k], v["short"][k])
                         counts.append(nk)
+                        n_short.append(sk)
                         full = full and fk
                 n = min(counts)
                 last = n < B
                 has_len = not full
-                eng.submit(slot, n, has_len)
+                if has_len:  # the short reads are listed: fast kernel + the listed pairs redone (or generic)
+                    eng.submit_ragged(slot, n, n_short)
+                else:
+                    eng.submit(slot, n, False)
                 pending.append((eng, slot, n, has_len, r1_text, r1_off, r2_text, r2_off))
                 while len(pending) > 1:  # the newest batch stays with the device while we read on
                     hand_over(pending.popleft())

@@ -22,17 +22,21 @@ def engine(torch_cuda):
     e.close()
 
 
-def _check_workload(torch, engine, w, force_generic=False):
+KERNEL_OPT = {"auto": 0, "fast": 1, "generic": 2, "wave": 3}
+
+
+def _check_workload(torch, engine, w, force_generic=False, kernel="fast"):
     codes_o, idx_o, mol_o, counts_o = H.oracle_on_workload(w)
     assert (codes_o == w.expected.numpy().astype(np.uint16)).all()  # generator's own truth
     engine.set_plan(w.plan)
     engine.set_barcodes(w.barcode_strings())
+    engine.set_option("kernel", KERNEL_OPT[kernel])
     seq = [t.cuda() for t in w.seq]
     qual = [t.cuda() for t in w.qual]
     lens = None
     if force_generic:
         lens = [torch.full((max(w.n, 1),), 255, dtype=torch.uint8, device="cuda") for _ in seq]
-    assert engine.kernel_kind(bool(lens)) == ("generic" if force_generic else "fast")
+    assert engine.kernel_kind(bool(lens)) == ("generic" if force_generic else kernel)
     codes, mol = H.hip_on_device(engine, seq, qual, w.n, lens)
     assert (codes == codes_o).all()
     if engine.layout.mol_width:
@@ -47,6 +51,96 @@ def _check_workload(torch, engine, w, force_generic=False):
 def test_fast_kernel_vs_oracle(torch_cuda, engine, name, n):
     from quade_amd import synth
     _check_workload(torch_cuda, engine, synth.generate(name, n, seed=1000 + n))
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"])
+@pytest.mark.parametrize("n", [0, 1, 2, 511, 512, 513, 1023, 4097, 30001, 70003])
+def test_wave_kernel_vs_oracle(torch_cuda, engine, name, n):
+    """The wave-span kernel: whole quads of 512 pairs through the LDS stage, the rest (n mod 512)
+    through the byte-granular tail, several workgroups (70003 pairs = 136 quads)."""
+    from quade_amd import synth
+    _check_workload(torch_cuda, engine, synth.generate(name, n, seed=2000 + n), kernel="wave")
+
+
+@pytest.mark.parametrize("block,quads", [(256, 1), (256, 3), (512, 1), (512, 8)])
+def test_wave_kernel_launch_shapes(torch_cuda, engine, block, quads):
+    from quade_amd import synth
+    for name in ("cfg3", "cfg4"):
+        engine.set_option("wave_block", block)
+        engine.set_option("wave_quads", quads)
+        _check_workload(torch_cuda, engine, synth.generate(name, 40961, seed=block + quads), kernel="wave")
+        engine.reset_counts()
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg4"])
+@pytest.mark.parametrize("kernel", ["fast", "wave"])
+@pytest.mark.parametrize("n_short", [0, 1, 57, 20000])
+def test_sparse_short_reads_on_the_fast_kernels(torch_cuda, engine, name, kernel, n_short):
+    """A batch with a few truncated index reads (Python slice clamping, src/Quade.py:217-218) stays on
+    the fast kernels: qd_demux_device_ragged redoes only the listed pairs.  20000 of 30001 listed =
+    more than half: the generic kernel takes the batch.  Codes, molecular bytes and counters equal
+    the oracle's run on the truncated reads."""
+    torch = torch_cuda
+    from quade_amd import synth
+    w = synth.generate(name, 30001, seed=4242 + n_short)
+    lay = w.layout
+    rng = np.random.default_rng(n_short)
+    lens = [np.full(w.n, lay.seq_off[k] + lay.seq_width[k], dtype=np.uint8) for k in range(lay.n_streams)]
+    seq = [t.numpy().copy() for t in w.seq]
+    qual = [t.numpy().copy() for t in w.qual]
+    short = np.sort(rng.choice(w.n, size=n_short, replace=False)).astype(np.uint32)
+    for r in short:
+        for k in range(lay.n_streams):
+            if rng.integers(0, 3) == 0 and k == 0:
+                continue  # this stream's read stays whole (the other one is cut)
+            c = int(rng.integers(0, lens[k][r]))
+            lens[k][r] = c
+            seq[k][r, c:] = 0  # rows as the packer writes them: zero / 0xFF padded behind the read
+            qc = max(0, min(lay.qual_width[k], c - (lay.qual_off[k] - lay.seq_off[k])))
+            qual[k][r, qc:] = 0xFF
+    bcs = w.barcode_strings()
+    # barcodes of a truncated length, so that some short reads DO match (that needs the table of every
+    # barcode, not the fast kernels' table of the K-long ones): the first short reads keep index read 1
+    # whole, cut index read 2 to 4 bases, and their 12-base key is registered as a sample of its own
+    if lay.n_streams == 2:
+        for r in short[:3]:
+            for k in (0, 1):  # restore, then cut read 2 at 4
+                seq[k][r] = w.seq[k][r].numpy()
+                qual[k][r] = w.qual[k][r].numpy()
+            lens[0][r] = lay.seq_off[0] + lay.seq_width[0]
+            lens[1][r] = 4
+            seq[1][r, 4:] = 0
+            qual[1][r, 4:] = 0xFF
+            key = (bytes(seq[0][r, :8]) + bytes(seq[1][r, :4])).decode("latin-1").upper()
+            if set(key) <= set("ACGTN") and key not in bcs:
+                bcs.append(key)
+    reads = []
+    for k in range(lay.n_streams):
+        reads += list(H.rows_to_reads(seq[k], qual[k], lay.seq_width[k], lay.qual_off[k] - lay.seq_off[k],
+                                      lay.qual_width[k], lens[k]))
+    if lay.n_streams == 1:
+        reads += [None, None]
+    codes_o, _, mol_o, counts_o = H.oracle_on_reads(bcs, w.plan, *reads)
+    engine.set_plan(w.plan)
+    engine.set_barcodes(bcs)
+    engine.set_option("kernel", KERNEL_OPT[kernel])
+    M = lay.mol_width
+    d_seq = [torch.from_numpy(a).cuda() for a in seq]
+    d_qual = [torch.from_numpy(a).cuda() for a in qual]
+    d_len = [torch.from_numpy(a).cuda() for a in lens]
+    d_short = torch.from_numpy(short.astype(np.int64)).to(torch.int32).cuda() if n_short else torch.zeros(1, dtype=torch.int32, device="cuda")
+    codes = torch.full((w.n,), 0x7777, dtype=torch.int16, device="cuda")
+    mol = torch.full((w.n, max(M, 1)), 0x55, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    engine.demux_device_ragged(w.n, [t.data_ptr() for t in d_seq], [t.data_ptr() for t in d_qual], codes.data_ptr(),
+                               mol.data_ptr() if M else None, [t.data_ptr() for t in d_len], n_short,
+                               d_short.data_ptr(), stream=0)
+    torch.cuda.synchronize()
+    got = codes.cpu().numpy().view(np.uint16)
+    assert (got == codes_o).all()
+    if M:
+        assert H.mol_rows_to_str(mol.cpu().numpy()) == mol_o
+    assert (engine.counts() == counts_o).all()
 
 
 @pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"])
@@ -122,15 +216,16 @@ def test_million_pairs_vs_c_oracle_fast_and_generic(torch_cuda, engine):
         engine.set_barcodes(w.barcode_strings())
         seq = [t.cuda() for t in w.seq]
         qual = [t.cuda() for t in w.qual]
-        for generic in (False, True):
-            engine.set_option("force_generic", int(generic))
+        for kernel in ("fast", "wave", "generic"):
+            engine.set_option("kernel", KERNEL_OPT[kernel])
+            assert engine.kernel_kind(False) == kernel
             engine.reset_counts()
             codes, mol = H.hip_on_device(engine, seq, qual, w.n)
-            assert (codes == codes_c).all(), (name, generic)
+            assert (codes == codes_c).all(), (name, kernel)
             if mol_c is not None:
                 assert (mol == mol_c).all()
             assert (engine.counts() == counts_c).all()
-        engine.set_option("force_generic", 0)
+        engine.set_option("kernel", 0)
 
 
 def test_ragged_reads_mixed_barcodes_vs_c_oracle(torch_cuda, engine):

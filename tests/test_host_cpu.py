@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libquade_hip.so does not export %s" % name
     assert declared == {s[0] for s in hb.SYMBOLS}, "ctypes table and header disagree"
-    assert lib.qd_version() == 1
+    assert lib.qd_version() == 2
     assert lib.qd_strerror(hb.QD_ERR_NO_DEVICE) == b"no usable gfx950 HIP device"
 
 
@@ -88,8 +88,12 @@ def test_fastq_index_and_pack_match_oracle_reader(tmp_path):
     sr = np.zeros((n, lay.seq_stride[0]), np.uint8)
     qr = np.zeros((n, lay.qual_stride[0]), np.uint8)
     lr = np.zeros(n, np.uint8)
-    got, full, cons = hb.pack_index_fastq(lay, 0, data, sr, qr, lr, n)
+    short = np.zeros(2, np.uint32)  # room for two: the count still says how many there were
+    got, full, cons, n_short = hb.pack_index_fastq(lay, 0, data, sr, qr, lr, n, short)
     assert (got, full, cons) == (n, False, len(data))
+    need = lay.seq_off[0] + lay.seq_width[0]
+    want_short = [r for r, rec in enumerate(recs) if len(rec.seq) < need]
+    assert n_short == len(want_short) and list(short[:min(2, n_short)]) == want_short[:2]
     for r, rec in enumerate(recs):
         assert lr[r] == len(rec.seq)
         win = rec.seq[lay.seq_off[0]:lay.seq_off[0] + lay.seq_width[0]].encode("latin-1")

@@ -51,8 +51,10 @@ def test_pack_tags_format_equal_oracle(tmp_path_factory, recs, crlf, final_nl, i
     sr = np.zeros((max(n, 1), lay.seq_stride[0]), np.uint8)
     qr = np.zeros((max(n, 1), lay.qual_stride[0]), np.uint8)
     lr = np.zeros(max(n, 1), np.uint8)
-    got, full, _ = hb.pack_index_fastq(lay, 0, buf, sr, qr, lr, n + 1)
+    short = np.zeros(max(n, 1), np.uint32)
+    got, full, _, n_short = hb.pack_index_fastq(lay, 0, buf, sr, qr, lr, n + 1, short)
     assert got == n
+    assert list(short[:n_short]) == [r for r, rec in enumerate(want) if len(rec.seq) < lay.seq_off[0] + lay.seq_width[0]]
     tags, tl = hb.build_tags(lay, plan, n, [sr], [lr])
     text = bytes(hb.format_records(buf, off, np.arange(n), tags, tl)).decode("latin-1")
     exp = ""
@@ -108,7 +110,10 @@ int main() {
     if (qd_plan_layout(&P, &L) != 0) return 11;
     std::vector<uint8_t> sr(n * L.seq_stride[0]), qr(n * L.qual_stride[0]), lr(n);
     int32_t full = 1;
-    if (qd_pack_index_fastq(&L, 0, (const uint8_t*)t.data(), (int64_t)t.size(), n, sr.data(), qr.data(), lr.data(), &full, &consumed) != n) return 12;
+    std::vector<uint32_t> sh(2);
+    int64_t nsh = 0;
+    if (qd_pack_index_fastq(&L, 0, (const uint8_t*)t.data(), (int64_t)t.size(), n, sr.data(), qr.data(), lr.data(), &full, &consumed, sh.data(), 2, &nsh) != n) return 12;
+    if (full != 0 || nsh < 2) return 16;
     const uint8_t* seqs[2] = {sr.data(), nullptr};
     const uint8_t* lens[2] = {lr.data(), nullptr};
     int stride = 2 + L.key_width + L.mol_width;
