@@ -247,6 +247,38 @@ int64_t qd_format_records(const uint8_t* text, const int64_t* rec_off, const int
                           const uint8_t* tag_rows, int32_t tag_stride, const uint8_t* tag_len, uint8_t* out,
                           int64_t out_cap);
 
+/* ---- host I/O: routed records -> per-destination fastq.gz files ---------------------------------------
+ * A sink is one output directory's set of destinations: "<name>_pass", "<name>_fail" per sample and
+ * "Undetermined", each a pair of files <dest>_R1.fastq.gz / <dest>_R2.fastq.gz (src/FastqWriter.py:29-31,
+ * src/Sample.py:44,147-148).  qd_sink_route replaces, for a whole batch, the routing tail of
+ * Sample.FINDER (src/Sample.py:74-75,82-83,90-91: writer called when the write_* flag of the pair's
+ * category is set) and FastqWriter.__call__/flush_buffers (src/FastqWriter.py:48-90): name tag,
+ * record format (as qd_format_records), lazy creation of a destination's two files at its first
+ * routed pair (truncating), gzip members appended in input order.  Compression runs on a thread pool
+ * owned by the library (libdeflate when libdeflate.so.0 loads, zlib otherwise); no file descriptor
+ * is held between members.  qd_sink_route returns once the batch's text has been consumed (the
+ * caller's buffers are free again); compression and the appends continue behind it.  A sink is driven
+ * by one thread at a time; different sinks may be driven concurrently. */
+typedef struct qd_sink qd_sink;
+/* Threads of the I/O pool: n_threads > 0 sets it (before the pool's first use), 0 = one per hardware
+ * thread, < 0 = query only.  Returns the size in effect. */
+int qd_io_threads(int32_t n_threads);
+int qd_io_backend(void); /* 1 = libdeflate, 0 = zlib */
+/* names: n_samples sample names in ordinal order (SAMPLE_LIST order, src/Sample.py:153); gzip_level 0..9;
+ * write_*: the [output] flags (src/Quade.py:125-129 -> Sample.CLASS_INIT). */
+int qd_sink_create(const char* outdir, int32_t n_samples, const char* const* names, int32_t gzip_level,
+                   int32_t write_pass, int32_t write_fail, int32_t write_undetermined, qd_sink** out);
+int qd_sink_set_quiet(qd_sink* sink, int32_t quiet); /* 1: no "Create ... file" lines on stdout */
+/* codes: the device's routing codes of the batch's n pairs; r1/r2 text + rec_off: the insert reads
+ * as qd_fastq_index gives them (record i of both = pair i); tags as qd_build_tags gives them. */
+int qd_sink_route(qd_sink* sink, int64_t n_pairs, const uint16_t* codes, const uint8_t* r1_text,
+                  const int64_t* r1_rec_off, const uint8_t* r2_text, const int64_t* r2_rec_off,
+                  const uint8_t* tag_rows, int32_t tag_stride, const uint8_t* tag_len);
+int qd_sink_flush(qd_sink* sink); /* waits until every member is in its file (src/Sample.py:93-102 FLUSH_ALL) */
+int qd_sink_stats(qd_sink* sink, int64_t* members, int64_t* text_bytes, int64_t* gzip_bytes, int64_t* files);
+const char* qd_sink_last_error(const qd_sink* sink);
+int qd_sink_close(qd_sink* sink); /* flush + destroy */
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,7 @@ class QuadeConf(object):
         self.slots = opt("slots", 3)
         self.gzip_level = opt("gzip_level", 6)
         self.chunk_workers = opt("chunk_workers", 1)
+        self.io_threads = opt("io_threads", 0)
 
         self._test_values()
 
@@ -120,8 +121,8 @@ class QuadeConf(object):
             assert pos["start"] >= 0
             assert pos["end"] >= pos["start"]
         assert self.batch_pairs >= 1 and 1 <= self.slots <= 64 and 0 <= self.gzip_level <= 9 and \
-            1 <= self.chunk_workers <= 64, \
-            "[gpu] batch_pairs >= 1, 1 <= slots <= 64, 0 <= gzip_level <= 9, 1 <= chunk_workers <= 64"
+            1 <= self.chunk_workers <= 64 and 0 <= self.io_threads <= 1024, \
+            "[gpu] batch_pairs >= 1, 1 <= slots <= 64, 0 <= gzip_level <= 9, 1 <= chunk_workers <= 64, 0 <= io_threads <= 1024"
 
     def plan(self):
         """The qd_plan the HIP library takes (include/quade_hip.h)."""

@@ -1,88 +1,87 @@
 # -*- coding: utf-8 -*-
 """
-Output side of the demultiplexer: one pair of fastq.gz files per destination.
+Output side of the demultiplexer: one pair of fastq.gz files per destination, written natively.
 
-Keeps what the reference's FastqWriter fixes (src/FastqWriter.py): file names
-<name>_R1.fastq.gz / <name>_R2.fastq.gz (:29-31), creation at the first routed pair only (:55-57),
-truncation of a pre-existing file at that moment (:76-81), appended gzip members afterwards
-(:83-90).  What changes is granularity: a call takes the already formatted records of a whole
-batch (qd_format_records) instead of one FastqSeq pair, so there is one gzip member per batch
-instead of one per 20 pairs; the decompressed bytes are identical.
+The reference's FastqWriter (src/FastqWriter.py) is one Python object per destination that formats,
+buffers and gzips 20 pairs at a time.  Here a whole output directory is one native *sink*
+(libquade_hip.so, quade_amd/csrc/quade_io.cpp): a batch is scattered by routing code, formatted,
+compressed on the library's thread pool (libdeflate, zlib as the fallback) and appended member by
+member in input order.  Kept from the reference: file names <name>_R1.fastq.gz / <name>_R2.fastq.gz
+(:29-31), creation at a destination's first routed pair only (:55-57), truncation of a pre-existing
+file at that moment (:76-81), appended gzip members afterwards (:83-90), the record and name format
+(:61-69).  No file descriptor stays open between members, so thousands of destinations (cfg5: 1536
+samples x pass/fail x R1/R2) stay far below RLIMIT_NOFILE, as with the reference's open-append-close.
 """
 from __future__ import annotations
 
-import os
-import zlib
-from collections import deque
-from concurrent.futures import ThreadPoolExecutor
+import ctypes as C
 
-# gzip members are compressed on a shared thread pool (zlib releases the GIL) and appended to their
-# file strictly in submission order, so the decompressed stream keeps the input order.
-_POOL = None
-_POOL_THREADS = max(1, min(32, (os.cpu_count() or 2) - 1))
+import numpy as np
+
+from . import hip_backend as hb
 
 
-def _pool():
-    global _POOL
-    if _POOL is None:
-        _POOL = ThreadPoolExecutor(max_workers=_POOL_THREADS, thread_name_prefix="quade-gzip")
-    return _POOL
+def io_threads(n=-1):
+    """Size of the library's I/O pool: n > 0 sets it (before its first use), 0 = one per hardware
+    thread, < 0 = query.  Returns the size in effect."""
+    return hb.load_library().qd_io_threads(int(n))
 
 
-def _gzip_member(data, level):
-    co = zlib.compressobj(level, zlib.DEFLATED, 31)  # 31 = gzip framing
-    return co.compress(data) + co.flush()
+def io_backend():
+    return "libdeflate" if hb.load_library().qd_io_backend() else "zlib"
 
 
-class FastqWriter(object):
-    def __init__(self, name="Unknown", outdir=".", gzip_level=6):
-        self.R1_fastq_name = os.path.join(outdir, name + "_R1.fastq.gz")
-        self.R2_fastq_name = os.path.join(outdir, name + "_R2.fastq.gz")
-        self.gzip_level = gzip_level
-        self.counter = -1  # -1 = files not created yet, as in the reference
-        self._fh = None
-        self._pending = deque()  # (future_R1, future_R2) in submission order
+class FastqSink(object):
+    """All destinations of one output directory."""
 
-    def __repr__(self):
-        return "<Instance of {} from {} >\n".format(self.__class__.__name__, self.__module__)
+    def __init__(self, outdir, sample_names, gzip_level=6, write_pass=True, write_fail=True, write_undetermined=True,
+                 quiet=False):
+        self.lib = hb.load_library()
+        names = [n.encode() if isinstance(n, str) else bytes(n) for n in sample_names]
+        arr = (C.c_char_p * max(len(names), 1))(*names)
+        h = C.c_void_p()
+        r = self.lib.qd_sink_create(str(outdir).encode(), len(names), arr, int(gzip_level), int(bool(write_pass)),
+                                    int(bool(write_fail)), int(bool(write_undetermined)), C.byref(h))
+        if r != hb.QD_OK:
+            raise hb.QuadeHipError(r, "qd_sink_create failed (gzip_level 0..9, names)")
+        self._h = h
+        if quiet:
+            self.lib.qd_sink_set_quiet(self._h, 1)
 
-    def __call__(self, records_R1: bytes, records_R2: bytes, n_pairs: int):
-        """Append the formatted records of n_pairs routed pairs."""
-        if n_pairs == 0:
+    def _chk(self, r):
+        if r != hb.QD_OK:
+            raise IOError(self.lib.qd_sink_last_error(self._h).decode() or "sink error %d" % r)
+
+    def route(self, n, codes, r1_text, r1_off, r2_text, r2_off, tags, tag_len):
+        """One batch: codes uint16[n], insert-read texts (uint8 arrays) + int64 record offsets,
+        name tags [n, stride] + lengths.  Returns when the batch's buffers may be reused."""
+        if n == 0:
             return
-        if self.counter == -1:
-            self.init_files()
-            self.counter = 0
-        self.counter += n_pairs
-        pool = _pool()
-        self._pending.append((pool.submit(_gzip_member, records_R1, self.gzip_level),
-                              pool.submit(_gzip_member, records_R2, self.gzip_level)))
-        self._drain(block=len(self._pending) > 8)
+        codes = np.ascontiguousarray(codes[:n], dtype=np.uint16)
+        self._chk(self.lib.qd_sink_route(self._h, int(n), hb._ptr(codes), hb._ptr(r1_text), hb._ptr(r1_off),
+                                         hb._ptr(r2_text), hb._ptr(r2_off), hb._ptr(tags), tags.shape[1],
+                                         hb._ptr(tag_len)))
 
-    def _drain(self, block):
-        """Write finished members, oldest first; never out of order."""
-        while self._pending:
-            f1, f2 = self._pending[0]
-            if not block and not (f1.done() and f2.done()):
-                break
-            self._fh[0].write(f1.result())
-            self._fh[1].write(f2.result())
-            self._pending.popleft()
+    def flush(self):
+        self._chk(self.lib.qd_sink_flush(self._h))
 
-    def init_files(self):
-        print("\tCreate {} file".format(self.R1_fastq_name))
-        print("\tCreate {} file".format(self.R2_fastq_name))
-        self._fh = (open(self.R1_fastq_name, "wb"), open(self.R2_fastq_name, "wb"))
-
-    def flush_buffers(self):
-        if self._fh:
-            self._drain(block=True)
-            for fh in self._fh:
-                fh.flush()
+    def stats(self):
+        v = [C.c_int64(0) for _ in range(4)]
+        self.lib.qd_sink_stats(self._h, *[C.byref(x) for x in v])
+        return dict(zip(("members", "text_bytes", "gzip_bytes", "files"), (x.value for x in v)))
 
     def close(self):
-        if self._fh:
-            self._drain(block=True)
-            for fh in self._fh:
-                fh.close()
-            self._fh = None
+        if getattr(self, "_h", None):
+            try:
+                self.flush()
+            finally:
+                self.lib.qd_sink_close(self._h)
+                self._h = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.qd_sink_close(self._h)
+                self._h = None
+        except Exception:
+            pass

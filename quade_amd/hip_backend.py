@@ -91,6 +91,16 @@ SYMBOLS = [
     ("qd_build_tags", C.c_int, [C.POINTER(qd_layout), C.POINTER(qd_plan), C.c_int64, C.POINTER(_P), C.POINTER(_P), _P,
                                 _P, C.c_int32, _P]),
     ("qd_format_records", C.c_int64, [_P, _P, _P, C.c_int64, _P, C.c_int32, _P, _P, C.c_int64]),
+    ("qd_io_threads", C.c_int, [C.c_int32]),
+    ("qd_io_backend", C.c_int, []),
+    ("qd_sink_create", C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                 C.POINTER(_P)]),
+    ("qd_sink_set_quiet", C.c_int, [_P, C.c_int32]),
+    ("qd_sink_route", C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    ("qd_sink_flush", C.c_int, [_P]),
+    ("qd_sink_stats", C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("qd_sink_last_error", C.c_char_p, [_P]),
+    ("qd_sink_close", C.c_int, [_P]),
 ]
 
 _lib = None

@@ -117,6 +117,8 @@ class Quade(object):
             devices = [os.environ.get("QUADE_DEVICE", os.environ.get("LOCAL_RANK", "0"))]
         elif devices == ["all"]:
             devices = list(range(hb.device_count()))
+        from .fastq_writer import io_threads
+        io_threads(cf.io_threads)  # size of the library's gzip pool (before its first use)
         plan = cf.plan()
         # chunk workers (host threads) each drive their own contexts: a context is single-threaded
         n_chunks = len(cf.seq_R1)

@@ -10,10 +10,8 @@ Python matching here, and no CPU fallback); counters are the device's counters.
 """
 from __future__ import annotations
 
-import numpy as np
-
 from . import hip_backend as hb
-from .fastq_writer import FastqWriter
+from .fastq_writer import FastqSink
 
 
 class Batch(object):
@@ -27,54 +25,30 @@ class Batch(object):
 
 
 class WriterSet(object):
-    """The pass / fail / Undetermined writers of one output directory, created on first use.
-    Sample owns one for the run's output directory; chunk workers and the multi-process mode use
-    one per chunk part directory."""
+    """The pass / fail / Undetermined destinations of one output directory: a native sink
+    (quade_amd/fastq_writer.py).  Sample owns one for the run's output directory; chunk workers and
+    the multi-process mode use one per chunk part directory."""
 
     def __init__(self, outdir, gzip_level):
         self.outdir, self.gzip_level = outdir, gzip_level
-        self._w = {}
-
-    def get(self, code):
-        """code: 0xFFFF, 2*ordinal (pass) or 2*ordinal+1 (fail)"""
-        w = self._w.get(code)
-        if w is None:
-            if code == hb.CODE_UNDETERMINED:
-                name = "Undetermined"
-            else:
-                name = "{}_{}".format(Sample.SAMPLE_LIST[code >> 1].name, "fail" if code & 1 else "pass")
-            w = self._w[code] = FastqWriter(name, self.outdir, self.gzip_level)
-        return w
+        self._sink = FastqSink(outdir, [s.name for s in Sample.SAMPLE_LIST], gzip_level, Sample.WRITE_PASS,
+                               Sample.WRITE_FAIL, Sample.WRITE_UNDETERMINED)
 
     def route(self, batch):
         """src/Sample.py:56-91 for every pair of the batch, counters excluded (they come from the
-        device).  Within a destination the input order is kept."""
-        n = batch.n
-        if n == 0:
-            return
-        codes = np.asarray(batch.codes[:n])
-        order = np.argsort(codes, kind="stable")
-        sorted_codes = codes[order]
-        bounds = np.flatnonzero(np.diff(sorted_codes)) + 1
-        starts = np.concatenate(([0], bounds))
-        ends = np.concatenate((bounds, [n]))
-        for lo, hi in zip(starts, ends):
-            code = int(sorted_codes[lo])
-            if code == hb.CODE_UNDETERMINED:
-                if not Sample.WRITE_UNDETERMINED:
-                    continue
-            elif code & 1:
-                if not Sample.WRITE_FAIL:
-                    continue
-            elif not Sample.WRITE_PASS:
-                continue
-            sel = order[lo:hi]
-            self.get(code)(hb.format_records(batch.r1_text, batch.r1_off, sel, batch.tags, batch.tag_len),
-                           hb.format_records(batch.r2_text, batch.r2_off, sel, batch.tags, batch.tag_len), hi - lo)
+        device): scatter by routing code (write_* flags honoured), format, gzip, append.  Within a
+        destination the input order is kept."""
+        self._sink.route(batch.n, batch.codes, batch.r1_text, batch.r1_off, batch.r2_text, batch.r2_off,
+                         batch.tags, batch.tag_len)
+
+    def flush(self):
+        self._sink.flush()
+
+    def stats(self):
+        return self._sink.stats()
 
     def close(self):
-        for w in self._w.values():
-            w.close()
+        self._sink.close()
 
 
 class Sample(object):
@@ -88,7 +62,6 @@ class Sample(object):
     MIN_QUAL = 0
     OUTDIR = "."
     GZIP_LEVEL = 6
-    UNDETERMINED_WRITER = None
     WRITERS = None  # WriterSet of the run's output directory
 
     # ~~~~~~~ CLASS METHODS ~~~~~~~ #
@@ -99,7 +72,8 @@ class Sample(object):
         cls.NAME_TO_SAMPLE = {}
         cls.INDEX_TO_SAMPLE = {}
         cls.SAMPLE_LIST = []
-        cls.UNDETERMINED_WRITER = None
+        if cls.WRITERS is not None:
+            cls.WRITERS.close()
         cls.WRITERS = None
 
     @classmethod
@@ -112,8 +86,7 @@ class Sample(object):
         cls.MIN_QUAL = min_qual
         cls.OUTDIR = outdir
         cls.GZIP_LEVEL = gzip_level
-        cls.WRITERS = WriterSet(outdir, gzip_level)
-        cls.UNDETERMINED_WRITER = cls.WRITERS.get(hb.CODE_UNDETERMINED)
+        cls.WRITERS = None  # the run's WriterSet: made at the first batch, once every Sample is registered
 
     @classmethod
     def BARCODES(cls):
@@ -125,7 +98,11 @@ class Sample(object):
         """Route one batch (src/Sample.py:56-91 for every pair of it).  Codes: 0xFFFF undetermined,
         2*ordinal pass, 2*ordinal+1 fail.  `writers`: a WriterSet other than the run's own (chunk
         part directories)."""
-        (writers or cls.WRITERS).route(batch)
+        if writers is None:
+            if cls.WRITERS is None:
+                cls.WRITERS = WriterSet(cls.OUTDIR, cls.GZIP_LEVEL)
+            writers = cls.WRITERS
+        writers.route(batch)
 
     @classmethod
     def SET_COUNTS(cls, counts):
@@ -145,9 +122,10 @@ class Sample(object):
 
     @classmethod
     def FLUSH_ALL(cls):
-        """src/Sample.py:93-102; also closes the files"""
+        """src/Sample.py:93-102: every member is in its file when this returns"""
         if cls.WRITERS:
             cls.WRITERS.close()
+            cls.WRITERS = None
 
     @classmethod
     def REPORT(cls):
@@ -193,14 +171,6 @@ class Sample(object):
     @property
     def total(self):
         return self.pass_qual + self.fail_qual
-
-    @property
-    def pass_writer(self):
-        return type(self).WRITERS.get(2 * self.ordinal)
-
-    @property
-    def fail_writer(self):
-        return type(self).WRITERS.get(2 * self.ordinal + 1)
 
     def __repr__(self):
         return "<Instance of {} from {} >\n".format(self.__class__.__name__, self.__module__)

@@ -1,0 +1,235 @@
+"""The native output sink (quade_amd/csrc/quade_io.cpp) on the CPU: routed, formatted, compressed and
+appended records against the oracle's FastqWriter (restated src/FastqWriter.py:48-90), byte for byte
+after decompression; lazy file creation, write flags, input order across many gzip members, the zlib
+fallback, and thousands of destinations under a small RLIMIT_NOFILE."""
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import quade_oracle as qo
+from quade_amd import hip_backend as hb
+from quade_amd.fastq_writer import FastqSink, io_backend
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _records(rng, n, seq_len):
+    names = ["SIM:1:FC:%d:%d:%d %d:N:0:" % (rng.integers(1, 9), i, rng.integers(0, 9999), 1) for i in range(n)]
+    seqs = ["".join(rng.choice(list("ACGTN"), seq_len)) for _ in range(n)]
+    quals = ["".join(chr(33 + int(q)) for q in rng.integers(2, 41, seq_len)) for _ in range(n)]
+    text = "".join("@%s\n%s\n+\n%s\n" % t for t in zip(names, seqs, quals)).encode("latin-1")
+    return names, seqs, quals, np.frombuffer(text, dtype=np.uint8)
+
+
+def _oracle_outputs(outdir, sample_names, batches, flags):
+    """The oracle's per-pair writers driven with the same routing decisions."""
+    writers = {}
+
+    def writer(code):
+        if code not in writers:
+            name = "Undetermined" if code == 0xFFFF else "%s_%s" % (sample_names[code >> 1], "fail" if code & 1 else "pass")
+            writers[code] = qo.FastqWriter(name, outdir)
+        return writers[code]
+
+    for codes, r1, r2, idx, mol in batches:
+        for i, code in enumerate(codes):
+            code = int(code)
+            ok = flags[2] if code == 0xFFFF else (flags[1] if code & 1 else flags[0])
+            if not ok:
+                continue
+            a = qo.FastqSeq(r1[0][i].split()[0], r1[1][i], [ord(c) - 33 for c in r1[2][i]])
+            b = qo.FastqSeq(r2[0][i].split()[0], r2[1][i], [ord(c) - 33 for c in r2[2][i]])
+            writer(code)(a, b, qo.FastqSeq("i", idx[i], [40] * len(idx[i])),
+                         qo.FastqSeq("m", mol[i], [40] * len(mol[i])) if mol[i] else "")
+    for w in writers.values():
+        w.close()
+
+
+def _gz(path):
+    with gzip.open(path, "rb") as fh:
+        return fh.read()
+
+
+def _compare(d1, d2):
+    f1 = sorted(f for f in os.listdir(d1) if f.endswith(".fastq.gz"))
+    f2 = sorted(f for f in os.listdir(d2) if f.endswith(".fastq.gz"))
+    assert f1 == f2
+    for f in f1:
+        assert _gz(os.path.join(d1, f)) == _gz(os.path.join(d2, f)), f
+    return f1
+
+
+@pytest.mark.parametrize("flags", [(True, True, True), (True, False, False), (False, False, True)])
+def test_sink_equals_oracle_writer(tmp_path, flags):
+    rng = np.random.default_rng(sum(flags))
+    S = 5
+    names = ["S%d" % i for i in range(S)]
+    mine, ref = tmp_path / "mine", tmp_path / "ref"
+    mine.mkdir()
+    ref.mkdir()
+    sink = FastqSink(str(mine), names, 4, *flags, quiet=True)
+    batches = []
+    for b in range(3):
+        n = [700, 1, 2500][b]
+        r1 = _records(rng, n, 60)
+        r2 = _records(rng, n, 40)
+        codes = rng.integers(0, 2 * S + 2, n).astype(np.uint16)
+        codes[codes >= 2 * S] = 0xFFFF
+        if b == 0:
+            codes[codes == 3] = 2  # S1_fail appears only from the second batch on (lazy creation mid-run)
+        idx = ["".join(rng.choice(list("ACGTacgtN"), 8)) for _ in range(n)]
+        mol = ["".join(rng.choice(list("ACGT"), int(rng.integers(0, 2)) * 5)) for _ in range(n)]
+        tags = np.zeros((n, 2 + 8 + 5), np.uint8)
+        tl = np.zeros(n, np.uint8)
+        for i in range(n):
+            t = (":" + idx[i] + (":" + mol[i] if mol[i] else "")).encode()
+            tags[i, :len(t)] = np.frombuffer(t, np.uint8)
+            tl[i] = len(t)
+        o1, _ = hb.fastq_index(r1[3])
+        o2, _ = hb.fastq_index(r2[3])
+        sink.route(n, codes, r1[3], o1, r2[3], o2, tags, tl)
+        batches.append((codes, r1, r2, idx, mol))
+    sink.close()
+    _oracle_outputs(str(ref), names, batches, flags)
+    files = _compare(str(mine), str(ref))
+    assert files and (flags[1] or not any("_fail_" in f for f in files))
+
+
+def test_sink_order_across_many_members_and_backends(tmp_path):
+    """One destination receives ~12 MB of text in one batch: several 2 MB members per file, compressed
+    concurrently, appended in input order; same bytes from libdeflate and from the zlib fallback."""
+    code = r'''
+import sys, os, gzip, numpy as np
+sys.path.insert(0, %r)
+from quade_amd import hip_backend as hb
+from quade_amd.fastq_writer import FastqSink, io_backend
+n = 40000
+text = b"".join(b"@r%%07d x\n%%s\n+\n%%s\n" %% (i, b"ACGT" * 36, b"IIII" * 36) for i in range(n))
+buf = np.frombuffer(text, np.uint8)
+off, _ = hb.fastq_index(buf)
+codes = np.zeros(n, np.uint16); codes[::7] = 0xFFFF
+tags = np.zeros((n, 4), np.uint8); tags[:] = np.frombuffer(b":ACG", np.uint8); tl = np.full(n, 4, np.uint8)
+s = FastqSink(sys.argv[1], ["A"], 1, quiet=True)
+for _ in range(2):
+    s.route(n, codes, buf, off, buf, off, tags, tl)
+st = s.stats(); s.close()
+data = gzip.open(os.path.join(sys.argv[1], "A_pass_R1.fastq.gz")).read()
+ids = [int(l[2:9]) for l in data.split(b"\n")[0::4] if l]
+exp = [i for i in range(n) if i %% 7] * 2
+assert ids == exp, "order broken"
+assert st["members"] >= 16, st
+print(io_backend(), st["members"], len(data))
+''' % ROOT
+    outs = []
+    for env_extra in ({}, {"QUADE_NO_LIBDEFLATE": "1"}):
+        d = tmp_path / ("o%d" % len(outs))
+        d.mkdir()
+        r = subprocess.run([sys.executable, "-c", code, str(d)], capture_output=True, text=True, env=dict(os.environ, **env_extra))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.split())
+    assert outs[1][0] == "zlib" and outs[0][2] == outs[1][2]
+    assert outs[0][0] == io_backend()
+
+
+def test_sink_thousands_of_destinations_under_small_fd_limit(tmp_path):
+    """cfg5-sized sample sheet (1536 samples -> up to 6146 files) with RLIMIT_NOFILE = 64: no descriptor
+    is held between members (the reference opens, appends and closes per flush, src/FastqWriter.py:83-90)."""
+    code = r'''
+import sys, os, resource, numpy as np
+resource.setrlimit(resource.RLIMIT_NOFILE, (64, 64))
+sys.path.insert(0, %r)
+from quade_amd import hip_backend as hb
+from quade_amd.fastq_writer import FastqSink
+S, n = 1536, 8000
+text = b"".join(b"@r%%d\nACGTACGT\n+\nIIIIIIII\n" %% i for i in range(n))
+buf = np.frombuffer(text, np.uint8)
+off, _ = hb.fastq_index(buf)
+rng = np.random.default_rng(3)
+tags = np.zeros((n, 3), np.uint8); tags[:] = np.frombuffer(b":AC", np.uint8); tl = np.full(n, 3, np.uint8)
+s = FastqSink(sys.argv[1], ["S%%d" %% i for i in range(S)], 1, quiet=True)
+tot = 0
+for b in range(3):
+    codes = rng.integers(0, 2 * S, n).astype(np.uint16)
+    s.route(n, codes, buf, off, buf, off, tags, tl)
+st = s.stats(); s.close()
+print(st["files"], len(os.listdir(sys.argv[1])))
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    files, listed = map(int, r.stdout.split())
+    assert files == listed and files > 5000
+
+
+def test_sink_reports_write_errors(tmp_path):
+    n = 10
+    text = b"".join(b"@r%d\nACGT\n+\nIIII\n" % i for i in range(n))
+    buf = np.frombuffer(text, np.uint8)
+    off, _ = hb.fastq_index(buf)
+    tags = np.zeros((n, 2), np.uint8)
+    tags[:] = np.frombuffer(b":A", np.uint8)
+    tl = np.full(n, 2, np.uint8)
+    s = FastqSink(str(tmp_path / "does" / "not" / "exist"), ["A"], 1, quiet=True)
+    with pytest.raises(IOError) as ei:
+        s.route(n, np.zeros(n, np.uint16), buf, off, buf, off, tags, tl)
+        s.flush()
+    assert "No such file or directory" in str(ei.value)
+    bad = np.full(n, 7, np.uint16)  # a code beyond the one-sample table
+    s2 = FastqSink(str(tmp_path), ["A"], 1, quiet=True)
+    with pytest.raises(IOError):
+        s2.route(n, bad, buf, off, buf, off, tags, tl)
+
+
+def test_sink_thread_sanitizer(tmp_path):
+    """quade_io.cpp + fastq_pack.cpp built with -fsanitize=thread: two sinks driven from two threads
+    over the shared pool, many small members per file."""
+    drv = tmp_path / "drv.cpp"
+    drv.write_text(r'''
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+#include "include/quade_hip.h"
+static int run(const char* dir, int seed) {
+    std::string t;
+    const int n = 30000;
+    for (int i = 0; i < n; ++i) { char b[160]; snprintf(b, sizeof b, "@r%d d\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n", i); t += b; }
+    std::vector<int64_t> off(n + 1);
+    int64_t consumed = 0;
+    if (qd_fastq_index((const uint8_t*)t.data(), (int64_t)t.size(), n, off.data(), &consumed) != n) return 1;
+    std::vector<uint16_t> codes(n);
+    for (int i = 0; i < n; ++i) codes[i] = (uint16_t)(((i * 7 + seed) % 5 == 4) ? 0xFFFF : (i * 7 + seed) % 4);
+    std::vector<uint8_t> tags(n * 3, ':'), tl(n, 3);
+    const char* names[2] = {"A", "B"};
+    qd_sink* s = nullptr;
+    if (qd_sink_create(dir, 2, names, 1, 1, 1, 1, &s) != 0) return 2;
+    qd_sink_set_quiet(s, 1);
+    for (int b = 0; b < 6; ++b)
+        if (qd_sink_route(s, n, codes.data(), (const uint8_t*)t.data(), off.data(), (const uint8_t*)t.data(), off.data(), tags.data(), 3, tl.data()) != 0) return 3;
+    return qd_sink_close(s);
+}
+int main(int argc, char** argv) {
+    qd_io_threads(6);
+    int r1 = -1, r2 = -1;
+    std::thread a([&] { r1 = run(argv[1], 0); }), b([&] { r2 = run(argv[2], 1); });
+    a.join(); b.join();
+    printf("%d %d\n", r1, r2);
+    return r1 || r2;
+}
+''')
+    exe = tmp_path / "drv"
+    cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=thread", "-fno-omit-frame-pointer", "-I", ROOT, str(drv),
+           os.path.join(ROOT, "quade_amd", "csrc", "quade_io.cpp"), os.path.join(ROOT, "quade_amd", "csrc", "fastq_pack.cpp"),
+           "-o", str(exe), "-lz", "-ldl", "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    r = subprocess.run([str(exe), str(tmp_path / "a"), str(tmp_path / "b")], capture_output=True, text=True,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout, r.stderr[-3000:])
+    assert len(os.listdir(tmp_path / "a")) == 10
