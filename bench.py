@@ -172,8 +172,7 @@ def main():
         if dist:
             dist.barrier()
     from quade_amd import synth
-    from quade_amd.hip_backend import Engine
-    from quade_amd.dist import allreduce_counts
+    from quade_amd.hip_backend import Comm, Engine, comm_unique_id
 
     cfg = synth.CONFIGS[args.config]
     per_gpu_default = {"cfg2": 10_000_000, "cfg3": 100_000_000, "cfg4": 62_500_000, "cfg5": 125_000_000}
@@ -208,10 +207,29 @@ def main():
     for _ in range(max(args.warmup, 50)):
         step()
     torch.cuda.synchronize()
-    if dist:  # warm the communicator up too: its first collective builds the rings
-        red_dev0 = torch.device("cuda", local_rank) if backend == "nccl" else None
+    # The count reduce of the N > 1 path is the PRODUCT's: libquade_hip.so's own RCCL communicator
+    # (qd_comm_create_rank / qd_reduce_counts); torch.distributed only carries its 128-byte unique id,
+    # the barriers and the max-over-ranks of the timing.  Rehearsals with several ranks on one GPU
+    # (QUADE_BENCH_BACKEND=gloo; RCCL wants one rank per device) sum through gloo instead.
+    comm = None
+
+    def reduce_counts():
+        if comm is not None:
+            return comm.reduce_counts()          # reduce of the partial rows + RCCL all-reduce + D2H
+        c = eng.counts()
+        if dist and world > 1:                   # rehearsal transport
+            t = torch.from_numpy(c.astype(np.int64))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            c = t.numpy().astype(np.uint64)
+        return c
+
+    if dist:
         with stdout_to_stderr():
-            allreduce_counts(eng.counts(), dist, device=red_dev0)
+            if backend == "nccl":
+                box = [comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                comm = Comm.rank(eng, world, rank, box[0])
+            reduce_counts()  # warm the communicator up too: its first collective builds the rings
             warm = torch.zeros(1, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(warm, op=dist.ReduceOp.MAX)
             dist.barrier()
@@ -229,10 +247,9 @@ def main():
     for i in range(args.steps):
         step()
     ev1.record(stream)
-    counts = eng.counts()                      # waits for the device, sums the partial rows
+    eng.synchronize()                          # this rank's launches are done
     t_counts = time.perf_counter()
-    red_dev = torch.device("cuda", local_rank) if backend == "nccl" else None
-    total_counts = allreduce_counts(counts, dist, device=red_dev) if dist else counts
+    total_counts = reduce_counts()             # partial rows summed on the device (+ the all-reduce over ranks)
     torch.cuda.synchronize()
     t_reduced = time.perf_counter()
     if dist:
@@ -263,7 +280,7 @@ def main():
         same = bool(torch.equal(got, w.expected))
         S = cfg["S"]
         exp_hist = torch.bincount(w.expected[w.expected != 0xFFFF].to(torch.int64), minlength=2 * S).cpu().numpy()
-        c = counts.astype(np.int64)
+        c = eng.counts().astype(np.int64)  # this rank's own counters
         ok_counts = bool((c[4:] == exp_hist * args.steps).all()) and c[0] == n * args.steps and \
             c[0] == c[1] + c[2] + c[3]
         verified = bool(same and ok_counts)
@@ -313,7 +330,7 @@ def main():
                      "traffic_source": traffic_source,
                      "kernel_ms": kern_ms_mean, "algorithmic_bytes_per_pair": algo_bytes},
         "world": comm_world,  # as the communicator reports it (1 = no process group)
-        "count_reduce": {"backend": ("rccl" if backend == "nccl" else backend) if dist else None,
+        "count_reduce": {"backend": ("rccl via qd_reduce_counts" if comm is not None else backend) if dist else None,
                          "ms_max_over_ranks": max(r["allreduce_ms"] for r in per_rank) if dist else 0.0},
         "ranks": per_rank,
         "launched_by": "self-spawn" if os.environ.get("QUADE_BENCH_SPAWNED") else
@@ -327,6 +344,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(rows, w.plan, lay, w.barcode_strings(), hip_codes, ns)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     eng.close()
     if dist:
         dist.destroy_process_group()

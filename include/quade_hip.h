@@ -247,6 +247,28 @@ int64_t qd_format_records(const uint8_t* text, const int64_t* rec_off, const int
                           const uint8_t* tag_rows, int32_t tag_stride, const uint8_t* tag_len, uint8_t* out,
                           int64_t out_cap);
 
+/* ---- multi-GPU: the one exchange of the path ------------------------------------------------------------
+ * Read pairs are independent (src/Sample.py:56-91 touches nothing but counters) and chunks are
+ * independent files (src/Quade.py:198,229), so work shards across GPUs with no data-path collective.
+ * What is exchanged is what the reference keeps in class-level counters (src/Sample.py:32,144): one
+ * sum of the uint64[2S+1] counters + TOTAL over all member contexts, an RCCL all-reduce over xGMI
+ * (librccl.so.1 is loaded on first use; single-GPU users never load it).
+ *   one process, several devices : qd_comm_create_local(contexts, n)            (ncclCommInitAll)
+ *   one process per device       : rank 0 calls qd_comm_unique_id and hands the 128 bytes to the other
+ *                                  ranks by any means; every rank calls qd_comm_create_rank (ncclCommInitRank)
+ * qd_reduce_counts waits for the member contexts' outstanding work, sums, and gives every caller the
+ * total in the layout of qd_get_counts.  Member contexts must hold the same sample table. */
+typedef struct qd_comm qd_comm;
+#define QD_UNIQUE_ID_BYTES 128
+int qd_comm_unique_id(uint8_t id[QD_UNIQUE_ID_BYTES]);
+int qd_comm_create_local(qd_ctx* const* contexts, int32_t n_contexts, qd_comm** out);
+int qd_comm_create_rank(qd_ctx* ctx, int32_t world_size, int32_t rank, const uint8_t id[QD_UNIQUE_ID_BYTES],
+                        qd_comm** out);
+int qd_comm_world(const qd_comm* comm);
+int qd_reduce_counts(qd_comm* comm, uint64_t* out, int32_t n_values);
+int qd_comm_destroy(qd_comm* comm);
+const char* qd_comm_last_error(void); /* text of the last qd_comm_* / qd_reduce_counts error on this thread */
+
 /* ---- host I/O: routed records -> per-destination fastq.gz files ---------------------------------------
  * A sink is one output directory's set of destinations: "<name>_pass", "<name>_fail" per sample and
  * "Undetermined", each a pair of files <dest>_R1.fastq.gz / <dest>_R2.fastq.gz (src/FastqWriter.py:29-31,

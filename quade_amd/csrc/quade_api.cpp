@@ -1,11 +1,14 @@
 // C ABI of libquade_hip.so: context, plan, barcode table, launches, counters, pinned slots.
 // Host C++ over the HIP runtime; kernels live in quade_kernels.hip.  See include/quade_hip.h.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library is bound at run time (dlopen), single-GPU users never load it
 
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -77,7 +80,8 @@ struct qd_ctx {
 
     // counters
     u64* d_partial = nullptr;
-    u64* d_counts = nullptr;
+    u64* d_counts = nullptr;   // [cnt_stride + 4]: 2S+1 counters, then TOTAL at [cnt_stride] (reduce scratch)
+    u64* d_total = nullptr;    // all-reduce result, same shape
     uint32_t partial_rows = 0, cnt_stride = 0;
     uint64_t total_pairs = 0;
 
@@ -189,6 +193,8 @@ void free_table(qd_ctx* c) {
     if (c->d_blen) (void)hipFree(c->d_blen);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_counts) (void)hipFree(c->d_counts);
+    if (c->d_total) (void)hipFree(c->d_total);
+    c->d_total = nullptr;
     c->d_slots_fast = c->d_slots_gen = nullptr;
     c->d_bk16 = c->d_bk32 = nullptr;
     c->d_blen = nullptr;
@@ -275,7 +281,8 @@ int rebuild(qd_ctx* c) {
     // one counter row per workgroup (modulo), capped at 64 MiB of rows for very large tables
     c->partial_rows = (uint32_t)std::max<size_t>(8, std::min<size_t>((size_t)c->cu * 8, ((size_t)64 << 20) / ((size_t)c->cnt_stride * 8)));
     HIPCHK(c, hipMalloc(&c->d_partial, (size_t)c->partial_rows * c->cnt_stride * 8));
-    HIPCHK(c, hipMalloc(&c->d_counts, (size_t)c->cnt_stride * 8));
+    HIPCHK(c, hipMalloc(&c->d_counts, ((size_t)c->cnt_stride + 4) * 8));
+    HIPCHK(c, hipMalloc(&c->d_total, ((size_t)c->cnt_stride + 4) * 8));
     HIPCHK(c, hipMemset(c->d_partial, 0, (size_t)c->partial_rows * c->cnt_stride * 8));
     c->total_pairs = 0;
     c->have_table = true;
@@ -586,18 +593,19 @@ int qd_synchronize(qd_ctx* c) {
     return QD_OK;
 }
 
-int qd_get_counts(qd_ctx* c, uint64_t* out, int32_t n_values) {
-    if (!c || !out) return QD_ERR_INVALID;
-    if (!c->have_table) return fail(c, QD_ERR_STATE, "qd_set_barcodes first");
-    if (n_values != 2 * c->S + 4) return fail(c, QD_ERR_INVALID, "n_values must be 2*S+4");
+// counters of this context summed on its device: d_counts[0..2S] + TOTAL at d_counts[cnt_stride], on c->stream
+static int counts_to_device(qd_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, join_into_own_stream(c));  // the reduce runs behind this context's launches, whatever stream they used
     const uint32_t ncnt = (uint32_t)(2 * c->S + 1);
     hipError_t e = qd_launch_reduce(c->d_partial, c->partial_rows, c->cnt_stride, ncnt, c->d_counts, c->stream);
     if (e != hipSuccess) return fail(c, QD_ERR_HIP, std::string("reduce launch: ") + hipGetErrorString(e));
-    std::vector<u64> h(ncnt);
-    HIPCHK(c, hipMemcpyAsync(h.data(), c->d_counts, (size_t)ncnt * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_counts + c->cnt_stride, &c->total_pairs, 8, hipMemcpyHostToDevice, c->stream));
+    return QD_OK;
+}
+
+// h = device layout [cnt_stride + 1] -> the ABI's vector [2S + 4]
+static void compose_counts(const qd_ctx* c, const u64* h, uint64_t* out) {
     uint64_t pass = 0, failq = 0;
     for (int i = 0; i < c->S; ++i) {
         out[4 + 2 * i] = h[2 * i];
@@ -605,10 +613,22 @@ int qd_get_counts(qd_ctx* c, uint64_t* out, int32_t n_values) {
         pass += h[2 * i];
         failq += h[2 * i + 1];
     }
-    out[0] = c->total_pairs;  // TOTAL: pairs submitted (Sample.py:62)
+    out[0] = h[c->cnt_stride];  // TOTAL: pairs submitted (Sample.py:62)
     out[1] = pass;
     out[2] = failq;
-    out[3] = h[2 * c->S];     // UNDETERMINED: counted on the device, not derived
+    out[3] = h[2 * c->S];       // UNDETERMINED: counted on the device, not derived
+}
+
+int qd_get_counts(qd_ctx* c, uint64_t* out, int32_t n_values) {
+    if (!c || !out) return QD_ERR_INVALID;
+    if (!c->have_table) return fail(c, QD_ERR_STATE, "qd_set_barcodes first");
+    if (n_values != 2 * c->S + 4) return fail(c, QD_ERR_INVALID, "n_values must be 2*S+4");
+    const int r = counts_to_device(c);
+    if (r != QD_OK) return r;
+    std::vector<u64> h((size_t)c->cnt_stride + 1);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->d_counts, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    compose_counts(c, h.data(), out);
     return QD_OK;
 }
 
@@ -761,6 +781,165 @@ int qd_wait(qd_ctx* c, int32_t slot) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(s.stream));
     s.busy = false;
+    return QD_OK;
+}
+
+}  // extern "C"
+
+// ---- multi-GPU: the one exchange of the path --------------------------------------------------------
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+    bool ok = false;
+    Rccl() {
+        handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!handle) handle = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!handle) {
+            why = std::string("librccl.so.1: ") + dlerror();
+            return;
+        }
+#define QD_SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(handle, name))
+        QD_SYM(GetUniqueId, "ncclGetUniqueId");
+        QD_SYM(CommInitRank, "ncclCommInitRank");
+        QD_SYM(CommInitAll, "ncclCommInitAll");
+        QD_SYM(CommDestroy, "ncclCommDestroy");
+        QD_SYM(AllReduce, "ncclAllReduce");
+        QD_SYM(GroupStart, "ncclGroupStart");
+        QD_SYM(GroupEnd, "ncclGroupEnd");
+        QD_SYM(GetErrorString, "ncclGetErrorString");
+#undef QD_SYM
+        ok = GetUniqueId && CommInitRank && CommInitAll && CommDestroy && AllReduce && GroupStart && GroupEnd && GetErrorString;
+        if (!ok) why = "librccl.so.1 lacks an expected symbol";
+    }
+};
+Rccl& rccl() {
+    static Rccl R;
+    return R;
+}
+thread_local std::string g_comm_error;
+int comm_fail(int code, const std::string& msg) {
+    g_comm_error = msg;
+    return code;
+}
+}  // namespace
+
+struct qd_comm {
+    std::vector<qd_ctx*> ctxs;       // this process's member contexts (one per local device)
+    std::vector<ncclComm_t> comms;   // their communicators
+    int world = 0, rank0 = 0;        // ranks of the whole communicator; rank of ctxs[0]
+};
+
+extern "C" {
+
+const char* qd_comm_last_error(void) { return g_comm_error.c_str(); }
+
+int qd_comm_unique_id(uint8_t id[QD_UNIQUE_ID_BYTES]) {
+    if (!id) return comm_fail(QD_ERR_INVALID, "id is NULL");
+    Rccl& R = rccl();
+    if (!R.ok) return comm_fail(QD_ERR_HIP, R.why);
+    static_assert(QD_UNIQUE_ID_BYTES == sizeof(ncclUniqueId), "unique id size");
+    ncclUniqueId u;
+    const ncclResult_t r = R.GetUniqueId(&u);
+    if (r != ncclSuccess) return comm_fail(QD_ERR_HIP, std::string("ncclGetUniqueId: ") + R.GetErrorString(r));
+    memcpy(id, &u, sizeof u);
+    return QD_OK;
+}
+
+int qd_comm_create_local(qd_ctx* const* ctxs, int32_t n, qd_comm** out) {
+    if (!ctxs || n < 1 || !out) return comm_fail(QD_ERR_INVALID, "bad arguments");
+    *out = nullptr;
+    Rccl& R = rccl();
+    if (!R.ok) return comm_fail(QD_ERR_HIP, R.why);
+    std::vector<int> devs;
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i]) return comm_fail(QD_ERR_INVALID, "NULL context");
+        for (int d : devs)
+            if (d == ctxs[i]->device) return comm_fail(QD_ERR_INVALID, "two member contexts share a device (RCCL wants one rank per device)");
+        devs.push_back(ctxs[i]->device);
+    }
+    std::unique_ptr<qd_comm> cm(new qd_comm());
+    cm->ctxs.assign(ctxs, ctxs + n);
+    cm->comms.resize((size_t)n);
+    cm->world = n;
+    const ncclResult_t r = R.CommInitAll(cm->comms.data(), n, devs.data());  // one process, the n local devices
+    if (r != ncclSuccess) return comm_fail(QD_ERR_HIP, std::string("ncclCommInitAll: ") + R.GetErrorString(r));
+    *out = cm.release();
+    return QD_OK;
+}
+
+int qd_comm_create_rank(qd_ctx* ctx, int32_t world, int32_t rank, const uint8_t id[QD_UNIQUE_ID_BYTES], qd_comm** out) {
+    if (!ctx || world < 1 || rank < 0 || rank >= world || !id || !out) return comm_fail(QD_ERR_INVALID, "bad arguments");
+    *out = nullptr;
+    Rccl& R = rccl();
+    if (!R.ok) return comm_fail(QD_ERR_HIP, R.why);
+    if (hipSetDevice(ctx->device) != hipSuccess) return comm_fail(QD_ERR_HIP, "hipSetDevice failed");
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    std::unique_ptr<qd_comm> cm(new qd_comm());
+    cm->ctxs.push_back(ctx);
+    cm->comms.resize(1);
+    cm->world = world;
+    cm->rank0 = rank;
+    const ncclResult_t r = R.CommInitRank(&cm->comms[0], world, u, rank);  // one process per GPU
+    if (r != ncclSuccess) return comm_fail(QD_ERR_HIP, std::string("ncclCommInitRank: ") + R.GetErrorString(r));
+    *out = cm.release();
+    return QD_OK;
+}
+
+int qd_comm_world(const qd_comm* cm) { return cm ? cm->world : QD_ERR_INVALID; }
+
+int qd_reduce_counts(qd_comm* cm, uint64_t* out, int32_t n_values) {
+    if (!cm || !out) return comm_fail(QD_ERR_INVALID, "bad arguments");
+    Rccl& R = rccl();
+    qd_ctx* c0 = cm->ctxs[0];
+    if (!c0->have_table) return comm_fail(QD_ERR_STATE, "qd_set_barcodes first");
+    if (n_values != 2 * c0->S + 4) return comm_fail(QD_ERR_INVALID, "n_values must be 2*S+4");
+    for (qd_ctx* c : cm->ctxs) {
+        if (!c->have_table || c->S != c0->S) return comm_fail(QD_ERR_STATE, "member contexts hold different sample tables");
+        const int r = counts_to_device(c);  // every member's counters + TOTAL, summed on its own device
+        if (r != QD_OK) return comm_fail(r, c->err);
+    }
+    // one all-reduce (sum, uint64) of 2S+1 counters + TOTAL over xGMI; latency-bound (<= 24.6 KB at S = 1536)
+    const size_t count = (size_t)c0->cnt_stride + 1;
+    ncclResult_t r = R.GroupStart();
+    for (size_t i = 0; r == ncclSuccess && i < cm->ctxs.size(); ++i) {
+        qd_ctx* c = cm->ctxs[i];
+        if (hipSetDevice(c->device) != hipSuccess) return comm_fail(QD_ERR_HIP, "hipSetDevice failed");
+        r = R.AllReduce(c->d_counts, c->d_total, count, ncclUint64, ncclSum, cm->comms[i], c->stream);
+    }
+    const ncclResult_t r2 = R.GroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess)
+        return comm_fail(QD_ERR_HIP, std::string("ncclAllReduce: ") + R.GetErrorString(r != ncclSuccess ? r : r2));
+    std::vector<u64> h(count);
+    if (hipSetDevice(c0->device) != hipSuccess) return comm_fail(QD_ERR_HIP, "hipSetDevice failed");
+    hipError_t e = hipMemcpyAsync(h.data(), c0->d_total, count * 8, hipMemcpyDeviceToHost, c0->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c0->stream);
+    for (size_t i = 1; e == hipSuccess && i < cm->ctxs.size(); ++i) {  // every member's collective has completed on return
+        if (hipSetDevice(cm->ctxs[i]->device) != hipSuccess) return comm_fail(QD_ERR_HIP, "hipSetDevice failed");
+        e = hipStreamSynchronize(cm->ctxs[i]->stream);
+    }
+    if (e != hipSuccess) return comm_fail(QD_ERR_HIP, std::string("count reduce: ") + hipGetErrorString(e));
+    compose_counts(c0, h.data(), out);
+    return QD_OK;
+}
+
+int qd_comm_destroy(qd_comm* cm) {
+    if (!cm) return QD_OK;
+    Rccl& R = rccl();
+    for (size_t i = 0; i < cm->comms.size(); ++i) {
+        (void)hipSetDevice(cm->ctxs[i]->device);
+        if (R.ok && cm->comms[i]) (void)R.CommDestroy(cm->comms[i]);
+    }
+    delete cm;
     return QD_OK;
 }
 

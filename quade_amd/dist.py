@@ -1,12 +1,22 @@
 # -*- coding: utf-8 -*-
 """
-The only inter-GPU exchange of the path: a sum of the per-sample counter vectors (uint64[2S+4],
-<= 24.6 KB at S = 1536) at the end of a run.  One process per GPU, torch.distributed (backend
-"nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).  Read pairs are independent
-(src/Sample.py:56-91 touches nothing but counters), so chunks shard across ranks with no
-data-path collective.
+Multi-GPU plumbing of the command line.  The only inter-GPU exchange of the path is a sum of the
+per-sample counter vectors (uint64[2S+4], <= 24.6 KB at S = 1536) at the end of a run: an RCCL
+all-reduce over xGMI made by libquade_hip.so itself (include/quade_hip.h: qd_comm_*,
+qd_reduce_counts) -- no PyTorch here.  Read pairs are independent (src/Sample.py:56-91 touches
+nothing but counters) and chunks are independent files (src/Quade.py:198,229), so chunks shard across
+ranks with no data-path collective.
+
+One process per GPU: started by `python -m quade_amd.launch -n N -c Conf.txt` (or any launcher that
+sets RANK / WORLD_SIZE / LOCAL_RANK, e.g. torch.distributed.run).  Rank 0 makes the communicator's
+unique id (128 bytes) and hands it to the other ranks through a file in the output directory; that
+directory is shared by construction (one node, the merged outputs land there).
 """
 from __future__ import annotations
+
+import os
+import shutil
+import time
 
 import numpy as np
 
@@ -18,18 +28,70 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allreduce_counts(counts, dist=None, device=None):
-    """Sums a counter vector over all ranks; every rank gets the total (numpy uint64)."""
-    import torch
-    if dist is None:
-        import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        return np.asarray(counts, dtype=np.uint64).copy()
-    t = torch.from_numpy(np.asarray(counts, dtype=np.uint64).astype(np.int64))  # NCCL has no uint64 sum
-    if device is not None:
-        t = t.to(device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t.cpu().numpy().astype(np.uint64)
+def world_from_env(env=None):
+    """(rank, world, local_rank) as a launcher exported them; (0, 1, 0) without a launcher."""
+    env = os.environ if env is None else env
+    world = int(env.get("QUADE_WORLD", env.get("WORLD_SIZE", "1")))
+    rank = int(env.get("QUADE_RANK", env.get("RANK", "0")))
+    local = int(env.get("QUADE_LOCAL_RANK", env.get("LOCAL_RANK", str(rank))))
+    return rank, world, local
+
+
+def run_token(env=None):
+    """Same string in every rank of one launch, different between launches: the launcher's token, or
+    (torch.distributed.run) its rendezvous port and the launcher's pid -- all ranks are its children."""
+    env = os.environ if env is None else env
+    return env.get("QUADE_RUN_TOKEN") or "%s_%d" % (env.get("MASTER_PORT", "0"), os.getppid())
+
+
+def rendezvous_dir(outdir, token):
+    return os.path.join(outdir, ".quade_rdv_" + token)
+
+
+def exchange_bytes(outdir, token, rank, name, make=None, timeout=300.0):
+    """Rank 0 publishes make() under `name` (written whole, then renamed); every other rank waits for
+    it.  Returns the bytes."""
+    d = rendezvous_dir(outdir, token)
+    path = os.path.join(d, name)
+    if rank == 0:
+        os.makedirs(d, exist_ok=True)
+        data = make()
+        with open(path + ".tmp", "wb") as fh:
+            fh.write(data)
+        os.replace(path + ".tmp", path)
+        return data
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > timeout:
+            raise RuntimeError("rank %d: no %s from rank 0 after %.0f s (did rank 0 start?)" % (rank, path, timeout))
+        time.sleep(0.01)
+    with open(path, "rb") as fh:
+        return fh.read()
+
+
+def sum_counts_through_files(outdir, token, rank, world, counts, timeout=600.0):
+    """Rehearsal transport (QUADE_DIST_TRANSPORT=files): ranks that cannot have an RCCL communicator --
+    several ranks sharing ONE device on a single-GPU box -- hand their counter vectors to rank 0 through
+    files in the rendezvous directory.  Rank 0 gets the total (it writes the report), the others
+    their own vector back.  Not used when every rank has its own GPU."""
+    d = rendezvous_dir(outdir, token)
+    os.makedirs(d, exist_ok=True)
+    counts = np.asarray(counts, dtype=np.uint64)
+    if rank != 0:
+        mine = os.path.join(d, "counts.%d" % rank)
+        counts.tofile(mine + ".tmp")
+        os.replace(mine + ".tmp", mine)
+        return counts
+    total = counts.copy()
+    t0 = time.time()
+    for r in range(1, world):
+        p = os.path.join(d, "counts.%d" % r)
+        while not os.path.exists(p):
+            if time.time() - t0 > timeout:
+                raise RuntimeError("rank 0: rank %d never published its counts" % r)
+            time.sleep(0.01)
+        total += np.fromfile(p, dtype=np.uint64)
+    return total
 
 
 # ---- chunk-sharded runs of the command line (one process per GPU) -----------------------------------
@@ -38,9 +100,18 @@ def chunk_owner(chunk_index, world):
     return chunk_index % world
 
 
+def parts_root(outdir):
+    return os.path.join(outdir, ".quade_parts")
+
+
 def part_dir(outdir, chunk_index):
-    import os
-    return os.path.join(outdir, ".quade_parts", "chunk%06d" % chunk_index)
+    return os.path.join(parts_root(outdir), "chunk%06d" % chunk_index)
+
+
+def clean_parts(outdir):
+    """Before any chunk starts (rank 0, ahead of publishing the communicator id): part files of a
+    crashed earlier run must not be spliced into this run's outputs."""
+    shutil.rmtree(parts_root(outdir), ignore_errors=True)
 
 
 def merge_parts(outdir, n_chunks):
@@ -48,8 +119,6 @@ def merge_parts(outdir, n_chunks):
     consist of several members (the reference's own writer appends members,
     src/FastqWriter.py:83-90), so the decompressed bytes equal those of a sequential run.  A final
     file exists only if some chunk produced it (lazy creation, src/FastqWriter.py:55-57)."""
-    import os
-    import shutil
     names = []
     for c in range(n_chunks):
         d = part_dir(outdir, c)
@@ -64,5 +133,5 @@ def merge_parts(outdir, n_chunks):
                 if os.path.exists(p):
                     with open(p, "rb") as fh:
                         shutil.copyfileobj(fh, out, 16 << 20)
-    shutil.rmtree(os.path.join(outdir, ".quade_parts"), ignore_errors=True)
+    shutil.rmtree(parts_root(outdir), ignore_errors=True)
     return names

@@ -91,6 +91,13 @@ SYMBOLS = [
     ("qd_build_tags", C.c_int, [C.POINTER(qd_layout), C.POINTER(qd_plan), C.c_int64, C.POINTER(_P), C.POINTER(_P), _P,
                                 _P, C.c_int32, _P]),
     ("qd_format_records", C.c_int64, [_P, _P, _P, C.c_int64, _P, C.c_int32, _P, _P, C.c_int64]),
+    ("qd_comm_unique_id", C.c_int, [_P]),
+    ("qd_comm_create_local", C.c_int, [C.POINTER(_P), C.c_int32, C.POINTER(_P)]),
+    ("qd_comm_create_rank", C.c_int, [_P, C.c_int32, C.c_int32, _P, C.POINTER(_P)]),
+    ("qd_comm_world", C.c_int, [_P]),
+    ("qd_reduce_counts", C.c_int, [_P, _P, C.c_int32]),
+    ("qd_comm_destroy", C.c_int, [_P]),
+    ("qd_comm_last_error", C.c_char_p, []),
     ("qd_io_threads", C.c_int, [C.c_int32]),
     ("qd_io_backend", C.c_int, []),
     ("qd_sink_create", C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -420,3 +427,66 @@ class Engine(object):
 
     def wait(self, slot):
         self._chk(self.lib.qd_wait(self._h, int(slot)))
+
+
+# ---- multi-GPU count reduce (RCCL through the C ABI) --------------------------------------------------------
+UNIQUE_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128 opaque bytes made by rank 0 (ncclGetUniqueId) that every rank of a communicator needs."""
+    lib = load_library()
+    buf = (C.c_uint8 * UNIQUE_ID_BYTES)()
+    r = lib.qd_comm_unique_id(buf)
+    if r != QD_OK:
+        raise QuadeHipError(r, lib.qd_comm_last_error().decode())
+    return bytes(buf)
+
+
+class Comm(object):
+    """The contexts whose counters are summed by one RCCL all-reduce (include/quade_hip.h, qd_comm)."""
+
+    def __init__(self, handle, engines):
+        self.lib = load_library()
+        self._h = handle
+        self.engines = engines
+
+    @classmethod
+    def local(cls, engines):
+        """One process, one context per local device (ncclCommInitAll)."""
+        lib = load_library()
+        arr = (_P * len(engines))(*[e._h for e in engines])
+        h = C.c_void_p()
+        r = lib.qd_comm_create_local(arr, len(engines), C.byref(h))
+        if r != QD_OK:
+            raise QuadeHipError(r, lib.qd_comm_last_error().decode())
+        return cls(h, list(engines))
+
+    @classmethod
+    def rank(cls, engine, world, rank, unique_id):
+        """One process per device: this process's rank of a `world`-rank communicator (ncclCommInitRank)."""
+        lib = load_library()
+        assert len(unique_id) == UNIQUE_ID_BYTES
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        r = lib.qd_comm_create_rank(engine._h, int(world), int(rank), buf, C.byref(h))
+        if r != QD_OK:
+            raise QuadeHipError(r, lib.qd_comm_last_error().decode())
+        return cls(h, [engine])
+
+    @property
+    def world(self):
+        return self.lib.qd_comm_world(self._h)
+
+    def reduce_counts(self):
+        """Sum of every member context's counters (all ranks): numpy uint64[2S+4]."""
+        out = np.zeros(2 * self.engines[0].n_samples + 4, dtype=np.uint64)
+        r = self.lib.qd_reduce_counts(self._h, _ptr(out), out.size)
+        if r != QD_OK:
+            raise QuadeHipError(r, self.lib.qd_comm_last_error().decode())
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.qd_comm_destroy(self._h)
+            self._h = None

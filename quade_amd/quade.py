@@ -11,11 +11,11 @@ Several batches are in flight (one per pinned slot, round-robin over the configu
 are consumed in batch order, so every output file keeps the input order (chunk order, then read
 order) exactly as the reference's sequential loop does.
 
-Multi-process mode (one process per GPU): started under `python -m torch.distributed.run
---nproc-per-node N -m quade_amd.quade -c Conf.txt`, rank r takes the chunks c with c mod N == r on GPU
-LOCAL_RANK, writes each chunk's records to that chunk's own part files, the counter vectors are
-summed with one all-reduce (RCCL over xGMI; nothing else is exchanged), and rank 0 concatenates the
-parts in chunk order (gzip members) and writes the report.
+Multi-process mode (one process per GPU): started by `python -m quade_amd.launch -n N -c Conf.txt`
+(or any launcher exporting RANK / WORLD_SIZE / LOCAL_RANK), rank r takes the chunks c with
+c mod N == r on GPU r, writes each chunk's records to that chunk's own part files, the counter vectors
+are summed with one all-reduce made by libquade_hip.so (RCCL over xGMI; nothing else is exchanged),
+and rank 0 concatenates the parts in chunk order (gzip members) and writes the report.
 """
 from __future__ import annotations
 
@@ -105,19 +105,15 @@ class Quade(object):
         """Main function of the script (src/Quade.py:169-193)"""
         start_time = time()
         cf = self.cf
-        self.rank, self.world, dist = 0, 1, None
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-            # one process per GPU: torch.distributed only carries the final count reduce
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(os.environ.get("QUADE_DIST_BACKEND", "nccl"))
-            self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        from . import dist
+        from .fastq_writer import io_threads
+        self.rank, self.world, local = dist.world_from_env()
+        self.token = dist.run_token()
         devices = cf.devices
-        if self.world > 1:
-            devices = [os.environ.get("QUADE_DEVICE", os.environ.get("LOCAL_RANK", "0"))]
+        if self.world > 1:  # one process per GPU
+            devices = [os.environ.get("QUADE_DEVICE", str(local))]
         elif devices == ["all"]:
             devices = list(range(hb.device_count()))
-        from .fastq_writer import io_threads
         io_threads(cf.io_threads)  # size of the library's gzip pool (before its first use)
         plan = cf.plan()
         # chunk workers (host threads) each drive their own contexts: a context is single-threaded
@@ -138,35 +134,31 @@ class Quade(object):
             self.engine_groups.append(group)
         self.plan, self.layout = plan, self.engines[0].layout
 
+        # the communicator comes up before any chunk is touched: rank 0 clears stale part files, then
+        # publishes the id the other ranks wait for, so nobody writes parts before the clean-up
+        self.comm = self._make_comm(devices)
+
         print("Start parsing files: {} chunks to be parsed".format(len(cf.seq_R1)))
         if cf.idx2:
             self.double_index_parser()
         else:
             self.simple_index_parser()
 
-        counts = None
-        for eng in self.engines:
-            c = eng.counts()
-            counts = c if counts is None else counts + c
         with _timed("drain gzip + close"):
-            Sample.FLUSH_ALL()
+            Sample.FLUSH_ALL()  # every rank's files are complete before its counters join the sum
+        counts = self._reduce_counts(devices)
         for eng in self.engines:
             eng.close()
         self.engines = []
-        from .dist import allreduce_counts, merge_parts
-        if self.world > 1:
-            import torch
-            dev = torch.device("cuda", int(devices[0])) if dist.get_backend() == "nccl" else None
-            counts = allreduce_counts(counts, dist, device=dev)  # the only exchange of the run
-            dist.barrier()  # every rank's part files are closed
         if self.parts and self.rank == 0:
+            # the all-reduce has returned here: every rank had closed its part files before it joined
             with _timed("merge chunk parts"):
-                merge_parts(self.outdir, n_chunks)
+                dist.merge_parts(self.outdir, n_chunks)
         if self.world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
             if self.rank != 0:
                 return 0
+            import shutil
+            shutil.rmtree(dist.rendezvous_dir(self.outdir, self.token), ignore_errors=True)
         Sample.SET_COUNTS(counts)
 
         print("Generate_a csv report")
@@ -179,6 +171,38 @@ class Quade(object):
             for k, v in sorted(_T.items(), key=lambda kv: -kv[1]):
                 print("\t[profile] {:<28s} {:8.3f} s".format(k, v))
         return 0
+
+    def _make_comm(self, devices):
+        """RCCL communicator of the count reduce (include/quade_hip.h qd_comm_*): one rank per process
+        when a launcher started several, else one rank per local device when several are configured."""
+        from . import dist
+        if self.rank == 0:
+            dist.clean_parts(self.outdir)
+        if self.world > 1:
+            if os.environ.get("QUADE_DIST_TRANSPORT") == "files":  # rehearsal: ranks sharing one GPU
+                dist.exchange_bytes(self.outdir, self.token, self.rank, "start", make=lambda: b"go")
+                return None
+            uid = dist.exchange_bytes(self.outdir, self.token, self.rank, "rccl_id", make=hb.comm_unique_id)
+            return hb.Comm.rank(self.engine_groups[0][0], self.world, self.rank, uid)
+        first = self.engine_groups[0]
+        if len(first) > 1 and self.workers == 1 and len(set(e.device_id for e in first)) == len(first):
+            return hb.Comm.local(first)
+        return None
+
+    def _reduce_counts(self, devices):
+        """The only exchange of the run: the counter vectors of every context, summed."""
+        from . import dist
+        if self.comm is not None:
+            counts = self.comm.reduce_counts()  # RCCL all-reduce over xGMI
+            self.comm.close()
+            return counts
+        counts = None  # contexts that share a device (or chunk-worker groups): summed here
+        for eng in self.engines:
+            c = eng.counts()
+            counts = c if counts is None else counts + c
+        if self.world > 1:
+            counts = dist.sum_counts_through_files(self.outdir, self.token, self.rank, self.world, counts)
+        return counts
 
     def double_index_parser(self):
         cf = self.cf

@@ -7,7 +7,7 @@ import sys
 import numpy as np
 
 from quade_amd import synth
-from quade_amd.dist import allreduce_counts, shard_range
+from quade_amd.dist import shard_range
 from tests import helpers as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,9 +23,40 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_allreduce_counts_single_process_is_identity():
-    c = np.array([5, 3, 1, 1, 2, 1], dtype=np.uint64)
-    assert (allreduce_counts(c) == c).all()
+def test_file_rendezvous_between_two_processes(tmp_path):
+    """What the command line's ranks use to find each other without PyTorch: rank 0 publishes bytes
+    (the RCCL unique id on the GPU box) under the output directory, the other rank waits for them; the
+    rehearsal transport hands counter vectors to rank 0 the same way."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from quade_amd import dist
+rank, world, local = dist.world_from_env()
+tok = dist.run_token()
+got = dist.exchange_bytes(sys.argv[1], tok, rank, "id", make=lambda: bytes(range(128)))
+assert got == bytes(range(128))
+tot = dist.sum_counts_through_files(sys.argv[1], tok, rank, world, np.array([rank + 1, 10, 20], dtype=np.uint64))
+print(rank, local, tot.tolist())
+''' % ROOT
+    procs = []
+    for r in (1, 0):  # rank 1 first: it has to wait
+        env = dict(os.environ, QUADE_RANK=str(r), QUADE_WORLD="2", QUADE_RUN_TOKEN="t1")
+        procs.append(subprocess.Popen([sys.executable, "-c", code, str(tmp_path)], env=env, stdout=subprocess.PIPE, text=True))
+    outs = sorted(p.communicate(timeout=120)[0].strip() for p in procs)
+    assert all(p.returncode == 0 for p in procs)
+    assert outs == ["0 0 [3, 20, 40]", "1 1 [2, 10, 20]"]
+    from quade_amd import dist
+    assert dist.world_from_env({"RANK": "3", "WORLD_SIZE": "8", "LOCAL_RANK": "3"}) == (3, 8, 3)
+    assert dist.world_from_env({}) == (0, 1, 0)
+    assert dist.run_token({"QUADE_RUN_TOKEN": "abc"}) == "abc"
+
+
+def test_stale_parts_are_removed_before_a_run(tmp_path):
+    from quade_amd.dist import clean_parts, part_dir
+    os.makedirs(part_dir(str(tmp_path), 3))
+    open(os.path.join(part_dir(str(tmp_path), 3), "Undetermined_R1.fastq.gz"), "wb").close()
+    clean_parts(str(tmp_path))
+    assert os.listdir(tmp_path) == []
 
 
 def test_two_rank_gloo_count_reduce(tmp_path):

@@ -204,9 +204,10 @@ def test_generated_dataset_matches_oracle(tmp_path, name):
 
 
 def test_two_process_chunk_sharded_run_matches_oracle(tmp_path):
-    """One process per GPU (rehearsed here with 2 ranks on GPU 0 and the gloo backend): chunks are
-    sharded over the ranks, counts all-reduced, parts merged in chunk order -> same bytes as the
-    oracle's sequential run."""
+    """One process per GPU, started by quade_amd.launch (rehearsed here with 2 ranks on GPU 0, which
+    RCCL refuses, so the counter vectors travel through the rendezvous files): chunks are sharded
+    over the ranks, counts summed, parts merged in chunk order -> same bytes as the oracle's
+    sequential run.  Stale part files of an earlier run must not leak into the outputs."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -221,15 +222,57 @@ def test_two_process_chunk_sharded_run_matches_oracle(tmp_path):
     ref_dir, my_dir = tmp_path / "ref", tmp_path / "mine"
     ref_dir.mkdir(); my_dir.mkdir()
     sset, _ = qo.run_quade(str(conf), outdir=str(ref_dir))
-    env = dict(os.environ, PYTHONPATH=root, QUADE_DIST_BACKEND="gloo", QUADE_DEVICE="0", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", "-m", "quade_amd.quade", "-c", str(conf)]
+    stale = my_dir / ".quade_parts" / "chunk000001"
+    os.makedirs(stale)
+    with gzip.open(stale / "Undetermined_R1.fastq.gz", "wb") as fh:
+        fh.write(b"@stale\nA\n+\nI\n")
+    env = dict(os.environ, PYTHONPATH=root, QUADE_DIST_TRANSPORT="files", QUADE_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "quade_amd.launch", "-n", "2", "-c", str(conf)]
     r = subprocess.run(cmd, cwd=str(my_dir), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert not os.path.exists(my_dir / ".quade_parts")
+    assert not [f for f in os.listdir(my_dir) if f.startswith(".quade_rdv")]
     _compare_dirs(str(my_dir), str(ref_dir))
     with open(my_dir / "Quade_report.csv") as fh:
         assert "Total pair\t%d" % sset.counts()[0] in fh.read()
+
+
+def test_rccl_count_reduce_through_the_c_abi():
+    """qd_comm_create_local / qd_comm_create_rank + qd_reduce_counts with the one rank a 1-GPU box can
+    hold (RCCL wants one rank per device): the library loads librccl, builds the communicator,
+    all-reduces the device-side counters and returns the ABI's vector == the oracle's counts."""
+    import torch
+    from quade_amd import hip_backend as hb
+    from quade_amd import synth
+    from tests import helpers as H
+    w = synth.generate("cfg4", 30011, seed=12)
+    _, _, _, counts_o = H.oracle_on_workload(w)
+    with hb.Engine(0) as eng:
+        eng.set_plan(w.plan)
+        eng.set_barcodes(w.barcode_strings())
+        seq, qual = [t.cuda() for t in w.seq], [t.cuda() for t in w.qual]
+        H.hip_on_device(eng, seq, qual, w.n)
+        comm = hb.Comm.local([eng])
+        assert comm.world == 1
+        assert (comm.reduce_counts() == counts_o).all()
+        assert (comm.reduce_counts() == counts_o).all()  # repeatable, counters untouched
+        comm.close()
+        uid = hb.comm_unique_id()
+        assert len(uid) == 128
+        comm = hb.Comm.rank(eng, 1, 0, uid)
+        H.hip_on_device(eng, seq, qual, w.n)
+        assert (comm.reduce_counts() == 2 * counts_o).all()
+        comm.close()
+        assert (eng.counts() == 2 * counts_o).all()
+        with pytest.raises(hb.QuadeHipError) as ei:  # two ranks on one device: refused before RCCL is asked
+            with hb.Engine(0) as eng2:
+                eng2.set_plan(w.plan)
+                eng2.set_barcodes(w.barcode_strings())
+                hb.Comm.local([eng, eng2])
+        assert "share a device" in str(ei.value)
+    del torch
 
 
 def test_pinned_slots_streaming_vs_oracle():
