@@ -90,6 +90,123 @@ def cpu_baseline(w_cpu_rows, plan, layout, barcodes, hip_codes, sample_pairs):
             "matches_gpu_codes": ok}
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def strong_cpu_baseline(rows, plan, barcodes, hip_codes):
+    """Baseline B of BASELINE.md: oracle/strong_demux.c (SWAR fold / gate, hash table, pthreads) on the
+    same rows, 1 core and all cores; codes compared with the GPU's.  8-byte-row configs only."""
+    import numpy as np
+    from oracle import c_oracle
+    n = rows["seq"][0].shape[0]
+    cores = os.cpu_count() or 1
+    out = {"kind": "port (oracle/strong_demux.c: SWAR fold + gate, open-addressing table, pthreads)", "cpu": cpu_model(),
+           "cores_available": cores, "unit": "read-pairs/s", "sample": "first %d pairs of the same workload" % n}
+    ok = True
+    for label, threads in (("one_core", 1), ("all_cores", cores)):
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            codes, _counts = c_oracle.strong_demux_rows8(plan, barcodes, rows["seq"], rows["qual"], threads)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        ok = ok and bool((codes == hip_codes[:n]).all())
+        out[label] = {"value": n / best, "cores": threads}
+    out["matches_gpu_codes"] = ok
+    return out
+
+
+def streamed_rate(w, lay, batch_pairs=4_000_000, n_slots=3, batches=12):
+    """Rate (2) of SURVEY.md 8(d): packed rows in pinned host memory -> H2D || kernel || D2H through the
+    library's slots (PCIe inclusive; never `value`)."""
+    import numpy as np
+    from quade_amd.hip_backend import Engine
+    B = min(batch_pairs, w.n)
+    host_seq = [t[:B].cpu().numpy() for t in w.seq]
+    host_qual = [t[:B].cpu().numpy() for t in w.qual]
+    exp = w.expected[:B].cpu().numpy().astype(np.uint16)
+    with Engine(0) as eng:
+        eng.set_plan(w.plan)
+        eng.set_barcodes(w.barcode_strings())
+        eng.slots_create(n_slots, B)
+        for s in range(n_slots):
+            v = eng.slot(s)
+            for k in range(lay.n_streams):
+                v["seq"][k][:] = host_seq[k]
+                v["qual"][k][:] = host_qual[k]
+        for s in range(n_slots):  # warm-up
+            eng.submit(s, B)
+        for s in range(n_slots):
+            eng.wait(s)
+        t0 = time.perf_counter()
+        for b in range(batches):
+            s = b % n_slots
+            if b >= n_slots:
+                eng.wait(s)
+            eng.submit(s, B)
+        for s in range(n_slots):
+            eng.wait(s)
+        dt = time.perf_counter() - t0
+        ok = all(bool((eng.slot(s)["codes"][:B] == exp).all()) for s in range(n_slots))
+    h2d = sum(lay.seq_stride[k] + lay.qual_stride[k] for k in range(lay.n_streams))
+    return {"value": B * batches / dt, "unit": "read-pairs/s", "h2d_GBps": B * batches * h2d / dt / 1e9,
+            "d2h_GBps": B * batches * (2 + lay.mol_width) / dt / 1e9, "pcie_gen5_x16_spec_GBps": 63.0,
+            "batch_pairs": B, "slots": n_slots, "batches": batches, "codes_ok": ok,
+            "what": "pinned host rows -> hipMemcpyAsync H2D || kernel || D2H through qd_submit / qd_wait"}
+
+
+def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
+    """Rate (3) of SURVEY.md 8(d): fastq.gz in -> per-sample fastq.gz + report out through the command
+    line driver (quade_amd.quade), at a stated N and gzip level.  Host bound."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    from quade_amd import synth
+    from quade_amd.fastq_writer import io_backend, io_threads
+    work = tempfile.mkdtemp(prefix="quade_bench_e2e_")
+    try:
+        t0 = time.perf_counter()
+        paths, bcs = synth.write_fastq_dataset(work, n_pairs)
+        t_gen = time.perf_counter() - t0
+        conf = os.path.join(work, "conf.txt")
+        synth.write_conf(conf, paths, bcs, n_chunks, gpu="[gpu]\nbatch_pairs : 1000000\ngzip_level : %d\n" % gzip_level)
+        out = os.path.join(work, "out")
+        os.mkdir(out)
+        cwd = os.getcwd()
+        os.chdir(out)
+        try:
+            from quade_amd.quade import Quade
+            from quade_amd.sample import Sample
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):  # the driver prints progress lines; stdout carries one JSON line
+                t0 = time.perf_counter()
+                Quade(conf_file=conf)()
+                dt = time.perf_counter() - t0
+            counts = Sample.COUNTS()[:4]
+        finally:
+            os.chdir(cwd)
+        in_bytes = sum(os.path.getsize(p) for p in paths.values()) * n_chunks
+        out_bytes = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out) if f.endswith(".gz"))
+        n = n_pairs * n_chunks
+        return {"value": n / dt, "unit": "read-pairs/s", "pairs": n, "chunks": n_chunks, "seconds": dt, "gzip_level": gzip_level,
+                "samples": len(bcs), "gzip_backend": io_backend(), "io_threads": io_threads(), "host_cores": os.cpu_count(),
+                "input_gz_bytes": in_bytes, "output_gz_bytes": out_bytes, "counts_total_pass_fail_undetermined": counts,
+                "dataset_seconds": t_gen,
+                "what": "2x150 bp + dual 8 bp index fastq.gz (8 MB gzip members) -> %d-sample pass/fail/Undetermined fastq.gz + "
+                        "report through quade_amd.quade (CLI driver), one process, one GPU" % len(bcs)}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def spawn_ranks(n):
     """python bench.py --gpus N without WORLD_SIZE: one child process per GPU via torch.distributed.run
     (127.0.0.1 rendezvous on a free port).  stdout of the children is captured so that exactly one
@@ -127,6 +244,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the config's single-GPU share)")
     ap.add_argument("--cpu-sample", type=int, default=5_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the streamed / end-to-end rates (N = 1 only)")
+    ap.add_argument("--e2e-pairs", type=int, default=1_000_000)
+    ap.add_argument("--strong-sample", type=int, default=32_000_000)
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
 
@@ -337,16 +457,36 @@ def main():
                        ("external launcher" if "WORLD_SIZE" in os.environ else "single process"),
     }
 
+    if comm is not None:
+        comm.close()
+    eng.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ns = min(args.cpu_sample, n)
         rows = {"seq": [t[:ns].cpu().numpy() for t in w.seq], "qual": [t[:ns].cpu().numpy() for t in w.qual]}
         hip_codes = codes[:ns].cpu().numpy().view(np.uint16)
         out["cpu_baseline"] = cpu_baseline(rows, w.plan, lay, w.barcode_strings(), hip_codes, ns)
+        if all(lay.seq_stride[k] == 8 and lay.qual_stride[k] == 8 for k in range(lay.n_streams)) and not M:
+            nb = min(args.strong_sample, n)
+            rows = {"seq": [t[:nb].cpu().numpy() for t in w.seq], "qual": [t[:nb].cpu().numpy() for t in w.qual]}
+            out["cpu_baseline"]["strong"] = strong_cpu_baseline(rows, w.plan, w.barcode_strings(),
+                                                                codes[:nb].cpu().numpy().view(np.uint16))
+    if rank == 0 and world == 1 and not args.no_extras:
+        # the other two rates of SURVEY.md 8(d); labelled, outside `value`
+        extra = {}
+        try:
+            extra["streamed"] = streamed_rate(w, lay)
+        except Exception as e:  # an extra must not take the headline measurement down with it
+            extra["streamed"] = {"error": repr(e)}
+        del codes, mol
+        w.seq, w.qual = [], []
+        torch.cuda.empty_cache()
+        try:
+            extra["e2e"] = e2e_rate(args.e2e_pairs)
+        except Exception as e:
+            extra["e2e"] = {"error": repr(e)}
+        out["extra"] = extra
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if comm is not None:
-        comm.close()
-    eng.close()
     if dist:
         dist.destroy_process_group()
     if verified is False:

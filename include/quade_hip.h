@@ -301,6 +301,27 @@ int qd_sink_stats(qd_sink* sink, int64_t* members, int64_t* text_bytes, int64_t*
 const char* qd_sink_last_error(const qd_sink* sink);
 int qd_sink_close(qd_sink* sink); /* flush + destroy */
 
+/* ---- host I/O: fastq(.gz) file -> batches of whole records ----------------------------------------------
+ * Replaces pyFastq.FastqReader as the reference uses it (src/Quade.py:203-214: one .next() per record):
+ * a reader owns a thread that reads, inflates ("*.gz": gzip, any number of members; else plain text),
+ * scans and batches the file ahead of the consumer.  A batch holds exactly batch_records kept records
+ * (fewer at the end of the file only); a record whose sequence and quality lengths differ is skipped
+ * inside its own stream, a trailing partial record ends the stream, a last line
+ * without newline counts.  text/rec_off stay valid until qd_text_batch_free(handle). */
+typedef struct qd_reader qd_reader;
+typedef struct qd_text_batch {
+    const uint8_t* text;    /* whole records, 4 lines each */
+    int64_t text_len;
+    const int64_t* rec_off; /* n_records + 1 offsets into text, as qd_fastq_index gives them */
+    int64_t n_records;      /* 0 = end of the stream (handle is NULL then) */
+    void* handle;
+} qd_text_batch;
+int qd_reader_open(const char* path, int64_t batch_records, int32_t queue_depth, qd_reader** out);
+int qd_reader_next(qd_reader* reader, qd_text_batch* out); /* blocks until a batch is ready */
+int qd_text_batch_free(void* handle);
+int qd_reader_close(qd_reader* reader);
+const char* qd_reader_last_error(const qd_reader* reader); /* reader == NULL: why qd_reader_open failed on this thread */
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,3 +45,36 @@ def demux_rows(layout, plan, barcodes, seq, qual, lens=None):
                             C.c_int64(n), arr(seq), arr(qual), arr(lens), P(codes.ctypes.data),
                             P(mol.ctypes.data), P(counts.ctypes.data))
     return codes, (mol if M else None), counts
+
+
+_strong = None
+
+
+def strong_demux_rows8(plan, barcodes, seq, qual, threads=1):
+    """oracle/strong_demux.c (baseline B: tuned, multi-threaded CPU path) on 8-byte rows whose barcode
+    slices are the whole rows.  Returns (codes, counts) or raises ValueError for other shapes."""
+    global _strong
+    if _strong is None:
+        path = os.path.join(_HERE, "libstrong_demux.so")
+        if not os.path.exists(path):
+            import subprocess
+            subprocess.check_call(["make", "-s", "-C", _HERE])
+        _strong = C.CDLL(path)
+        _strong.strong_demux_rows8.restype = C.c_int
+    dual = bool(plan.dual)
+    if (plan.idx1_start, plan.idx1_end) != (0, 8) or (dual and (plan.idx2_start, plan.idx2_end) != (0, 8)) or \
+            any(a.shape[1] != 8 for a in list(seq) + list(qual)):
+        raise ValueError("strong_demux covers the 8-byte-row configs only")
+    n, S = seq[0].shape[0], len(barcodes)
+    blob = np.frombuffer("".join(barcodes).encode("latin-1") + b"\0", dtype=np.uint8)
+    assert all(len(b) == (16 if dual else 8) for b in barcodes)
+    codes = np.empty(n, dtype=np.uint16)
+    counts = np.zeros(2 * S + 4, dtype=np.uint64)
+    P = C.c_void_p
+    arrs = [np.ascontiguousarray(x) for x in (seq[0], qual[0], seq[1] if dual else seq[0], qual[1] if dual else qual[0])]
+    r = _strong.strong_demux_rows8(C.c_int(int(dual)), C.c_int32(plan.min_qual), C.c_int32(S), P(blob.ctypes.data), C.c_int64(n),
+                                   P(arrs[0].ctypes.data), P(arrs[1].ctypes.data), P(arrs[2].ctypes.data),
+                                   P(arrs[3].ctypes.data), C.c_int32(int(threads)), P(codes.ctypes.data), P(counts.ctypes.data))
+    if r != 0:
+        raise ValueError("strong_demux_rows8 refused the shape")
+    return codes, counts

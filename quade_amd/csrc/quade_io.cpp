@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "../../include/quade_hip.h"
+#include "fastq_scan.h"
 
 namespace {
 
@@ -396,15 +397,16 @@ int qd_sink_route(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_t* r
         s->pending_bytes += batch_bytes;
         s->pending_jobs += (int64_t)pieces.size();
     }
-    Latch formatted;
-    formatted.n = (int64_t)pieces.size();
+    // shared: the last job may still be inside done() when this call has already been woken
+    std::shared_ptr<Latch> formatted = std::make_shared<Latch>();
+    formatted->n = (int64_t)pieces.size();
     Pool& P = pool();
     for (const Piece& p : pieces) {
-        P.submit([s, p, tag_rows, tag_stride, tag_len, &formatted] {
+        P.submit([s, p, tag_rows, tag_stride, tag_len, formatted] {
             std::vector<uint8_t> text((size_t)p.text_bytes + 8 * (size_t)p.n_sel + 16), member;
             const int64_t w = qd_format_records(p.text, p.rec_off, p.sel, p.n_sel, tag_rows, tag_stride, tag_len, text.data(),
                                                 (int64_t)text.size());
-            formatted.done();  // nothing of the caller's is touched after this line
+            formatted->done();  // nothing of the caller's is touched after this line
             bool ok = w >= 0;
             if (!ok) sink_error(s, "qd_format_records failed (malformed record text)");
             if (ok && !gzip_member(text.data(), (size_t)w, s->level, member)) {
@@ -423,7 +425,7 @@ int qd_sink_route(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_t* r
             s->cv.notify_all();
         });
     }
-    formatted.wait();
+    formatted->wait();
     return QD_OK;
 }
 
@@ -449,6 +451,330 @@ int qd_sink_close(qd_sink* s) {
     const int r = qd_sink_flush(s);
     delete s;
     return r;
+}
+
+}  // extern "C"
+
+// ---- native chunk reader -----------------------------------------------------------------------------------
+// Replaces what the reference draws from pyFastq.FastqReader one record at a time (src/Quade.py:203-214):
+// a thread per open file reads it, inflates it (gzip members: libdeflate when a whole member fits the
+// window, streaming zlib otherwise -- concatenated members are legal, the reference's own writer appends
+// them, src/FastqWriter.py:83-90), scans the records (a record whose sequence and quality lengths differ
+// is dropped inside its own stream) and hands over batches of exactly `batch_records` kept
+// records (fewer only at the end of the file): one text block + the record offsets.  The consumer gets
+// finished batches; nothing of this runs on its thread.
+namespace {
+
+struct Batch {
+    uint8_t* text = nullptr;
+    int64_t cap = 0, text_len = 0, n = 0;
+    std::vector<int64_t> off;
+    ~Batch() { free(text); }
+};
+
+constexpr size_t READ_BYTES = 8u << 20;     // compressed bytes per read()
+constexpr size_t WINDOW = 32u << 20;        // a member inflated in one piece must lie inside this much input ...
+constexpr size_t MEMBER_OUT = 192u << 20;   // ... and inflate to at most this much
+constexpr size_t PIECE = 4u << 20;          // text handed to the scanner at a time
+
+}  // namespace
+
+struct qd_reader {
+    std::string path, err;
+    int fd = -1;
+    bool gz = false;
+    int64_t B = 0;
+    size_t depth = 2;
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv_room, cv_ready;
+    std::deque<Batch*> ready;
+    bool done = false, stop = false;
+    // producer state
+    Batch* cur = nullptr;
+    int64_t fill = 0, scan = 0;
+    double avg = 400.0;  // bytes per record, learned
+    uint8_t last = '\n';
+};
+
+namespace {
+
+Batch* new_batch(qd_reader* r, int64_t need) {
+    Batch* b = new Batch();
+    b->cap = std::max<int64_t>((int64_t)((double)r->B * r->avg * 1.08) + (int64_t)PIECE, need + (int64_t)PIECE);
+    b->text = (uint8_t*)malloc((size_t)b->cap);
+    b->off.reserve((size_t)std::min<int64_t>(r->B, 1 << 22) + 1);
+    return b;
+}
+
+// blocks while the queue is full; false when the reader is being closed
+bool push_batch(qd_reader* r, Batch* b) {
+    std::unique_lock<std::mutex> g(r->m);
+    r->cv_room.wait(g, [r] { return r->stop || r->ready.size() < r->depth; });
+    if (r->stop) {
+        delete b;
+        return false;
+    }
+    r->ready.push_back(b);
+    r->cv_ready.notify_all();
+    return true;
+}
+
+bool scan_records(qd_reader* r) {
+    for (;;) {
+        Batch* b = r->cur;
+        Rec rec;
+        while (b->n < r->B && next_record(b->text, r->fill, r->scan, rec)) {
+            if (rec.seq_end - rec.seq == rec.qual_end - rec.qual) {
+                b->off.push_back(rec.head);
+                ++b->n;
+            }
+            r->scan = rec.next;
+        }
+        if (b->n < r->B) return true;
+        b->off.push_back(r->scan);
+        b->text_len = r->scan;
+        r->avg = (double)r->scan / (double)b->n;
+        const int64_t left = r->fill - r->scan;
+        Batch* nb = new_batch(r, left);
+        if (left) memcpy(nb->text, b->text + r->scan, (size_t)left);
+        if (!push_batch(r, b)) {
+            delete nb;
+            r->cur = nullptr;
+            return false;
+        }
+        r->cur = nb;
+        r->fill = left;
+        r->scan = 0;
+    }
+}
+
+bool feed(qd_reader* r, const uint8_t* d, size_t len) {
+    while (len) {
+        const size_t piece = std::min(len, PIECE);
+        Batch* b = r->cur;
+        if (r->fill + (int64_t)piece > b->cap) {
+            b->cap = std::max<int64_t>(b->cap * 2, r->fill + (int64_t)piece);
+            b->text = (uint8_t*)realloc(b->text, (size_t)b->cap);
+        }
+        memcpy(b->text + r->fill, d, piece);
+        r->fill += (int64_t)piece;
+        r->last = d[piece - 1];
+        d += piece;
+        len -= piece;
+        if (!scan_records(r)) return false;
+    }
+    return true;
+}
+
+void fail_reader(qd_reader* r, const std::string& msg) {
+    std::lock_guard<std::mutex> g(r->m);
+    if (r->err.empty()) r->err = r->path + ": " + msg;
+}
+
+// compressed input with a sliding window: [pos, fill) of buf is unread
+struct Input {
+    int fd;
+    std::vector<uint8_t> buf;
+    size_t pos = 0, fill = 0;
+    bool eof = false;
+    explicit Input(int f) : fd(f), buf(WINDOW + READ_BYTES) {}
+    size_t avail() const { return fill - pos; }
+    // tops the window up to `want` unread bytes (or the end of the file); false on a read error
+    bool refill(size_t want) {
+        if (avail() >= want || eof) return true;
+        if (pos) {
+            memmove(buf.data(), buf.data() + pos, avail());
+            fill -= pos;
+            pos = 0;
+        }
+        while (fill < want && !eof) {
+            const ssize_t g = read(fd, buf.data() + fill, std::min(READ_BYTES, buf.size() - fill));
+            if (g < 0) {
+                if (errno == EINTR) continue;
+                return false;
+            }
+            if (g == 0) eof = true;
+            fill += (size_t)g;
+        }
+        return true;
+    }
+};
+
+void produce(qd_reader* r) {
+    r->cur = new_batch(r, 0);
+    Input in(r->fd);
+    bool ok = true;
+    if (!r->gz) {
+        while (ok) {
+            if (!in.refill(1)) {
+                fail_reader(r, strerror(errno));
+                break;
+            }
+            if (!in.avail()) break;
+            ok = feed(r, in.buf.data() + in.pos, in.avail());
+            in.pos = in.fill;
+        }
+    } else {
+        LibDeflate& L = deflate_lib();
+        void* dec = L.ok ? L.alloc_decompressor() : nullptr;
+        std::vector<uint8_t> scratch;
+        bool whole_members = dec != nullptr;  // until a member turns out not to fit the window
+        while (ok) {
+            if (!in.refill(whole_members ? WINDOW : 1)) {
+                fail_reader(r, strerror(errno));
+                break;
+            }
+            if (!in.avail()) break;  // clean end: the last member ended where the file ends
+            bool all_zero = in.eof;  // zero padding behind the last member is tolerated
+            for (size_t i = in.pos; all_zero && i < in.fill; ++i) all_zero = in.buf[i] == 0;
+            if (all_zero) break;
+            if (whole_members) {
+                if (scratch.empty()) scratch.resize(MEMBER_OUT);
+                size_t ain = 0, aout = 0;
+                const int res = L.gzip_decompress_ex(dec, in.buf.data() + in.pos, in.avail(), scratch.data(), scratch.size(), &ain, &aout);
+                if (res == 0) {
+                    ok = feed(r, scratch.data(), aout);
+                    in.pos += ain;
+                    continue;
+                }
+                // the member does not end inside the window, or inflates beyond the scratch, or is damaged:
+                // the streaming inflater takes it from its first byte (and reports real damage)
+                whole_members = false;
+            }
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, 15 + 16) != Z_OK) {
+                fail_reader(r, "inflateInit2 failed");
+                break;
+            }
+            if (scratch.size() < PIECE) scratch.resize(PIECE);
+            int zr = Z_OK;
+            while (ok && zr != Z_STREAM_END) {
+                if (!in.avail()) {
+                    if (!in.refill(1)) {
+                        fail_reader(r, strerror(errno));
+                        ok = false;
+                        break;
+                    }
+                    if (!in.avail()) {
+                        fail_reader(r, "compressed file ended before the end-of-stream marker");
+                        ok = false;
+                        break;
+                    }
+                }
+                zs.next_in = in.buf.data() + in.pos;
+                zs.avail_in = (uInt)std::min<size_t>(in.avail(), 1u << 30);
+                zs.next_out = scratch.data();
+                zs.avail_out = (uInt)PIECE;
+                const uInt before = zs.avail_in;
+                zr = inflate(&zs, Z_NO_FLUSH);
+                if (zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) {
+                    fail_reader(r, std::string("not a valid gzip stream (") + (zs.msg ? zs.msg : "zlib error") + ")");
+                    ok = false;
+                    break;
+                }
+                in.pos += before - zs.avail_in;
+                const size_t got = PIECE - zs.avail_out;
+                if (got) ok = feed(r, scratch.data(), got);
+            }
+            inflateEnd(&zs);
+            if (ok && dec && !in.eof) whole_members = true;  // the next member may be a small one again
+        }
+        if (dec) L.free_decompressor(dec);
+    }
+    bool failed;
+    {
+        std::lock_guard<std::mutex> g(r->m);
+        failed = !r->err.empty();
+    }
+    if (ok && !failed && r->cur) {
+        if (r->fill > 0 && r->last != '\n') {  // a last line without newline still ends a record
+            const uint8_t nl = '\n';
+            ok = feed(r, &nl, 1);
+        }
+        if (ok && r->cur) {  // the (possibly empty) last batch
+            Batch* b = r->cur;
+            r->cur = nullptr;
+            b->off.push_back(r->scan);
+            b->text_len = r->scan;
+            if (b->n > 0)
+                push_batch(r, b);
+            else
+                delete b;
+        }
+    }
+    delete r->cur;
+    r->cur = nullptr;
+    std::lock_guard<std::mutex> g(r->m);
+    r->done = true;
+    r->cv_ready.notify_all();
+}
+
+thread_local std::string g_reader_open_error;
+
+}  // namespace
+
+extern "C" {
+
+const char* qd_reader_last_error(const qd_reader* r) { return r ? r->err.c_str() : g_reader_open_error.c_str(); }
+
+int qd_reader_open(const char* path, int64_t batch_records, int32_t queue_depth, qd_reader** out) {
+    if (!path || batch_records < 1 || queue_depth < 1 || queue_depth > 64 || !out) return QD_ERR_INVALID;
+    *out = nullptr;
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) {
+        g_reader_open_error = std::string(path) + ": " + strerror(errno);
+        return QD_ERR_FORMAT;
+    }
+    qd_reader* r = new qd_reader();
+    r->path = path;
+    r->fd = fd;
+    const size_t n = strlen(path);
+    r->gz = n >= 3 && (path[n - 3] == '.') && (path[n - 2] == 'g' || path[n - 2] == 'G') && (path[n - 1] == 'z' || path[n - 1] == 'Z');
+    r->B = batch_records;
+    r->depth = (size_t)queue_depth;
+    r->th = std::thread(produce, r);
+    *out = r;
+    return QD_OK;
+}
+
+int qd_reader_next(qd_reader* r, qd_text_batch* out) {
+    if (!r || !out) return QD_ERR_INVALID;
+    memset(out, 0, sizeof *out);
+    std::unique_lock<std::mutex> g(r->m);
+    r->cv_ready.wait(g, [r] { return !r->ready.empty() || r->done; });
+    if (!r->ready.empty()) {
+        Batch* b = r->ready.front();
+        r->ready.pop_front();
+        r->cv_room.notify_all();
+        out->text = b->text;
+        out->text_len = b->text_len;
+        out->rec_off = b->off.data();
+        out->n_records = b->n;
+        out->handle = b;
+        return QD_OK;
+    }
+    return r->err.empty() ? QD_OK : QD_ERR_FORMAT;  // end of the stream: n_records == 0, handle NULL
+}
+
+int qd_text_batch_free(void* handle) {
+    delete static_cast<Batch*>(handle);
+    return QD_OK;
+}
+
+int qd_reader_close(qd_reader* r) {
+    if (!r) return QD_OK;
+    {
+        std::lock_guard<std::mutex> g(r->m);
+        r->stop = true;
+        r->cv_room.notify_all();
+    }
+    if (r->th.joinable()) r->th.join();
+    for (Batch* b : r->ready) delete b;
+    close(r->fd);
+    delete r;
+    return QD_OK;
 }
 
 }  // extern "C"

@@ -383,9 +383,49 @@ __device__ __forceinline__ u64 take8(const u64 (&w)[NW], int start) {
     return sh ? (a >> sh) | (b << (64 - sh)) : a;
 }
 
+// ---- row shapes ------------------------------------------------------------------------------------------
+// DynShape: every slice position is a kernel argument (any plan inside the fast envelope).
+// StaticShape: the layout "barcode at the start of the window, molecular index right behind it", the same in
+// both index reads, baked in at compile time: slices become fixed byte shuffles, masks become constants and
+// the scalar registers that carried them are free again (the generic code keeps ~100 scalars live and
+// spills them through VGPR lanes: a third of its vector instructions were v_readlane / v_writelane).
+struct DynShape {
+    static __device__ __forceinline__ void apply(DemuxParams&) {}
+    static bool matches(const DemuxParams&) { return true; }
+};
+template <int IW, int MW>  // dual index, IW-base barcodes at columns 0..IW-1, MW-base molecular index behind them
+struct StaticShape {
+    static constexpr int STRIDE = (IW + MW + 1) & ~1, QSTRIDE = (IW + 1) & ~1;
+    static __device__ __forceinline__ void apply(DemuxParams& p) {
+        p.n_streams = 2;
+        p.K = 2 * IW;
+        p.M = 2 * MW;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            p.seq_stride[k] = STRIDE;
+            p.qual_stride[k] = QSTRIDE;
+            p.idx_off[k] = 0;
+            p.idx_w[k] = IW;
+            p.mol_off[k] = MW ? IW : 0;
+            p.mol_w[k] = MW;
+            p.idx_mask[k] = IW >= 8 ? ~0ull : ((1ull << (8 * IW)) - 1);
+            p.mol_mask[k] = MW >= 8 ? ~0ull : ((1ull << (8 * MW)) - 1);
+        }
+    }
+    static bool matches(const DemuxParams& p) {
+        if (p.n_streams != 2 || p.K != 2 * IW || p.M != 2 * MW) return false;
+        for (int k = 0; k < 2; ++k)
+            if (p.seq_stride[k] != STRIDE || p.qual_stride[k] != QSTRIDE || p.idx_off[k] != 0 || p.idx_w[k] != IW ||
+                p.mol_w[k] != MW || (MW && p.mol_off[k] != IW))
+                return false;
+        return true;
+    }
+};
+
 // ---- Rows8: all strides 8 ------------------------------------------------------------------------
-template <int BLOCK_, bool DUAL, int UNITS>
+template <int BLOCK_, bool DUAL, int UNITS, class SH = DynShape>
 struct Rows8 {
+    typedef SH Shape;
     static constexpr int BLOCK = BLOCK_;
     static constexpr bool PREFETCH = QD_FAST_PREFETCH != 0;   // 64 B per lane per tile: double-buffer
     static constexpr bool GUARD_LAST = false;                 // aligned loads never leave the rows
@@ -478,8 +518,9 @@ struct Rows8 {
 };
 
 // ---- RowsX: even strides <= 16, NL1/NL2 = 16-byte loads per lane for the seq rows of read 1 / 2 -----
-template <int BLOCK_, int NL1, int NL2, bool DUAL, int UNITS>
+template <int BLOCK_, int NL1, int NL2, bool DUAL, int UNITS, class SH = DynShape>
 struct RowsX {
+    typedef SH Shape;
     static constexpr int BLOCK = BLOCK_;
     static constexpr bool PREFETCH = QD_FAST_PREFETCH != 0 && (NL1 + (DUAL ? NL2 : 0)) <= QD_FASTX_PREFETCH_MAXNL;
     static constexpr bool GUARD_LAST = true;  // a 16-byte load of the batch's last rows could pass the array end
@@ -566,7 +607,9 @@ struct RowsX {
 #define QD_FAST_BOUNDS __launch_bounds__(OPS::BLOCK)
 #endif
 template <class OPS>
-__global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p) {
+__global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
+    DemuxParams p = p_in;
+    OPS::Shape::apply(p);  // a static shape overwrites the layout fields with its constants
     constexpr int BLOCK = OPS::BLOCK;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint32_t* slots = reinterpret_cast<uint32_t*>(lds_raw);
@@ -801,8 +844,9 @@ struct Span {                                        // rows of stride S, 256 pa
     static constexpr int STAGE = NL * 1024;          // LDS bytes of the stage
 };
 
-template <int BLOCK_, int S1, int S2, bool DUAL>
+template <int BLOCK_, int S1, int S2, bool DUAL, class SH = DynShape>
 struct WaveX {
+    typedef SH Shape;
     static constexpr int BLOCK = BLOCK_;
     static constexpr int NL1 = Span<S1>::NL, NL2 = DUAL ? Span<S2>::NL : 1;
     static constexpr int STAGE1 = Span<S1>::STAGE, STAGE2 = DUAL ? Span<S2>::STAGE : 0;
@@ -927,7 +971,9 @@ __device__ __forceinline__ void flush_codes(const DemuxParams& p, const uint32_t
 }
 
 template <class OPS>
-__global__ __launch_bounds__(OPS::BLOCK) void demux_wave(const DemuxParams p) {
+__global__ __launch_bounds__(OPS::BLOCK) void demux_wave(const DemuxParams p_in) {
+    DemuxParams p = p_in;
+    OPS::Shape::apply(p);
     constexpr int BLOCK = OPS::BLOCK, WAVES = BLOCK / 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint32_t* slots = reinterpret_cast<uint32_t*>(lds_raw);
@@ -1069,6 +1115,10 @@ hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, in
     const bool all8 = p.seq_stride[0] == 8 && p.qual_stride[0] == 8 &&
                       (!dual || (p.seq_stride[1] == 8 && p.qual_stride[1] == 8));
     if (all8) {
+#ifndef QD_NO_STATIC_SHAPES
+        if (StaticShape<8, 0>::matches(p))  // dual 8 + 8 bp index, no molecular index (BASELINE cfg3, cfg5)
+            return launch_fast_t<Rows8<BLOCK, true, U, StaticShape<8, 0>>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
+#endif
         if (dual) return launch_fast_t<Rows8<BLOCK, true, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
 #ifndef QD_SWEEP_BUILD  // tuning builds instantiate the dual 8+8 kernel only
         return launch_fast_t<Rows8<BLOCK, false, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
@@ -1080,6 +1130,10 @@ hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, in
         if (nl1 == 1) return launch_fast_t<RowsX<BLOCK, 1, 1, false, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
         return launch_fast_t<RowsX<BLOCK, 2, 1, false, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
     }
+#ifndef QD_NO_STATIC_SHAPES
+    if (StaticShape<8, 6>::matches(p))  // 8 bp barcode + 6 bp molecular index per index read (BASELINE cfg4)
+        return launch_fast_t<RowsX<BLOCK, 2, 2, true, U, StaticShape<8, 6>>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
+#endif
     if (nl1 == 1 && nl2 == 1) return launch_fast_t<RowsX<BLOCK, 1, 1, true, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
     if (nl1 == 1 && nl2 == 2) return launch_fast_t<RowsX<BLOCK, 1, 2, true, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
     if (nl1 == 2 && nl2 == 1) return launch_fast_t<RowsX<BLOCK, 2, 1, true, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
@@ -1108,9 +1162,9 @@ struct WaveShape {
     bool dual;
 };
 // instantiated row shapes of the wave kernel: seq strides (quality strides are 8)
-template <int BLOCK, int S1, int S2, bool DUAL>
+template <int BLOCK, int S1, int S2, bool DUAL, class SH = DynShape>
 hipError_t launch_wave_t(const DemuxParams& p, QdKernelCache& cache, unsigned grid, size_t lds, hipStream_t st) {
-    auto k = demux_wave<WaveX<BLOCK, S1, S2, DUAL>>;
+    auto k = demux_wave<WaveX<BLOCK, S1, S2, DUAL, SH>>;
     QdKernelCache::Entry& ce = cache.entries[reinterpret_cast<const void*>(k)];
     if (!ce.attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1124,6 +1178,10 @@ template <int BLOCK>
 hipError_t launch_wave_b(const DemuxParams& p, QdKernelCache& cache, unsigned grid, size_t lds, hipStream_t st) {
     const bool dual = p.n_streams > 1;
     const int s1 = p.seq_stride[0], s2 = dual ? p.seq_stride[1] : 0;
+#ifndef QD_NO_STATIC_SHAPES
+    if (StaticShape<8, 6>::matches(p)) return launch_wave_t<BLOCK, 14, 14, true, StaticShape<8, 6>>(p, cache, grid, lds, st);
+    if (StaticShape<8, 0>::matches(p)) return launch_wave_t<BLOCK, 8, 8, true, StaticShape<8, 0>>(p, cache, grid, lds, st);
+#endif
 #define QD_WAVE_CASE(A, B, D) \
     if (s1 == A && s2 == B && dual == D) return launch_wave_t<BLOCK, A, (B ? B : 8), D>(p, cache, grid, lds, st);
     QD_WAVE_CASE(14, 14, true)

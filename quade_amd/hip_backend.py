@@ -46,6 +46,11 @@ class qd_rows(C.Structure):
     _fields_ = [("seq", C.c_void_p * 2), ("qual", C.c_void_p * 2), ("len", C.c_void_p * 2)]
 
 
+class qd_text_batch(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("text_len", C.c_int64), ("rec_off", C.c_void_p), ("n_records", C.c_int64),
+                ("handle", C.c_void_p)]
+
+
 class qd_slot_buffers(C.Structure):
     _fields_ = [("seq", C.c_void_p * 2), ("qual", C.c_void_p * 2), ("len", C.c_void_p * 2),
                 ("codes", C.c_void_p), ("mol", C.c_void_p), ("max_pairs", C.c_int64),
@@ -98,6 +103,11 @@ SYMBOLS = [
     ("qd_reduce_counts", C.c_int, [_P, _P, C.c_int32]),
     ("qd_comm_destroy", C.c_int, [_P]),
     ("qd_comm_last_error", C.c_char_p, []),
+    ("qd_reader_open", C.c_int, [C.c_char_p, C.c_int64, C.c_int32, C.POINTER(_P)]),
+    ("qd_reader_next", C.c_int, [_P, C.POINTER(qd_text_batch)]),
+    ("qd_text_batch_free", C.c_int, [_P]),
+    ("qd_reader_close", C.c_int, [_P]),
+    ("qd_reader_last_error", C.c_char_p, [_P]),
     ("qd_io_threads", C.c_int, [C.c_int32]),
     ("qd_io_backend", C.c_int, []),
     ("qd_sink_create", C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -239,7 +239,7 @@ class Quade(object):
             try:
                 for i, c in enumerate(mine):
                     while nxt < len(mine) and nxt <= i + lookahead:
-                        opened.append([FastqStream(f) for f in chunks[mine[nxt]]])
+                        opened.append([FastqStream(f, self.cf.batch_pairs) for f in chunks[mine[nxt]]])
                         nxt += 1
                     one_chunk(c, opened.popleft(), self.engine_groups[0])
             finally:
@@ -262,7 +262,7 @@ class Quade(object):
                 except queue.Empty:
                     return
                 try:
-                    one_chunk(c, [FastqStream(f) for f in chunks[c]], engines)
+                    one_chunk(c, [FastqStream(f, self.cf.batch_pairs) for f in chunks[c]], engines)
                 except BaseException as e:  # surfaced in the main thread
                     errors.append(e)
 
@@ -311,15 +311,15 @@ class Quade(object):
                     with _timed("wait router"):
                         job.result()
                 v = eng.slot(slot)
-                with _timed("scan insert reads"):
-                    r1_text, r1_off = r1s.take(B)
-                    r2_text, r2_off = r2s.take(B)
-                counts = [r1_off.size - 1, r2_off.size - 1]
+                with _timed("wait insert reads"):  # inflated, scanned and batched by the readers' own threads
+                    r1b = r1s.take()
+                    r2b = r2s.take()
+                counts = [r1b.n, r2b.n]
                 full = True
                 n_short = []
                 with _timed("pack index reads"):
                     for k, st in enumerate(idx):
-                        nk, fk, sk = st.take_packed(B, L, k, v["seq"][k], v["qual"][k], v["len"][k], v["short"][k])
+                        nk, fk, sk = st.take_packed(L, k, v["seq"][k], v["qual"][k], v["len"][k], v["short"][k])
                         counts.append(nk)
                         n_short.append(sk)
                         full = full and fk
@@ -330,7 +330,7 @@ class Quade(object):
                     eng.submit_ragged(slot, n, n_short)
                 else:
                     eng.submit(slot, n, False)
-                pending.append((eng, slot, n, has_len, r1_text, r1_off, r2_text, r2_off))
+                pending.append((eng, slot, n, has_len, r1b, r2b))
                 while len(pending) > 1:  # the newest batch stays with the device while we read on
                     hand_over(pending.popleft())
                 b += 1
@@ -347,13 +347,15 @@ class Quade(object):
     def _route(self, item, writers=None):
         """Router thread: name tags from the slot's rows and the device's molecular bytes, then
         Sample.FINDER (format + queue for gzip) -- host memory only, no context calls."""
-        eng, slot, n, has_len, r1_text, r1_off, r2_text, r2_off = item
+        eng, slot, n, has_len, r1b, r2b = item
         v = eng.slot(slot)
         with _timed("build tags"):
             tags, tag_len = hb.build_tags(self.layout, self.plan, n, v["seq"], v["len"] if has_len else None,
                                           mol_rows=v["mol"])
         with _timed("route + format + queue gzip"):
-            Sample.FINDER(Batch(n, r1_text, r1_off, r2_text, r2_off, v["codes"], tags, tag_len), writers)
+            Sample.FINDER(Batch(n, r1b.text, r1b.off, r2b.text, r2b.off, v["codes"], tags, tag_len), writers)
+        r1b.release()  # the sink has consumed the text: the blocks go back to the allocator now
+        r2b.release()
 
 
 def main(argv=None):

@@ -161,3 +161,115 @@ def generate(name, n, seed=None, device="cpu", chunk=8_000_000, layout=None):
             qual[k][a:a + m].fill_(0xFF)
             qual[k][a:a + m, 0:8] = q[:, 8 * k:8 * k + 8]
     return Workload(name, n, seq, qual, expected, bcs_cpu, plan, lay)
+
+
+# ---- synthetic fastq files (end-to-end runs: bench.py extra.e2e, tools/e2e_bench.py, tests) ---------------
+def _digits(vals, width):
+    """non-negative ints -> uint8 [n, width] of zero-padded ASCII digits"""
+    import numpy as np
+    out = np.empty((len(vals), width), np.uint8)
+    v = np.asarray(vals, dtype=np.int64).copy()
+    for j in range(width - 1, -1, -1):
+        out[:, j] = 48 + v % 10
+        v //= 10
+    return out
+
+
+def _gzip_members(data, path, level, member_bytes, threads):
+    """Writes `data` as a gzip file: one member (member_bytes = 0) or members of member_bytes of text,
+    compressed in parallel (zlib releases the GIL) -- what parallel compressors produce."""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(chunk):
+        co = zlib.compressobj(level, zlib.DEFLATED, 31)
+        return co.compress(chunk) + co.flush()
+
+    view = memoryview(data).cast("B")
+    if not member_bytes:
+        parts = [one(view)]
+    else:
+        cuts = list(range(0, len(view), member_bytes))
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            parts = list(ex.map(one, [view[a:a + member_bytes] for a in cuts]))
+    with open(path, "wb") as fh:
+        for p in parts:
+            fh.write(p)
+
+
+def write_fastq_dataset(workdir, n_pairs, n_samples=96, insert_len=150, seed=5, gz_level=1, member_bytes=8 << 20,
+                        threads=8, plain=False):
+    """2 x insert_len bp insert reads + dual 8 bp index reads of n_pairs pairs as four fastq(.gz) files
+    under workdir (SURVEY.md 8d recipe: 90 % carry a sample's barcode pair, 10 % get an N; qualities
+    phred 30..40, 15 % of the index reads with one position at phred 2..24).  Names are identical across
+    the four streams.  Returns (paths dict, barcode pairs)."""
+    import os
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    bcs = set()
+    while len(bcs) < n_samples:
+        bcs.add(("".join(rng.choice(list("ACGT"), 8)), "".join(rng.choice(list("ACGT"), 8))))
+    bcs = sorted(bcs)
+    bc_arr = np.array([[np.frombuffer((a + b).encode(), dtype=np.uint8)] for a, b in bcs]).reshape(n_samples, 16)
+    n = n_pairs
+
+    def raw(m):  # m uniform bytes straight from the bit generator (bounded integers are 10x slower)
+        return rng.bit_generator.random_raw((m + 7) // 8).view(np.uint8)[:m]
+
+    lut_acgt = acgt[np.arange(256) & 3]
+    lut_phred = (63 + (np.arange(256) * 11 >> 8)).astype(np.uint8)  # '?'..'I' = phred 30..40
+
+    idx = np.arange(n)
+    head = np.concatenate([np.frombuffer(b"@SIM:1:FC:1:", np.uint8)[None, :].repeat(n, 0), _digits(idx % 97, 4),
+                           np.full((n, 1), ord(":"), np.uint8), _digits(idx, 9), np.full((n, 1), ord(":"), np.uint8),
+                           _digits((idx * 3) % 1000000007, 10)], axis=1)
+    which = rng.integers(0, n_samples, n)
+    key = bc_arr[which].copy()
+    mut = rng.integers(0, 10, n) == 0
+    key[mut, rng.integers(0, 16, int(mut.sum()))] = ord("N")
+    paths = {}
+    for name, L, suffix in (("seq_R1", insert_len, b" 1:N:0:"), ("seq_R2", insert_len, b" 2:N:0:"),
+                            ("index_R1", 8, b" 1:N:0:"), ("index_R2", 8, b" 2:N:0:")):
+        if L == insert_len:
+            seq = None  # drawn straight into the record matrix below
+        else:
+            k = 0 if name == "index_R1" else 1
+            seq = key[:, 8 * k:8 * k + 8]
+        # one fixed-width record per row, filled column block by column block
+        W = head.shape[1] + len(suffix) + 1 + L + 3 + L + 1
+        rec = np.empty((n, W), np.uint8)
+        o = head.shape[1]
+        rec[:, :o] = head
+        rec[:, o:o + len(suffix)] = np.frombuffer(suffix, np.uint8)
+        o += len(suffix)
+        rec[:, o] = 10
+        rec[:, o + 1:o + 1 + L] = lut_acgt[raw(n * L).reshape(n, L)] if seq is None else seq
+        o += 1 + L
+        rec[:, o:o + 3] = np.frombuffer(b"\n+\n", np.uint8)
+        rec[:, o + 3:o + 3 + L] = lut_phred[raw(n * L).reshape(n, L)]  # phred 30..40
+        if L != insert_len:  # 15 % of the index reads: one barcode position at phred 2..24
+            bad = np.flatnonzero(rng.integers(0, 100, n) < 15)
+            rec[bad, o + 3 + rng.integers(0, L, bad.size)] = (rng.integers(2, 25, bad.size) + 33).astype(np.uint8)
+        rec[:, o + 3 + L] = 10
+        data = rec.reshape(-1).data  # buffer, no copy
+
+        p = os.path.join(workdir, name + (".fastq" if plain else ".fastq.gz"))
+        if plain:
+            with open(p, "wb") as fh:
+                fh.write(data)
+        else:
+            _gzip_members(data, p, gz_level, member_bytes, threads)
+        paths[name] = p
+    return paths, bcs
+
+
+def write_conf(path, paths, bcs, n_chunks=1, minimal_qual=25, gpu=""):
+    """A Quade configuration file for write_fastq_dataset's files (each listed n_chunks times)."""
+    with open(path, "w") as fh:
+        fh.write("[quality]\nminimal_qual : %d\n[fastq]\n" % minimal_qual +
+                 "".join("%s : %s\n" % (k, "  ".join([v] * n_chunks)) for k, v in paths.items()) +
+                 "[index]\nindex2 : True\nmolecular1 : False\nmolecular2 : False\nindex1_start : 1\nindex1_end : 8\n"
+                 "index2_start : 1\nindex2_end : 8\n[output]\nwrite_pass : True\nwrite_fail : True\nwrite_undetermined : True\n" +
+                 gpu + "".join("[sample%d]\nname : S%d\nindex1_seq : %s\nindex2_seq : %s\n" % (i + 1, i + 1, a, b)
+                               for i, (a, b) in enumerate(bcs)))

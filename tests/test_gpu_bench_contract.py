@@ -20,7 +20,8 @@ def _run(args, env=None, launcher=None):
 
 
 def test_single_gpu_line():
-    j = _run(["--steps", "3", "--warmup", "1", "--pairs", "3000000", "--cpu-sample", "20000"])
+    j = _run(["--steps", "3", "--warmup", "1", "--pairs", "3000000", "--cpu-sample", "20000", "--e2e-pairs", "30000",
+              "--strong-sample", "1000000"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k
@@ -38,6 +39,16 @@ def test_single_gpu_line():
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["matches_gpu_codes"] is True
     assert abs(j["value"] - 3000000 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
+    # the three rates of SURVEY.md 8(d) and both CPU baselines travel in the same line
+    assert r["traffic_source"] is None or "replayed" in r["traffic_source"]
+    st = c["strong"]
+    assert st["matches_gpu_codes"] is True and st["one_core"]["cores"] == 1 and st["one_core"]["value"] > 0
+    assert st["all_cores"]["cores"] == st["cores_available"] >= 1 and st["cpu"]
+    sm = j["extra"]["streamed"]
+    assert sm["codes_ok"] is True and sm["value"] > 0 and sm["h2d_GBps"] > 0 and sm["batches"] >= 10
+    e = j["extra"]["e2e"]
+    assert e["pairs"] == 30000 and e["value"] > 0 and e["gzip_level"] == 1 and e["gzip_backend"] in ("libdeflate", "zlib")
+    assert e["counts_total_pass_fail_undetermined"][0] == 30000 == sum(e["counts_total_pass_fail_undetermined"][1:])
 
 
 def test_two_ranks_self_spawned():

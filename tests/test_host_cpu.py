@@ -115,29 +115,88 @@ def test_fastq_index_and_pack_match_oracle_reader(tmp_path):
     assert out == exp
 
 
-def test_streaming_take_is_piecewise_consistent(tmp_path):
+def _names_of(stream):
+    names, sizes = [], []
+    while True:
+        b = stream.take()
+        for r in range(b.n):
+            names.append(bytes(b.text[b.off[r] + 1:b.off[r + 1]]).split()[0].decode())
+        sizes.append(b.n)
+        b.release()
+        if b.n < stream.batch_records:
+            break
+    stream.close()
+    return names, sizes
+
+
+def test_native_reader_batches_equal_oracle_reader(tmp_path):
+    """The native reader (thread per file: inflate, scan, batch) against the oracle's FastqReader: same
+    kept records in the same order for one gzip member, many members (libdeflate path), plain text,
+    CRLF line ends and a missing final newline; batches hold exactly the requested number of records."""
     from quade_amd.fastq_reader import FastqStream
     rng = np.random.default_rng(3)
     recs = []
     for i in range(1000):
         L = int(rng.integers(0, 40))
         s = "".join(rng.choice(list("ACGTN"), L))
-        q = "".join(chr(int(c)) for c in rng.integers(33, 74, L if i % 97 else L + 1))
+        q = "".join(chr(int(c)) for c in rng.integers(33, 74, L if i % 97 else L + 1))  # every 97th: malformed
         recs.append("@r%d extra\n%s\n+\n%s\n" % (i, s, q))
-    p = tmp_path / "s.fastq.gz"
+    blob = "".join(recs).encode()
+    variants = {}
+    p = tmp_path / "one.fastq.gz"
     with gzip.open(p, "wb") as fh:
-        fh.write("".join(recs).encode())
-    expect = list(qo.FastqReader(str(p)))
-    st = FastqStream(str(p), read_bytes=1000)
-    names = []
-    while True:
-        text, off = st.take(64)
-        for r in range(off.size - 1):
-            names.append(bytes(text[off[r] + 1:off[r + 1]]).split()[0].decode())
-        if off.size - 1 < 64:
-            break
-    assert names == [r.name for r in expect]
+        fh.write(blob)
+    variants["one member"] = p
+    p = tmp_path / "many.fastq.gz"
+    with open(p, "wb") as fh:  # members cut in the middle of records
+        for a in range(0, len(blob), 3001):
+            fh.write(gzip.compress(blob[a:a + 3001]))
+        fh.write(b"\0" * 37)  # zero padding behind the last member is tolerated (as by gzip itself)
+    variants["many members"] = p
+    p = tmp_path / "plain.fastq"
+    p.write_bytes(blob)
+    variants["plain"] = p
+    p = tmp_path / "crlf.fastq.gz"
+    with gzip.open(p, "wb") as fh:
+        fh.write(blob.replace(b"\n", b"\r\n")[:-2])  # CRLF, and no newline at the very end
+    variants["crlf"] = p
+    for label, path in variants.items():
+        expect = [r.name for r in qo.FastqReader(str(path))]
+        assert len(expect) >= 985
+        for B in (64, 1, 5000):
+            names, sizes = _names_of(FastqStream(str(path), B, queue_depth=2))
+            assert names == expect, (label, B)
+            assert all(n == B for n in sizes[:-1]) and 0 <= sizes[-1] <= B, (label, B)
+    # empty file, file without a complete record, unreadable file, damaged gzip
+    (tmp_path / "empty.fastq.gz").write_bytes(b"")
+    assert _names_of(FastqStream(str(tmp_path / "empty.fastq.gz"), 10)) == ([], [0])
+    (tmp_path / "partial.fastq").write_bytes(b"@r1\nACGT\n+")
+    assert _names_of(FastqStream(str(tmp_path / "partial.fastq"), 10)) == ([], [0])
+    with pytest.raises(IOError):
+        FastqStream(str(tmp_path / "missing.fastq.gz"), 10)
+    with open(variants["one member"], "rb") as fh:
+        good = fh.read()
+    (tmp_path / "cut.fastq.gz").write_bytes(good[:len(good) // 2])
+    with pytest.raises(IOError) as ei:
+        _names_of(FastqStream(str(tmp_path / "cut.fastq.gz"), 100))
+    assert "ended before the end-of-stream marker" in str(ei.value)
+    (tmp_path / "junk.fastq.gz").write_bytes(b"this is not gzip at all" * 10)
+    with pytest.raises(IOError):
+        _names_of(FastqStream(str(tmp_path / "junk.fastq.gz"), 100))
 
+
+def test_native_reader_closes_with_batches_pending(tmp_path):
+    """close() while the producer is blocked on a full queue (the driver stops at the first exhausted
+    stream, src/Quade.py:223-224: the other files are abandoned mid-way)."""
+    from quade_amd.fastq_reader import FastqStream
+    p = tmp_path / "big.fastq"
+    p.write_bytes(b"".join(b"@r%d\nACGT\n+\nIIII\n" % i for i in range(20000)))
+    st = FastqStream(str(p), 10, queue_depth=1)
+    b = st.take()
+    assert b.n == 10
+    st.close()
+    assert bytes(b.text[:4]) == b"@r0\n"  # a batch outlives its reader
+    b.release()
 
 def test_bundled_index_files_pack(bundled_dir):
     """skip-malformed inside its own stream: C1_R1 has one bad record (seq 100 nt, qual 101)"""

@@ -61,3 +61,19 @@ def test_c_oracle_on_reference_finder_vectors(finder_vectors):
         codes, _, counts = c_oracle.demux_rows(lay, plan, [b for _, b in vs["samples"]], [sr], [qr], [lr])
         assert codes.tolist() == vs["codes"]
         assert counts.tolist() == vs["counts"]
+
+
+def test_strong_cpu_baseline_equals_python_oracle():
+    """oracle/strong_demux.c (baseline B of BASELINE.md, timed by bench.py's cpu_baseline leg) gives the
+    pinned oracle's codes and counters on the 8-byte-row configs, on 1 thread and on several."""
+    import pytest
+    for name in ["cfg2", "cfg3", "cfg5"]:
+        w = synth.generate(name, 6001, seed=5)
+        codes_p, _, _, counts_p = H.oracle_on_workload(w)
+        for threads in (1, 3):
+            codes_s, counts_s = c_oracle.strong_demux_rows8(w.plan, w.barcode_strings(), [t.numpy() for t in w.seq],
+                                                            [t.numpy() for t in w.qual], threads)
+            assert (codes_s == codes_p).all() and (counts_s == counts_p).all(), (name, threads)
+    w = synth.generate("cfg4", 100, seed=5)
+    with pytest.raises(ValueError):
+        c_oracle.strong_demux_rows8(w.plan, w.barcode_strings(), [t.numpy() for t in w.seq], [t.numpy() for t in w.qual])
