@@ -28,7 +28,9 @@ struct Slot {
     uint8_t* d_base = nullptr;
     qd_slot_buffers h{};        // host views
     qd_slot_buffers d{};        // device views (same struct, device pointers)
-    uint32_t* h_short = nullptr;  // pinned: the two streams' lists merged (unique, ascending), 2 * short_cap
+    // pinned + device: the two streams' lists merged (unique, ascending; 2 * short_cap indices), then the
+    // listed reads' lengths per stream (2 * short_cap bytes each): all the fixup kernel needs of the len rows
+    uint32_t* h_short = nullptr;
     uint32_t* d_short = nullptr;
     bool busy = false;
 };
@@ -341,8 +343,9 @@ int pick_kernel(const qd_ctx* c, bool dense_len) {
 }
 
 // n_short < 0: no exception list (len rows, if any, apply to every pair -> generic kernel)
+// short_len: the listed reads' lengths, compact ([k][i] for short_idx[i]); NULL: rows->len holds them per pair
 int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* mol, hipStream_t st,
-           int64_t n_short = -1, const uint32_t* short_idx = nullptr) {
+           int64_t n_short = -1, const uint32_t* short_idx = nullptr, const uint8_t* const* short_len = nullptr) {
     const qd_layout& L = c->lay;
     bool has_len = false;
     for (int k = 0; k < L.n_streams; ++k) {
@@ -351,6 +354,7 @@ int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* 
             return fail(c, QD_ERR_INVALID, "row buffers must be 16-byte aligned");
         has_len = has_len || rows->len[k] != nullptr;
     }
+    if (short_len) has_len = true;
     if (!codes || !aligned16(codes)) return fail(c, QD_ERR_INVALID, "codes buffer NULL or not 16-byte aligned");
     if (L.mol_width > 0 && (!mol || !aligned16(mol)))
         return fail(c, QD_ERR_INVALID, "mol buffer NULL or not 16-byte aligned");
@@ -396,6 +400,7 @@ int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* 
     if (kind != K_GENERIC && sparse && n_short > 0) {
         p.exc = short_idx;
         p.n_exc = (uint32_t)n_short;
+        for (int k = 0; k < L.n_streams; ++k) p.exc_len[k] = short_len ? short_len[k] : nullptr;
         e = qd_launch_fixup(p, st);
         if (e != hipSuccess) return fail(c, QD_ERR_HIP, std::string("fixup launch: ") + hipGetErrorString(e));
     }
@@ -681,8 +686,8 @@ int qd_slots_create(qd_ctx* c, int32_t n_slots, int64_t max_pairs) {
         HIPCHK(c, hipMalloc((void**)&s.d_base, bytes));
         carve(s.h, s.h_base, c->lay, max_pairs);
         carve(s.d, s.d_base, c->lay, max_pairs);
-        HIPCHK(c, hipHostMalloc((void**)&s.h_short, (size_t)s.h.short_cap * 8, hipHostMallocDefault));
-        HIPCHK(c, hipMalloc((void**)&s.d_short, (size_t)s.h.short_cap * 8));
+        HIPCHK(c, hipHostMalloc((void**)&s.h_short, (size_t)s.h.short_cap * 12, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc((void**)&s.d_short, (size_t)s.h.short_cap * 12));
     }
     return QD_OK;
 }
@@ -746,20 +751,32 @@ static int submit_impl(qd_ctx* c, int32_t slot, int64_t n, int32_t has_len, cons
             if (m == 0) has_len = 0;  // every short read lies beyond the batch
         }
     }
+    const bool listed = has_len && m > 0 && m <= n / 2;  // a listed minority: only their lengths travel, not the len rows
     qd_rows rows{};
     for (int k = 0; k < L.n_streams; ++k) {
         HIPCHK(c, hipMemcpyAsync(s.d.seq[k], s.h.seq[k], (size_t)n * L.seq_stride[k], hipMemcpyHostToDevice, s.stream));
         HIPCHK(c, hipMemcpyAsync(s.d.qual[k], s.h.qual[k], (size_t)n * L.qual_stride[k], hipMemcpyHostToDevice, s.stream));
         rows.seq[k] = s.d.seq[k];
         rows.qual[k] = s.d.qual[k];
-        if (has_len) {
+        if (has_len && !listed) {
             HIPCHK(c, hipMemcpyAsync(s.d.len[k], s.h.len[k], (size_t)n, hipMemcpyHostToDevice, s.stream));
             rows.len[k] = s.d.len[k];
         }
     }
-    if (has_len && m > 0)
+    const uint8_t* dlen[2] = {nullptr, nullptr};
+    if (listed) {
+        const size_t cap2 = (size_t)s.h.short_cap * 2;
+        uint8_t* hl = reinterpret_cast<uint8_t*>(s.h_short + cap2);
+        uint8_t* dl = reinterpret_cast<uint8_t*>(s.d_short + cap2);
+        for (int k = 0; k < L.n_streams; ++k) {
+            for (int64_t i = 0; i < m; ++i) hl[k * cap2 + (size_t)i] = s.h.len[k][s.h_short[i]];
+            dlen[k] = dl + k * cap2;
+        }
         HIPCHK(c, hipMemcpyAsync(s.d_short, s.h_short, (size_t)m * 4, hipMemcpyHostToDevice, s.stream));
-    const int r = launch(c, n, &rows, s.d.codes, s.d.mol, s.stream, has_len ? m : -1, s.d_short);
+        for (int k = 0; k < L.n_streams; ++k)
+            HIPCHK(c, hipMemcpyAsync(dl + k * cap2, hl + k * cap2, (size_t)m, hipMemcpyHostToDevice, s.stream));
+    }
+    const int r = launch(c, n, &rows, s.d.codes, s.d.mol, s.stream, listed ? m : -1, s.d_short, listed ? dlen : nullptr);
     if (r != QD_OK) return r;
     HIPCHK(c, hipMemcpyAsync(s.h.codes, s.d.codes, (size_t)n * 2, hipMemcpyDeviceToHost, s.stream));
     if (L.mol_width)

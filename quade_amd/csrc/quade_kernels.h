@@ -70,6 +70,7 @@ struct DemuxParams {
     uint32_t quads_per_block, lds_wave_off, lds_wave_bytes;
     // exception pairs (reads shorter than their window) redone by demux_fixup after a fast launch
     const uint32_t* exc;
+    const uint8_t* exc_len[2];  // lengths of the exception pairs' reads, compact (NULL: taken from len[k][pair])
     uint32_t n_exc;
 };
 

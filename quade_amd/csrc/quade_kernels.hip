@@ -314,7 +314,7 @@ __device__ __forceinline__ void store_mol_wave(const DemuxParams& p, uint8_t* st
         if (piece < pieces) {
             const v4u32 v = *reinterpret_cast<const v4u32*>(strip + 16 * piece);
 #if QD_FAST_WT_STORES
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + 16 * piece), "v"(v) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + 16 * piece), "v"(v) : "memory");  // pad: 5.7
 #else
             *reinterpret_cast<v4u32*>(dst + 16 * piece) = v;
 #endif
@@ -703,13 +703,14 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // Writes codes[r] (and mol[r]); returns the routing code.  Counters are the caller's business.
-__device__ __forceinline__ uint32_t generic_pair(const DemuxParams& p, int64_t r) {
+// len0 / len1: the reads' lengths (0x7FFFFFFF = covers its window).
+__device__ __forceinline__ uint32_t generic_pair(const DemuxParams& p, int64_t r, int len0, int len1) {
     // slice lengths after clamping to the read length
     int a[2] = {0, 0}, ma[2] = {0, 0};
     const uint8_t* srow[2] = {nullptr, nullptr};
     const uint8_t* qrow[2] = {nullptr, nullptr};
     for (int k = 0; k < p.n_streams; ++k) {
-        const int len = p.len[k] ? (int)p.len[k][r] : 0x7FFFFFFF;
+        const int len = k ? len1 : len0;
         // columns [start, min(end, len)) -> bytes available
         a[k] = clampi((p.idx_col[k] + p.idx_w[k] < len ? p.idx_col[k] + p.idx_w[k] : len) - p.idx_col[k], 0, p.idx_w[k]);
         ma[k] = clampi((p.mol_col[k] + p.mol_w[k] < len ? p.mol_col[k] + p.mol_w[k] : len) - p.mol_col[k], 0, p.mol_w[k]);
@@ -768,21 +769,42 @@ __device__ __forceinline__ uint32_t generic_pair(const DemuxParams& p, int64_t r
     return code;
 }
 
-__global__ __launch_bounds__(QD_GEN_BLOCK) void demux_generic(const DemuxParams p) {
+// lengths from the per-pair len rows (absent: every read covers its window)
+__device__ __forceinline__ uint32_t generic_pair(const DemuxParams& p, int64_t r) {
+    return generic_pair(p, r, p.len[0] ? (int)p.len[0][r] : 0x7FFFFFFF, p.len[1] ? (int)p.len[1][r] : 0x7FFFFFFF);
+}
+
+// hist_entries = 2S+1 when the per-sample counters fit the workgroup's LDS (dynamic, 4 B each): one LDS
+// add per matched pair and one global add per non-zero counter per workgroup; 0 for sample tables too
+// large for that (global 64-bit adds per pair, as before).
+__global__ __launch_bounds__(QD_GEN_BLOCK) void demux_generic(const DemuxParams p, uint32_t hist_entries) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw);
     const int64_t stride = (int64_t)gridDim.x * QD_GEN_BLOCK;
     const uint32_t S = p.n_samples;
     u64* row = p.partial + (size_t)(blockIdx.x % p.partial_rows) * p.cnt_stride;
+    for (uint32_t i = threadIdx.x; i < hist_entries; i += QD_GEN_BLOCK) hist[i] = 0;
+    if (hist_entries) __syncthreads();
     uint32_t undet = 0;
     for (int64_t r = (int64_t)blockIdx.x * QD_GEN_BLOCK + threadIdx.x; r < p.n; r += stride) {
         const uint32_t code = generic_pair(p, r);
         if (code == QD_CODE_UNDET)
             ++undet;
+        else if (hist_entries)
+            atomicAdd(&hist[code], 1u);
         else
             atomicAdd(reinterpret_cast<unsigned long long*>(&row[code]), 1ull);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) undet += __shfl_xor(undet, o, 64);
     if ((threadIdx.x & 63) == 0 && undet) atomicAdd(reinterpret_cast<unsigned long long*>(&row[2 * S]), (unsigned long long)undet);
+    if (hist_entries) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < hist_entries; i += QD_GEN_BLOCK) {
+            const uint32_t v = hist[i];
+            if (v) atomicAdd(reinterpret_cast<unsigned long long*>(&row[i]), (unsigned long long)v);
+        }
+    }
 }
 
 // Exception pairs after a fast launch on the same stream: the reads of p.exc[0..n_exc) (unique pair
@@ -795,7 +817,8 @@ __global__ __launch_bounds__(QD_GEN_BLOCK) void demux_fixup(const DemuxParams p)
         const int64_t r = p.exc[i];
         if (r >= p.n) continue;
         const uint32_t old = p.codes[r];
-        const uint32_t code = generic_pair(p, r);
+        const uint32_t code = p.exc_len[0] ? generic_pair(p, r, p.exc_len[0][i], p.exc_len[1] ? (int)p.exc_len[1][i] : 0x7FFFFFFF)
+                                           : generic_pair(p, r);
         if (code != old) {
             atomicAdd(reinterpret_cast<unsigned long long*>(&row[old == QD_CODE_UNDET ? 2 * S : old]), ~0ull);  // -1
             atomicAdd(reinterpret_cast<unsigned long long*>(&row[code == QD_CODE_UNDET ? 2 * S : code]), 1ull);
@@ -819,6 +842,8 @@ __global__ __launch_bounds__(QD_GEN_BLOCK) void demux_fixup(const DemuxParams p)
 // Pairs beyond the last full quad (< 512) go through generic_pair() in the last workgroup.
 // ------------------------------------------------------------------------------------------------
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u32_lds __attribute__((ext_vector_type(4), may_alias));  // LDS staging: other lanes read other types
+typedef uint32_t u32_lds __attribute__((may_alias));
 
 __device__ __forceinline__ v4u32 ldv4s(const uint8_t* p) {
 #if QD_FAST_NT
@@ -830,7 +855,9 @@ __device__ __forceinline__ v4u32 ldv4s(const uint8_t* p) {
 
 __device__ __forceinline__ void stv4_wt(uint8_t* p, v4u32 v) {
 #if QD_FAST_WT_STORES
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    // s_nop 1: the store reads its four data registers over several cycles and the compiler does not pad an
+    // asm statement -- without it the next instruction may overwrite them first (cdna_hip_programming.md 5.7)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #else
     *reinterpret_cast<v4u32*>(p) = v;
 #endif
@@ -879,13 +906,18 @@ struct WaveX {
         }
     }
 
-    // registers -> the wave's LDS stage, lane i <-> consecutive 16 B (the repeated half lands behind the span)
+    // registers -> the wave's LDS stage, lane i <-> consecutive 16 B (the repeated half lands behind the span).
+    // The stage is written as 16-byte vectors and read back as dwords by other lanes: the accesses are
+    // typed may_alias and fenced at wavefront scope on both sides, so that the compiler keeps them in
+    // program order (the LDS itself executes a wave's operations in order).
     static __device__ __forceinline__ void stage(const Tile& T, uint8_t* st1, uint8_t* st2, uint32_t lane) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous step's row reads come first
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < NL1; ++j) *reinterpret_cast<v4u32*>(st1 + j * 1024 + lane * 16) = T.s1[j];
+        for (int j = 0; j < NL1; ++j) *reinterpret_cast<v4u32_lds*>(st1 + j * 1024 + lane * 16) = T.s1[j];
         if (DUAL) {
 #pragma unroll
-            for (int j = 0; j < NL2; ++j) *reinterpret_cast<v4u32*>(st2 + j * 1024 + lane * 16) = T.s2[j];
+            for (int j = 0; j < NL2; ++j) *reinterpret_cast<v4u32_lds*>(st2 + j * 1024 + lane * 16) = T.s2[j];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -894,7 +926,7 @@ struct WaveX {
     template <int S>
     static __device__ __forceinline__ void rows_from_stage(u64 (&w)[4], const uint8_t* st, int g, uint32_t lane) {
         // the lane's two rows of group g: 2*S bytes at byte (128 g + 2 lane) * S, dword aligned
-        const uint32_t* d = reinterpret_cast<const uint32_t*>(st) + 32 * S * g + Span<S>::ND * lane;
+        const u32_lds* d = reinterpret_cast<const u32_lds*>(st) + 32 * S * g + Span<S>::ND * lane;
 #pragma unroll
         for (int j = 0; j < 4; ++j) w[j] = 0;
 #pragma unroll
@@ -931,9 +963,9 @@ struct WaveX {
             u64 mlo[2] = {0, 0}, mhi[2] = {0, 0};
             match_two<DUAL>(p, t, k1, k2, m1, m2, q1, q2, c, mlo, mhi);
             undet += (c[0] == QD_CODE_UNDET) + (c[1] == QD_CODE_UNDET);
-            codestage[128 * sj + 64 * g + lane] = c[0] | (c[1] << 16);
+            reinterpret_cast<u32_lds*>(codestage)[128 * sj + 64 * g + lane] = c[0] | (c[1] << 16);
             if (M > 0) {
-                uint32_t* mine = reinterpret_cast<uint32_t*>(strip + (128 * g + 2 * lane) * M);
+                u32_lds* mine = reinterpret_cast<u32_lds*>(strip + (128 * g + 2 * lane) * M);
                 const uint32_t a0[4] = {(uint32_t)mlo[0], (uint32_t)(mlo[0] >> 32), (uint32_t)mhi[0], (uint32_t)(mhi[0] >> 32)};
                 const uint32_t a1[4] = {(uint32_t)mlo[1], (uint32_t)(mlo[1] >> 32), (uint32_t)mhi[1], (uint32_t)(mhi[1] >> 32)};
                 const int nd = M >> 2;  // dwords per pair, wave-uniform (M % 4 == 0 on this kernel)
@@ -953,7 +985,7 @@ struct WaveX {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int piece = r * 64 + (int)lane;
-                if (piece < pieces) stv4_wt(dst + 16 * piece, *reinterpret_cast<const v4u32*>(strip + 16 * piece));
+                if (piece < pieces) stv4_wt(dst + 16 * piece, *reinterpret_cast<const v4u32_lds*>(strip + 16 * piece));
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -965,7 +997,7 @@ struct WaveX {
 __device__ __forceinline__ void flush_codes(const DemuxParams& p, const uint32_t* codestage, int64_t q, uint32_t lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const v4u32 v = *reinterpret_cast<const v4u32*>(reinterpret_cast<const uint8_t*>(codestage) + lane * 16);
+    const v4u32 v = *reinterpret_cast<const v4u32_lds*>(reinterpret_cast<const uint8_t*>(codestage) + lane * 16);
     stv4_wt(reinterpret_cast<uint8_t*>(p.codes) + q * 1024 + lane * 16, v);
     __builtin_amdgcn_wave_barrier();
 }
@@ -1227,7 +1259,8 @@ hipError_t qd_launch_wave(DemuxParams& p, QdKernelCache& cache, int cus, int blo
 }
 
 hipError_t qd_launch_generic(const DemuxParams& p, int grid, hipStream_t st) {
-    hipLaunchKernelGGL(demux_generic, dim3(grid), dim3(QD_GEN_BLOCK), 0, st, p);
+    const uint32_t entries = 2 * p.n_samples + 1 <= 16000 ? 2 * p.n_samples + 1 : 0;  // <= 64 KB of LDS (the default limit)
+    hipLaunchKernelGGL(demux_generic, dim3(grid), dim3(QD_GEN_BLOCK), (size_t)entries * 4, st, p, entries);
     return hipGetLastError();
 }
 
