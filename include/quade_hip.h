@@ -150,8 +150,7 @@ int qd_demux_device_ragged(qd_ctx* ctx, int64_t n_pairs, const qd_rows* rows, ui
                            int64_t n_short, const uint32_t* short_idx_dev, void* stream);
 
 /* Which kernel qd_demux_device would launch for a batch: 1 = fast (LDS table, vector rows),
- * 2 = generic, 3 = wave-span (LDS table, aligned span loads, rows redistributed through LDS).
- * Informational (tests, bench). */
+ * 2 = generic.  Informational (tests, bench). */
 int qd_kernel_kind(const qd_ctx* ctx, int has_len);
 
 /* Tuning / test knobs (no reference counterpart).  Names:
@@ -159,10 +158,7 @@ int qd_kernel_kind(const qd_ctx* ctx, int has_len);
  *   "fast_block"              0 = automatic (default), 256 / 512 / 1024 threads per workgroup
  *   "mol_strips"              1 = stage molecular bytes through LDS for 16-byte stores (default), 0 = off
  *   "force_generic"           1 = always launch the generic kernel
- *   "kernel"                  0 = automatic (default), 1 = fast, 2 = generic, 3 = wave-span (when the row
- *                             shape has an instantiation, else the automatic choice)
- *   "wave_block"              0 = automatic, 256 / 512 threads per workgroup of the wave-span kernel
- *   "wave_quads"              0 = automatic, 1..65536 quads (512 pairs) per wave of the wave-span kernel */
+ *   "kernel"                  0 = automatic (default), 1 = fast (when the plan is eligible), 2 = generic */
 int qd_set_option(qd_ctx* ctx, const char* name, int64_t value);
 
 /* ---- counters: replace the class counters of src/Sample.py:32,144 and feed Sample.REPORT ---------

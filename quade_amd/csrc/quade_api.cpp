@@ -35,7 +35,7 @@ struct Slot {
     bool busy = false;
 };
 
-enum { K_FAST = 1, K_GENERIC = 2, K_WAVE = 3 };
+enum { K_FAST = 1, K_GENERIC = 2 };
 
 }  // namespace
 
@@ -71,10 +71,7 @@ struct qd_ctx {
     int opt_force_generic = 0;
     int opt_block = 0;        // 0 = automatic
     int opt_mol_strips = 1;   // LDS-staged molecular stores in the fast kernel
-    int opt_kernel = 0;       // 0 = automatic, K_FAST / K_GENERIC / K_WAVE
-    bool auto_wave = false;   // automatic choice: the wave-span kernel where it is instantiated (set by measurement)
-    int opt_wave_block = 0, opt_wave_quads = 0;
-    bool wave_ok = false;     // the row shape has a wave-span instantiation that fits LDS
+    int opt_kernel = 0;       // 0 = automatic, K_FAST / K_GENERIC
     QdKernelCache kcache;     // per-context launch memo (attribute set, occupancy)
     // streams this context has work on (its own, its slots', the caller's) with an event recorded after
     // the last operation issued on each: waits are scoped to the context, never the whole device
@@ -266,18 +263,6 @@ int rebuild(qd_ctx* c) {
         ok = ok && mw <= 8 && L.qual_width[k] <= 8;
     }
     c->fast_ok = ok;
-    c->wave_ok = false;
-    if (ok) {
-        DemuxParams wp;
-        memset(&wp, 0, sizeof wp);
-        wp.n_streams = L.n_streams;
-        wp.M = L.mol_width;
-        for (int k = 0; k < 2; ++k) {
-            wp.seq_stride[k] = L.seq_stride[k];
-            wp.qual_stride[k] = L.qual_stride[k];
-        }
-        c->wave_ok = qd_wave_supported(wp) && c->lds_bytes + 4 * qd_wave_lds_per_wave(wp) <= 160 * 1024;
-    }
 
     c->cnt_stride = (uint32_t)((2 * S + 1 + 3) & ~3);
     // one counter row per workgroup (modulo), capped at 64 MiB of rows for very large tables
@@ -337,9 +322,7 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // which kernel takes a batch: dense = per-read lengths apply to (potentially) every pair
 int pick_kernel(const qd_ctx* c, bool dense_len) {
     if (!c->fast_ok || dense_len || c->opt_force_generic || c->opt_kernel == K_GENERIC) return K_GENERIC;
-    if (c->opt_kernel == K_FAST) return K_FAST;
-    if (c->opt_kernel == K_WAVE) return c->wave_ok ? K_WAVE : K_FAST;
-    return c->wave_ok && c->auto_wave ? K_WAVE : K_FAST;
+    return K_FAST;
 }
 
 // n_short < 0: no exception list (len rows, if any, apply to every pair -> generic kernel)
@@ -373,23 +356,7 @@ int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* 
     p.mol = mol;
     p.n = n;
     hipError_t e;
-    if (kind == K_WAVE) {
-        int block = c->opt_wave_block ? c->opt_wave_block : 256;
-        const size_t per_wave = qd_wave_lds_per_wave(p);
-        if (c->lds_bytes + (size_t)(block / 64) * per_wave > 160 * 1024) block = 256;
-        const int waves = block / 64;
-        int quads = c->opt_wave_quads;
-        if (quads <= 0) {
-            // small table image: short-lived workgroups (the grid is oversubscribed and evens itself out);
-            // large image: stage it once per resident workgroup
-            quads = 4;
-            if (c->lds_bytes > 24 * 1024) {
-                const int64_t resident = (int64_t)c->cu * std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)(c->lds_bytes + waves * per_wave));
-                quads = (int)std::max<int64_t>(4, ((n >> 9) + resident * waves - 1) / (resident * waves));
-            }
-        }
-        e = qd_launch_wave(p, c->kcache, c->cu, block, quads, c->lds_bytes, st);
-    } else if (kind == K_FAST) {
+    if (kind == K_FAST) {
         e = qd_launch_fast(p, c->kcache, c->cu, c->opt_wg_per_cu, c->opt_block, c->lds_bytes, c->lds_strip_bytes, st);
     } else {
         const int64_t nb = (n + QD_GEN_BLOCK - 1) / QD_GEN_BLOCK;
@@ -555,18 +522,8 @@ int qd_set_option(qd_ctx* c, const char* name, int64_t value) {
         return QD_OK;
     }
     if (!strcmp(name, "kernel")) {
-        if (value < 0 || value > 3) return fail(c, QD_ERR_INVALID, "kernel must be 0 (automatic), 1 (fast), 2 (generic) or 3 (wave-span)");
+        if (value < 0 || value > 2) return fail(c, QD_ERR_INVALID, "kernel must be 0 (automatic), 1 (fast) or 2 (generic)");
         c->opt_kernel = (int)value;
-        return QD_OK;
-    }
-    if (!strcmp(name, "wave_block")) {
-        if (value != 0 && value != 256 && value != 512) return fail(c, QD_ERR_INVALID, "wave_block must be 0, 256 or 512");
-        c->opt_wave_block = (int)value;
-        return QD_OK;
-    }
-    if (!strcmp(name, "wave_quads")) {
-        if (value < 0 || value > 65536) return fail(c, QD_ERR_INVALID, "wave_quads must be 0..65536");
-        c->opt_wave_quads = (int)value;
         return QD_OK;
     }
     return fail(c, QD_ERR_INVALID, std::string("unknown option ") + name);

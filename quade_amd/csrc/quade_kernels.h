@@ -62,12 +62,10 @@ struct DemuxParams {
     int32_t mol_off[2], mol_w[2];
     int32_t idx_col[2], mol_col[2];  // absolute 0-based column of the slices (length clamping)
     uint64_t idx_mask[2], mol_mask[2];  // (1 << 8*w) - 1
-    // table of EVERY barcode (any length), global memory: generic kernel, tail pairs and exception
-    // pairs of the wave kernel (the LDS table of the fast kernels holds the barcodes of length K only)
+    // table of EVERY barcode (any length), global memory: generic kernel and the exception pairs redone
+    // after a fast launch (the LDS table of the fast kernel holds the barcodes of length K only)
     const uint32_t* gslots;
     uint32_t gmask, gseed;
-    // wave kernel: quads (512 pairs) per workgroup, LDS offset / size of the per-wave areas
-    uint32_t quads_per_block, lds_wave_off, lds_wave_bytes;
     // exception pairs (reads shorter than their window) redone by demux_fixup after a fast launch
     const uint32_t* exc;
     const uint8_t* exc_len[2];  // lengths of the exception pairs' reads, compact (NULL: taken from len[k][pair])
@@ -88,12 +86,6 @@ struct QdKernelCache {
 // wg_per_cu <= 0: automatic (see launch_fast_t); block_override: 0 = automatic, else 256/512/1024
 hipError_t qd_launch_fast(const DemuxParams& p, QdKernelCache& cache, int cus, int wg_per_cu, int block_override,
                           size_t lds_bytes, size_t strip_bytes_per_wave, hipStream_t st);
-// Wave-span kernel (aligned 1 KiB span loads, rows redistributed through LDS, 16-byte output stores).
-// Returns hipErrorNotSupported when no instantiation covers the row shape of `p`.
-bool qd_wave_supported(const DemuxParams& p);
-size_t qd_wave_lds_per_wave(const DemuxParams& p);
-hipError_t qd_launch_wave(DemuxParams& p, QdKernelCache& cache, int cus, int block, int quads_per_wave, size_t table_lds,
-                          hipStream_t st);
 hipError_t qd_launch_generic(const DemuxParams& p, int grid, hipStream_t st);
 hipError_t qd_launch_fixup(const DemuxParams& p, hipStream_t st);
 hipError_t qd_launch_reduce(const uint64_t* partial, uint32_t rows, uint32_t cnt_stride,

@@ -390,11 +390,13 @@ __device__ __forceinline__ u64 take8(const u64 (&w)[NW], int start) {
 // the scalar registers that carried them are free again (the generic code keeps ~100 scalars live and
 // spills them through VGPR lanes: a third of its vector instructions were v_readlane / v_writelane).
 struct DynShape {
+    static constexpr bool STATIC = false;
     static __device__ __forceinline__ void apply(DemuxParams&) {}
     static bool matches(const DemuxParams&) { return true; }
 };
 template <int IW, int MW>  // dual index, IW-base barcodes at columns 0..IW-1, MW-base molecular index behind them
 struct StaticShape {
+    static constexpr bool STATIC = true;
     static constexpr int STRIDE = (IW + MW + 1) & ~1, QSTRIDE = (IW + 1) & ~1;
     static __device__ __forceinline__ void apply(DemuxParams& p) {
         p.n_streams = 2;
@@ -522,7 +524,9 @@ template <int BLOCK_, int NL1, int NL2, bool DUAL, int UNITS, class SH = DynShap
 struct RowsX {
     typedef SH Shape;
     static constexpr int BLOCK = BLOCK_;
-    static constexpr bool PREFETCH = QD_FAST_PREFETCH != 0 && (NL1 + (DUAL ? NL2 : 0)) <= QD_FASTX_PREFETCH_MAXNL;
+    // register double buffering: always with a static shape (its code is lean enough that the next tile's
+    // loads in flight pay: -3 % on cfg4), for dynamic shapes only while the tile is small
+    static constexpr bool PREFETCH = QD_FAST_PREFETCH != 0 && (SH::STATIC || (NL1 + (DUAL ? NL2 : 0)) <= QD_FASTX_PREFETCH_MAXNL);
     static constexpr bool GUARD_LAST = true;  // a 16-byte load of the batch's last rows could pass the array end
     struct Tile {
         u64 s1[UNITS][2 * NL1], q1[UNITS][2], s2[UNITS][2 * NL2], q2[UNITS][2];
@@ -826,256 +830,6 @@ __global__ __launch_bounds__(QD_GEN_BLOCK) void demux_fixup(const DemuxParams p)
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Wave-span kernel.  The unit of work is a QUAD = 512 consecutive pairs owned by ONE wave, done as two
-// STEPS of 256 pairs.  Per step and index stream the wave reads the rows' contiguous span
-// (256 x stride bytes, 16-byte aligned because steps start at multiples of 256 pairs) with whole
-// 1 KiB wave loads -- lane i <-> consecutive 16 B, no load straddles anything, every byte is fetched
-// once -- drops the pieces into its private LDS stage and reads its own rows back from there
-// (lane i owns pairs 128g + 2i, 128g + 2i + 1 of the step, g = 0, 1; the quality rows, stride 8,
-// arrive in exactly that form and stay in registers).  While a step is matched out of LDS the next
-// step's loads are in flight into the one register set: LDS is the second buffer.
-// Outputs leave as 16-byte-per-lane write-through stores only: the quad's 512 codes (1 KiB) and a
-// step's 256 x M molecular bytes are staged per wave in LDS and written lane i <-> consecutive 16 B.
-// A workgroup owns quads [blockIdx * quads_per_block, +quads_per_block), its waves interleaved, so
-// the workgroup as a whole streams one contiguous window of every array.
-// Pairs beyond the last full quad (< 512) go through generic_pair() in the last workgroup.
-// ------------------------------------------------------------------------------------------------
-typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
-typedef unsigned int v4u32_lds __attribute__((ext_vector_type(4), may_alias));  // LDS staging: other lanes read other types
-typedef uint32_t u32_lds __attribute__((may_alias));
-
-__device__ __forceinline__ v4u32 ldv4s(const uint8_t* p) {
-#if QD_FAST_NT
-    return __builtin_nontemporal_load(reinterpret_cast<const v4u32*>(p));
-#else
-    return *reinterpret_cast<const v4u32*>(p);
-#endif
-}
-
-__device__ __forceinline__ void stv4_wt(uint8_t* p, v4u32 v) {
-#if QD_FAST_WT_STORES
-    // s_nop 1: the store reads its four data registers over several cycles and the compiler does not pad an
-    // asm statement -- without it the next instruction may overwrite them first (cdna_hip_programming.md 5.7)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#else
-    *reinterpret_cast<v4u32*>(p) = v;
-#endif
-}
-
-template <int S>
-struct Span {                                        // rows of stride S, 256 pairs
-    static constexpr int NL = (S + 3) / 4;           // 16-byte wave loads (1 KiB each) covering 256 * S bytes
-    static constexpr bool HALF = (S % 4) == 2;       // the last of them covers 512 bytes only
-    static constexpr int ND = S / 2;                 // dwords holding a lane's two consecutive rows
-    static constexpr int STAGE = NL * 1024;          // LDS bytes of the stage
-};
-
-template <int BLOCK_, int S1, int S2, bool DUAL, class SH = DynShape>
-struct WaveX {
-    typedef SH Shape;
-    static constexpr int BLOCK = BLOCK_;
-    static constexpr int NL1 = Span<S1>::NL, NL2 = DUAL ? Span<S2>::NL : 1;
-    static constexpr int STAGE1 = Span<S1>::STAGE, STAGE2 = DUAL ? Span<S2>::STAGE : 0;
-    struct Tile {
-        v4u32 s1[NL1], s2[NL2];
-        U128 q1[2], q2[2];
-    };
-    struct Quals {
-        U128 q1[2], q2[2];
-    };
-
-    template <int S, int NL>
-    static __device__ __forceinline__ void load_span(v4u32 (&v)[NL], const uint8_t* rows, int64_t P0, uint32_t lane) {
-        const uint8_t* base = rows + P0 * S;
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            // the half load: lanes 32..63 repeat lanes 0..31 (same lines, merged in the texture unit)
-            const uint32_t l = (Span<S>::HALF && j == NL - 1) ? (lane & 31u) : lane;
-            v[j] = ldv4s(base + j * 1024 + l * 16);
-        }
-    }
-
-    static __device__ __forceinline__ void load(Tile& T, const DemuxParams& p, int64_t P0, uint32_t lane) {
-        load_span<S1, NL1>(T.s1, p.seq[0], P0, lane);
-        if (DUAL) load_span<S2, NL2>(T.s2, p.seq[1], P0, lane);
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            T.q1[g] = ld16s(p.qual[0] + (P0 + 128 * g) * 8 + lane * 16);
-            if (DUAL) T.q2[g] = ld16s(p.qual[1] + (P0 + 128 * g) * 8 + lane * 16);
-        }
-    }
-
-    // registers -> the wave's LDS stage, lane i <-> consecutive 16 B (the repeated half lands behind the span).
-    // The stage is written as 16-byte vectors and read back as dwords by other lanes: the accesses are
-    // typed may_alias and fenced at wavefront scope on both sides, so that the compiler keeps them in
-    // program order (the LDS itself executes a wave's operations in order).
-    static __device__ __forceinline__ void stage(const Tile& T, uint8_t* st1, uint8_t* st2, uint32_t lane) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous step's row reads come first
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < NL1; ++j) *reinterpret_cast<v4u32_lds*>(st1 + j * 1024 + lane * 16) = T.s1[j];
-        if (DUAL) {
-#pragma unroll
-            for (int j = 0; j < NL2; ++j) *reinterpret_cast<v4u32_lds*>(st2 + j * 1024 + lane * 16) = T.s2[j];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    template <int S>
-    static __device__ __forceinline__ void rows_from_stage(u64 (&w)[4], const uint8_t* st, int g, uint32_t lane) {
-        // the lane's two rows of group g: 2*S bytes at byte (128 g + 2 lane) * S, dword aligned
-        const u32_lds* d = reinterpret_cast<const u32_lds*>(st) + 32 * S * g + Span<S>::ND * lane;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = 0;
-#pragma unroll
-        for (int j = 0; j < Span<S>::ND; ++j) w[j >> 1] |= (u64)d[j] << (32 * (j & 1));
-    }
-
-    // One step (256 pairs from P0) out of the stage: match, codes into the quad's code stage, molecular
-    // bytes through the strip.  sj = 0/1: the step's half of the quad.
-    template <int TAG>
-    static __device__ __forceinline__ uint32_t compute(const Quals& Q, const DemuxParams& p, const LdsTable& t,
-                                                       const uint8_t* st1, const uint8_t* st2, uint32_t* codestage,
-                                                       uint8_t* strip, int sj, int64_t P0, uint32_t lane) {
-        asm volatile("; demux wave step copy %0" ::"i"(TAG));
-        uint32_t undet = 0;
-        const int M = p.M;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            u64 w1[4], w2[4] = {0, 0, 0, 0};
-            rows_from_stage<S1>(w1, st1, g, lane);
-            if (DUAL) rows_from_stage<S2>(w2, st2, g, lane);
-            u64 k1[2], k2[2] = {0, 0}, m1[2], m2[2] = {0, 0}, q1[2], q2[2] = {0, 0};
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {  // h = 0: pair 128g + 2 lane, h = 1: the next one
-                k1[h] = take8(w1, h * S1 + p.idx_off[0]) & p.idx_mask[0];
-                m1[h] = take8(w1, h * S1 + p.mol_off[0]) & p.mol_mask[0];
-                q1[h] = (h ? Q.q1[g].hi : Q.q1[g].lo) | ~p.idx_mask[0];  // beyond the slice: 0xFF
-                if (DUAL) {
-                    k2[h] = take8(w2, h * S2 + p.idx_off[1]) & p.idx_mask[1];
-                    m2[h] = take8(w2, h * S2 + p.mol_off[1]) & p.mol_mask[1];
-                    q2[h] = (h ? Q.q2[g].hi : Q.q2[g].lo) | ~p.idx_mask[1];
-                }
-            }
-            uint32_t c[2];
-            u64 mlo[2] = {0, 0}, mhi[2] = {0, 0};
-            match_two<DUAL>(p, t, k1, k2, m1, m2, q1, q2, c, mlo, mhi);
-            undet += (c[0] == QD_CODE_UNDET) + (c[1] == QD_CODE_UNDET);
-            reinterpret_cast<u32_lds*>(codestage)[128 * sj + 64 * g + lane] = c[0] | (c[1] << 16);
-            if (M > 0) {
-                u32_lds* mine = reinterpret_cast<u32_lds*>(strip + (128 * g + 2 * lane) * M);
-                const uint32_t a0[4] = {(uint32_t)mlo[0], (uint32_t)(mlo[0] >> 32), (uint32_t)mhi[0], (uint32_t)(mhi[0] >> 32)};
-                const uint32_t a1[4] = {(uint32_t)mlo[1], (uint32_t)(mlo[1] >> 32), (uint32_t)mhi[1], (uint32_t)(mhi[1] >> 32)};
-                const int nd = M >> 2;  // dwords per pair, wave-uniform (M % 4 == 0 on this kernel)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < nd) {
-                        mine[j] = a0[j];
-                        mine[nd + j] = a1[j];
-                    }
-            }
-        }
-        if (M > 0) {  // the step's 256 * M molecular bytes, 16 B per lane per store
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            uint8_t* dst = p.mol + P0 * M;
-            const int pieces = 16 * M;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int piece = r * 64 + (int)lane;
-                if (piece < pieces) stv4_wt(dst + 16 * piece, *reinterpret_cast<const v4u32_lds*>(strip + 16 * piece));
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        return undet;
-    }
-};
-
-// the quad's 512 codes: one 16-byte write-through store per lane (1 KiB per wave instruction)
-__device__ __forceinline__ void flush_codes(const DemuxParams& p, const uint32_t* codestage, int64_t q, uint32_t lane) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const v4u32 v = *reinterpret_cast<const v4u32_lds*>(reinterpret_cast<const uint8_t*>(codestage) + lane * 16);
-    stv4_wt(reinterpret_cast<uint8_t*>(p.codes) + q * 1024 + lane * 16, v);
-    __builtin_amdgcn_wave_barrier();
-}
-
-template <class OPS>
-__global__ __launch_bounds__(OPS::BLOCK) void demux_wave(const DemuxParams p_in) {
-    DemuxParams p = p_in;
-    OPS::Shape::apply(p);
-    constexpr int BLOCK = OPS::BLOCK, WAVES = BLOCK / 64;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    uint32_t* slots = reinterpret_cast<uint32_t*>(lds_raw);
-    u64* bk = reinterpret_cast<u64*>(lds_raw + p.lds_bk_off);
-    uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw + p.lds_hist_off);
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keep it scalar
-    const uint32_t S = p.n_samples;
-    uint8_t* area = lds_raw + p.lds_wave_off + wave * p.lds_wave_bytes;
-    uint32_t* codestage = reinterpret_cast<uint32_t*>(area);
-    uint8_t* st1 = area + 1024;
-    uint8_t* st2 = st1 + OPS::STAGE1;
-    uint8_t* strip = st2 + OPS::STAGE2;
-
-    const int64_t NQ = p.n >> 9;
-    const int64_t qbeg = (int64_t)blockIdx.x * p.quads_per_block;
-    const int64_t qend = (qbeg + p.quads_per_block < NQ) ? qbeg + p.quads_per_block : NQ;
-    int64_t q = qbeg + wave;
-    const bool active = q < qend;
-    typename OPS::Tile R;
-    if (active) OPS::load(R, p, q * 512, lane);  // in flight while the table is staged
-
-    for (uint32_t i = tid; i <= p.slot_mask; i += BLOCK) slots[i] = p.slots[i];
-    for (uint32_t i = tid; i < 2 * S; i += BLOCK) bk[i] = p.bk16[i];
-    for (uint32_t i = tid; i < 2 * S + 1; i += BLOCK) hist[i] = 0;
-    __syncthreads();
-    const LdsTable t{slots, bk, hist, nullptr};
-
-    uint32_t undet = 0;
-    if (active) {
-        typename OPS::Quals Q;
-        for (;;) {  // one quad per iteration; "load next, then match current" is straight-line code
-            OPS::stage(R, st1, st2, lane);
-            Q.q1[0] = R.q1[0]; Q.q1[1] = R.q1[1]; Q.q2[0] = R.q2[0]; Q.q2[1] = R.q2[1];
-            OPS::load(R, p, q * 512 + 256, lane);
-            undet += OPS::template compute<0>(Q, p, t, st1, st2, codestage, strip, 0, q * 512, lane);
-            OPS::stage(R, st1, st2, lane);
-            Q.q1[0] = R.q1[0]; Q.q1[1] = R.q1[1]; Q.q2[0] = R.q2[0]; Q.q2[1] = R.q2[1];
-            if (q + WAVES >= qend) {
-                undet += OPS::template compute<1>(Q, p, t, st1, st2, codestage, strip, 1, q * 512 + 256, lane);
-                flush_codes(p, codestage, q, lane);
-                break;
-            }
-            OPS::load(R, p, (q + WAVES) * 512, lane);
-            undet += OPS::template compute<2>(Q, p, t, st1, st2, codestage, strip, 1, q * 512 + 256, lane);
-            flush_codes(p, codestage, q, lane);
-            q += WAVES;
-        }
-    }
-    // pairs behind the last full quad (< 512): byte-granular path, last workgroup
-    if (blockIdx.x == gridDim.x - 1) {
-        for (int64_t r = NQ * 512 + tid; r < p.n; r += BLOCK) {
-            const uint32_t code = generic_pair(p, r);
-            if (code == QD_CODE_UNDET)
-                ++undet;
-            else
-                atomicAdd(&hist[code], 1u);
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) undet += __shfl_xor(undet, o, 64);
-    if (lane == 0 && undet) atomicAdd(&hist[2 * S], undet);
-    __syncthreads();
-    u64* row = p.partial + (size_t)(blockIdx.x % p.partial_rows) * p.cnt_stride;
-    for (uint32_t i = tid; i < 2 * S + 1; i += BLOCK) {
-        const uint32_t v = hist[i];
-        if (v) atomicAdd(reinterpret_cast<unsigned long long*>(&row[i]), (unsigned long long)v);
-    }
-}
-
 // sum the partial rows -> out[ncnt] (out zeroed by the caller).  blockIdx.y = a group of
 // QD_REDUCE_ROWS rows, thread = one counter: row reads are coalesced across the threads and
 // independent across the rows; one 64-bit atomic per (row group, counter).
@@ -1148,7 +902,10 @@ hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, in
                       (!dual || (p.seq_stride[1] == 8 && p.qual_stride[1] == 8));
     if (all8) {
 #ifndef QD_NO_STATIC_SHAPES
-        if (StaticShape<8, 0>::matches(p))  // dual 8 + 8 bp index, no molecular index (BASELINE cfg3, cfg5)
+        // dual 8 + 8 bp index, no molecular index (BASELINE cfg3, cfg5): measured +2.6 % for the large-table
+        // launch form (cfg5), -1.4 % for the small-table one (cfg3) -> used where it pays
+        // (profiles/r02_static_vs_dynamic_shape_cfg{3,5}.txt)
+        if (StaticShape<8, 0>::matches(p) && table_lds > 24 * 1024)
             return launch_fast_t<Rows8<BLOCK, true, U, StaticShape<8, 0>>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
 #endif
         if (dual) return launch_fast_t<Rows8<BLOCK, true, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
@@ -1186,76 +943,6 @@ hipError_t qd_launch_fast(const DemuxParams& p, QdKernelCache& cache, int cus, i
     if (block == 1024) return launch_fast_b<1024>(p, cache, cus, wg_per_cu, lds, lds_bytes, st);
     if (block == 256) return launch_fast_b<256>(p, cache, cus, wg_per_cu, lds, lds_bytes, st);
     return launch_fast_b<512>(p, cache, cus, wg_per_cu, lds, lds_bytes, st);
-}
-
-namespace {
-struct WaveShape {
-    int s1, s2;
-    bool dual;
-};
-// instantiated row shapes of the wave kernel: seq strides (quality strides are 8)
-template <int BLOCK, int S1, int S2, bool DUAL, class SH = DynShape>
-hipError_t launch_wave_t(const DemuxParams& p, QdKernelCache& cache, unsigned grid, size_t lds, hipStream_t st) {
-    auto k = demux_wave<WaveX<BLOCK, S1, S2, DUAL, SH>>;
-    QdKernelCache::Entry& ce = cache.entries[reinterpret_cast<const void*>(k)];
-    if (!ce.attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        ce.attr_set = true;
-    }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), lds, st, p);
-    return hipGetLastError();
-}
-template <int BLOCK>
-hipError_t launch_wave_b(const DemuxParams& p, QdKernelCache& cache, unsigned grid, size_t lds, hipStream_t st) {
-    const bool dual = p.n_streams > 1;
-    const int s1 = p.seq_stride[0], s2 = dual ? p.seq_stride[1] : 0;
-#ifndef QD_NO_STATIC_SHAPES
-    if (StaticShape<8, 6>::matches(p)) return launch_wave_t<BLOCK, 14, 14, true, StaticShape<8, 6>>(p, cache, grid, lds, st);
-    if (StaticShape<8, 0>::matches(p)) return launch_wave_t<BLOCK, 8, 8, true, StaticShape<8, 0>>(p, cache, grid, lds, st);
-#endif
-#define QD_WAVE_CASE(A, B, D) \
-    if (s1 == A && s2 == B && dual == D) return launch_wave_t<BLOCK, A, (B ? B : 8), D>(p, cache, grid, lds, st);
-    QD_WAVE_CASE(14, 14, true)
-    QD_WAVE_CASE(8, 8, true)
-    QD_WAVE_CASE(14, 0, false)
-    QD_WAVE_CASE(8, 0, false)
-#undef QD_WAVE_CASE
-    return hipErrorNotSupported;
-}
-}  // namespace
-
-bool qd_wave_supported(const DemuxParams& p) {
-    const bool dual = p.n_streams > 1;
-    if (p.qual_stride[0] != 8 || (dual && p.qual_stride[1] != 8)) return false;
-    if (p.M != 0 && ((p.M & 3) != 0 || p.M > 16)) return false;
-    const int s1 = p.seq_stride[0], s2 = dual ? p.seq_stride[1] : 0;
-    if (dual) return (s1 == 14 && s2 == 14) || (s1 == 8 && s2 == 8);
-    return s1 == 14 || s1 == 8;
-}
-
-size_t qd_wave_lds_per_wave(const DemuxParams& p) {
-    const bool dual = p.n_streams > 1;
-    auto stage = [](int s) { return (size_t)((s + 3) / 4) * 1024; };
-    return 1024 + stage(p.seq_stride[0]) + (dual ? stage(p.seq_stride[1]) : 0) + (size_t)256 * p.M;
-}
-
-// block: 256 or 512 threads; quads_per_wave: quads (512 pairs) every wave of a workgroup walks
-hipError_t qd_launch_wave(DemuxParams& p, QdKernelCache& cache, int cus, int block, int quads_per_wave, size_t table_lds,
-                          hipStream_t st) {
-    (void)cus;
-    const int waves = block / 64;
-    p.lds_wave_off = (uint32_t)((table_lds + 15) & ~(size_t)15);
-    p.lds_wave_bytes = (uint32_t)qd_wave_lds_per_wave(p);
-    p.quads_per_block = (uint32_t)(waves * quads_per_wave);
-    const size_t lds = p.lds_wave_off + (size_t)waves * p.lds_wave_bytes;
-    const int64_t nq = p.n >> 9;
-    int64_t grid = (nq + p.quads_per_block - 1) / p.quads_per_block;
-    if (grid < 1) grid = 1;  // tail-only batches still need one workgroup
-    if (lds > 160 * 1024) return hipErrorNotSupported;
-    if (block == 256) return launch_wave_b<256>(p, cache, (unsigned)grid, lds, st);
-    if (block == 512) return launch_wave_b<512>(p, cache, (unsigned)grid, lds, st);
-    return hipErrorInvalidValue;
 }
 
 hipError_t qd_launch_generic(const DemuxParams& p, int grid, hipStream_t st) {

@@ -355,7 +355,7 @@ class Engine(object):
         self._chk(self.lib.qd_set_option(self._h, name.encode(), int(value)))
 
     def kernel_kind(self, has_len=False):
-        return {1: "fast", 2: "generic", 3: "wave"}[self.lib.qd_kernel_kind(self._h, int(has_len))]
+        return {1: "fast", 2: "generic"}[self.lib.qd_kernel_kind(self._h, int(has_len))]
 
     # -- device-resident batches (pointers are device addresses, e.g. torch tensor .data_ptr())
     @staticmethod

@@ -232,3 +232,49 @@ def test_arbitrary_bytes_in_reads_and_qualities(engine):
     codes_p, _, _, _ = H2.oracle_on_reads(bcs, make_plan(False, 20, (0, 8)), s, q)
     codes_c, _ = _run_vs_c_oracle(engine, make_plan(False, 20, (0, 8)), bcs, [(reads[0][0][:3000], reads[0][1][:3000])])
     assert (codes_p == codes_c).all()
+
+
+def test_two_threads_two_contexts_different_tables():
+    """include/quade_hip.h: different contexts may be driven concurrently from different threads.  Two
+    host threads, each with its own context, plan and sample table (96 samples -> the oversubscribed
+    launch form, 1536 samples -> the large-table form; one dual 8+8, one with a molecular index), many
+    launches each: the per-context launch memo (dynamic-LDS attribute, occupancy) must not leak from
+    one context into the other, and waits are scoped to the context."""
+    import threading
+    import torch
+    from quade_amd import synth
+    from quade_amd.hip_backend import Engine
+    results, errors = {}, []
+
+    def worker(name, n, rounds):
+        try:
+            w = synth.generate(name, n, seed=11)
+            codes_o, _, mol_o, counts_o = H.oracle_on_workload(w)
+            with Engine(0) as eng:
+                lay = eng.set_plan(w.plan)
+                eng.set_barcodes(w.barcode_strings())
+                M = lay.mol_width
+                seq, qual = [t.cuda() for t in w.seq], [t.cuda() for t in w.qual]
+                codes = torch.empty(n, dtype=torch.int16, device="cuda")
+                mol = torch.empty((n, max(M, 1)), dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()
+                for r in range(rounds):
+                    eng.demux_device(n, [t.data_ptr() for t in seq], [t.data_ptr() for t in qual], codes.data_ptr(),
+                                     mol.data_ptr() if M else None)  # the context's own stream
+                    if r % 7 == 0:
+                        c = eng.counts()  # waits for this context only
+                        assert (c == (r + 1) * counts_o).all(), (name, r)
+                c = eng.counts()
+                got = codes.cpu().numpy().view(np.uint16)
+                results[name] = bool((got == codes_o).all()) and bool((c == rounds * counts_o).all()) and \
+                    (not M or H.mol_rows_to_str(mol.cpu().numpy()) == mol_o)
+        except BaseException as e:  # surfaced below
+            errors.append((name, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=a) for a in (("cfg3", 30011, 60), ("cfg5", 20011, 60), ("cfg4", 25013, 60))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert results == {"cfg3": True, "cfg5": True, "cfg4": True}

@@ -9,9 +9,6 @@ pytestmark = pytest.mark.gpu
 FULL = {"cfg2": 10_000_000, "cfg3": 100_000_000, "cfg4": 62_500_000, "cfg5": 125_000_000}
 
 
-KERNELS = {"fast": 1, "wave": 3}
-
-
 def _run(eng, torch, seq, qual, n, M):
     codes = torch.empty(n, dtype=torch.int16, device="cuda")
     mol = torch.empty((n, max(M, 1)), dtype=torch.uint8, device="cuda")
@@ -23,9 +20,8 @@ def _run(eng, torch, seq, qual, n, M):
     return codes.view(torch.int16).to(torch.int32) & 0xFFFF, mol, eng.counts().astype(np.int64)
 
 
-@pytest.mark.parametrize("kernel", ["fast", "wave"])
 @pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"])
-def test_full_size_properties(name, kernel):
+def test_full_size_properties(name):
     import torch
     from quade_amd import synth
     from quade_amd.hip_backend import Engine
@@ -36,8 +32,7 @@ def test_full_size_properties(name, kernel):
         lay = eng.set_plan(w.plan)
         eng.set_barcodes(w.barcode_strings())
         M = lay.mol_width
-        eng.set_option("kernel", KERNELS[kernel])
-        assert eng.kernel_kind() == kernel
+        assert eng.kernel_kind() == "fast"
         codes, mol, counts = _run(eng, torch, w.seq, w.qual, n, M)
         # 1. every pair against the construction truth
         assert torch.equal(codes, w.expected)

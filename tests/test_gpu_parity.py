@@ -22,7 +22,7 @@ def engine(torch_cuda):
     e.close()
 
 
-KERNEL_OPT = {"auto": 0, "fast": 1, "generic": 2, "wave": 3}
+KERNEL_OPT = {"auto": 0, "fast": 1, "generic": 2}
 
 
 def _check_workload(torch, engine, w, force_generic=False, kernel="fast"):
@@ -47,35 +47,15 @@ def _check_workload(torch, engine, w, force_generic=False, kernel="fast"):
 
 
 @pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"])
-@pytest.mark.parametrize("n", [0, 1, 2, 1023, 4097, 30001])
+@pytest.mark.parametrize("n", [0, 1, 2, 511, 1023, 4097, 30001, 70003])
 def test_fast_kernel_vs_oracle(torch_cuda, engine, name, n):
     from quade_amd import synth
     _check_workload(torch_cuda, engine, synth.generate(name, n, seed=1000 + n))
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"])
-@pytest.mark.parametrize("n", [0, 1, 2, 511, 512, 513, 1023, 4097, 30001, 70003])
-def test_wave_kernel_vs_oracle(torch_cuda, engine, name, n):
-    """The wave-span kernel: whole quads of 512 pairs through the LDS stage, the rest (n mod 512)
-    through the byte-granular tail, several workgroups (70003 pairs = 136 quads)."""
-    from quade_amd import synth
-    _check_workload(torch_cuda, engine, synth.generate(name, n, seed=2000 + n), kernel="wave")
-
-
-@pytest.mark.parametrize("block,quads", [(256, 1), (256, 3), (512, 1), (512, 8)])
-def test_wave_kernel_launch_shapes(torch_cuda, engine, block, quads):
-    from quade_amd import synth
-    for name in ("cfg3", "cfg4"):
-        engine.set_option("wave_block", block)
-        engine.set_option("wave_quads", quads)
-        _check_workload(torch_cuda, engine, synth.generate(name, 40961, seed=block + quads), kernel="wave")
-        engine.reset_counts()
-
-
 @pytest.mark.parametrize("name", ["cfg3", "cfg4"])
-@pytest.mark.parametrize("kernel", ["fast", "wave"])
 @pytest.mark.parametrize("n_short", [0, 1, 57, 20000])
-def test_sparse_short_reads_on_the_fast_kernels(torch_cuda, engine, name, kernel, n_short):
+def test_sparse_short_reads_on_the_fast_kernels(torch_cuda, engine, name, n_short):
     """A batch with a few truncated index reads (Python slice clamping, src/Quade.py:217-218) stays on
     the fast kernels: qd_demux_device_ragged redoes only the listed pairs.  20000 of 30001 listed =
     more than half: the generic kernel takes the batch.  Codes, molecular bytes and counters equal
@@ -123,7 +103,6 @@ def test_sparse_short_reads_on_the_fast_kernels(torch_cuda, engine, name, kernel
     codes_o, _, mol_o, counts_o = H.oracle_on_reads(bcs, w.plan, *reads)
     engine.set_plan(w.plan)
     engine.set_barcodes(bcs)
-    engine.set_option("kernel", KERNEL_OPT[kernel])
     M = lay.mol_width
     d_seq = [torch.from_numpy(a).cuda() for a in seq]
     d_qual = [torch.from_numpy(a).cuda() for a in qual]
@@ -216,7 +195,7 @@ def test_million_pairs_vs_c_oracle_fast_and_generic(torch_cuda, engine):
         engine.set_barcodes(w.barcode_strings())
         seq = [t.cuda() for t in w.seq]
         qual = [t.cuda() for t in w.qual]
-        for kernel in ("fast", "wave", "generic"):
+        for kernel in ("fast", "generic"):
             engine.set_option("kernel", KERNEL_OPT[kernel])
             assert engine.kernel_kind(False) == kernel
             engine.reset_counts()
