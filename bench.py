@@ -106,10 +106,11 @@ def strong_cpu_baseline(rows, plan, barcodes, hip_codes):
     same rows, 1 core and all cores; codes compared with the GPU's.  8-byte-row configs only."""
     import numpy as np
     from oracle import c_oracle
+    from quade_amd.fastq_writer import host_cores
     n = rows["seq"][0].shape[0]
-    cores = os.cpu_count() or 1
+    cores = host_cores()  # affinity mask capped by the cgroup CPU quota (os.cpu_count() is the whole host)
     out = {"kind": "port (oracle/strong_demux.c: SWAR fold + gate, open-addressing table, pthreads)", "cpu": cpu_model(),
-           "cores_available": cores, "unit": "read-pairs/s", "sample": "first %d pairs of the same workload" % n}
+           "cores_available": cores, "host_logical_cpus": os.cpu_count(), "unit": "read-pairs/s", "sample": "first %d pairs of the same workload" % n}
     ok = True
     for label, threads in (("one_core", 1), ("all_cores", cores)):
         best = None
@@ -166,12 +167,10 @@ def streamed_rate(w, lay, batch_pairs=4_000_000, n_slots=3, batches=12):
 def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
     """Rate (3) of SURVEY.md 8(d): fastq.gz in -> per-sample fastq.gz + report out through the command
     line driver (quade_amd.quade), at a stated N and gzip level.  Host bound."""
-    import contextlib
-    import io
     import shutil
     import tempfile
     from quade_amd import synth
-    from quade_amd.fastq_writer import io_backend, io_threads
+    from quade_amd.fastq_writer import host_cores, io_backend, io_threads
     work = tempfile.mkdtemp(prefix="quade_bench_e2e_")
     try:
         t0 = time.perf_counter()
@@ -186,8 +185,7 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
         try:
             from quade_amd.quade import Quade
             from quade_amd.sample import Sample
-            buf = io.StringIO()
-            with contextlib.redirect_stdout(buf):  # the driver prints progress lines; stdout carries one JSON line
+            with stdout_to_stderr():  # the driver and the native sink print progress lines; stdout carries one JSON line
                 t0 = time.perf_counter()
                 Quade(conf_file=conf)()
                 dt = time.perf_counter() - t0
@@ -198,7 +196,7 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
         out_bytes = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out) if f.endswith(".gz"))
         n = n_pairs * n_chunks
         return {"value": n / dt, "unit": "read-pairs/s", "pairs": n, "chunks": n_chunks, "seconds": dt, "gzip_level": gzip_level,
-                "samples": len(bcs), "gzip_backend": io_backend(), "io_threads": io_threads(), "host_cores": os.cpu_count(),
+                "samples": len(bcs), "gzip_backend": io_backend(), "io_threads": io_threads(), "host_cores": host_cores(),
                 "input_gz_bytes": in_bytes, "output_gz_bytes": out_bytes, "counts_total_pass_fail_undetermined": counts,
                 "dataset_seconds": t_gen,
                 "what": "2x150 bp + dual 8 bp index fastq.gz (8 MB gzip members) -> %d-sample pass/fail/Undetermined fastq.gz + "

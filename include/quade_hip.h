@@ -129,7 +129,9 @@ int qd_set_barcodes(qd_ctx* ctx, int32_t n_samples, const uint8_t* barcodes, con
  * codes_dev: n_pairs uint16.  mol_dev: n_pairs*mol_width bytes, may be NULL when mol_width == 0.
  * `stream` is a hipStream_t: NULL is HIP's null (default) stream, ordered with the caller's other
  * default-stream work; QD_STREAM_CONTEXT is the context's own non-blocking stream.  Asynchronous:
- * returns after the launch.  Counters accumulate in the context. */
+ * returns after the launch.  Counters accumulate in the context.  The library never synchronises the
+ * whole device: rows written by work on ANOTHER stream must be complete (or ordered by the caller)
+ * before the launch on `stream` reads them. */
 #define QD_STREAM_CONTEXT ((void*)(intptr_t)-1)
 typedef struct qd_rows {
     const uint8_t* seq[2];
@@ -279,9 +281,10 @@ const char* qd_comm_last_error(void); /* text of the last qd_comm_* / qd_reduce_
  * by one thread at a time; different sinks may be driven concurrently. */
 typedef struct qd_sink qd_sink;
 /* Threads of the I/O pool: n_threads > 0 sets it (before the pool's first use), 0 = one per hardware
- * thread, < 0 = query only.  Returns the size in effect. */
+ * core this process may use (qd_host_cores), < 0 = query only.  Returns the size in effect. */
 int qd_io_threads(int32_t n_threads);
 int qd_io_backend(void); /* 1 = libdeflate, 0 = zlib */
+int qd_host_cores(void); /* cores this process may use: affinity mask capped by the cgroup CPU quota */
 /* names: n_samples sample names in ordinal order (SAMPLE_LIST order, src/Sample.py:153); gzip_level 0..9;
  * write_*: the [output] flags (src/Quade.py:125-129 -> Sample.CLASS_INIT). */
 int qd_sink_create(const char* outdir, int32_t n_samples, const char* const* names, int32_t gzip_level,

@@ -17,6 +17,7 @@
 // No GPU calls here: this file builds with plain g++ (sanitizer tests).
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -162,15 +163,43 @@ class Pool {
 
 std::mutex g_pool_mutex;
 std::unique_ptr<Pool> g_pool;
-int g_pool_threads = 0;  // 0 = one per hardware thread
+int g_pool_threads = 0;  // 0 = one per core this process may use
+
+// cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container
+// on a 256-thread host is often given a few cores' worth of time: 256 runnable gzip threads would
+// then starve the reader threads they are fed by)
+int available_cores() {
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) {
+        const int a = CPU_COUNT(&set);
+        if (a > 0 && (n < 1 || a < n)) n = a;
+    }
+    long long quota = -1, period = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+        char q[64];
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else {
+        FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");  // cgroup v1
+        FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (fq && fp && fscanf(fq, "%lld", &quota) == 1 && fscanf(fp, "%lld", &period) == 1) {
+        } else {
+            quota = -1;
+        }
+        if (fq) fclose(fq);
+        if (fp) fclose(fp);
+    }
+    if (quota > 0 && period > 0) {
+        const int c = (int)((quota + period - 1) / period);
+        if (c > 0 && c < n) n = c;
+    }
+    return n < 1 ? 1 : n;
+}
 
 Pool& pool() {
     std::lock_guard<std::mutex> g(g_pool_mutex);
-    if (!g_pool) {
-        int n = g_pool_threads > 0 ? g_pool_threads : (int)std::thread::hardware_concurrency();
-        if (n < 1) n = 1;
-        g_pool.reset(new Pool(n));
-    }
+    if (!g_pool) g_pool.reset(new Pool(g_pool_threads > 0 ? g_pool_threads : available_cores()));
     return *g_pool;
 }
 
@@ -278,10 +307,10 @@ int qd_io_threads(int32_t n_threads) {
     std::lock_guard<std::mutex> g(g_pool_mutex);
     if (n_threads >= 0 && !g_pool) g_pool_threads = n_threads;
     if (g_pool) return g_pool->size();
-    if (g_pool_threads > 0) return g_pool_threads;
-    const int hw = (int)std::thread::hardware_concurrency();
-    return hw < 1 ? 1 : hw;
+    return g_pool_threads > 0 ? g_pool_threads : available_cores();
 }
+
+int qd_host_cores(void) { return available_cores(); }
 
 int qd_io_backend(void) { return deflate_lib().ok ? 1 : 0; }
 
@@ -457,9 +486,9 @@ int qd_sink_close(qd_sink* s) {
 
 // ---- native chunk reader -----------------------------------------------------------------------------------
 // Replaces what the reference draws from pyFastq.FastqReader one record at a time (src/Quade.py:203-214):
-// a thread per open file reads it, inflates it (gzip members: libdeflate when a whole member fits the
+// two threads per open file: one reads and inflates it (gzip members: libdeflate when a whole member fits the
 // window, streaming zlib otherwise -- concatenated members are legal, the reference's own writer appends
-// them, src/FastqWriter.py:83-90), scans the records (a record whose sequence and quality lengths differ
+// them, src/FastqWriter.py:83-90), the other scans the records (a record whose sequence and quality lengths differ
 // is dropped inside its own stream) and hands over batches of exactly `batch_records` kept
 // records (fewer only at the end of the file): one text block + the record offsets.  The consumer gets
 // finished batches; nothing of this runs on its thread.
@@ -485,9 +514,16 @@ struct qd_reader {
     bool gz = false;
     int64_t B = 0;
     size_t depth = 2;
-    std::thread th;
+    std::thread th, th_inflate;
     std::mutex m;
     std::condition_variable cv_room, cv_ready;
+    // inflater -> batcher hand-off: two scratch blocks
+    std::vector<uint8_t> scratch[2];
+    std::mutex hm;
+    std::condition_variable hcv;
+    int hstate[2] = {0, 0};
+    size_t hlen[2] = {0, 0};
+    bool inflated = false;
     std::deque<Batch*> ready;
     bool done = false, stop = false;
     // producer state
@@ -601,24 +637,40 @@ struct Input {
     }
 };
 
-void produce(qd_reader* r) {
-    r->cur = new_batch(r, 0);
+// ---- the two threads of a reader: inflate -> (two scratch blocks) -> scan + batch ----------------------
+// state[i]: 0 = scratch i is the inflater's, 1 = it holds len[i] bytes of text for the batcher.  Both sides
+// walk the blocks in the same order 0, 1, 0, 1 ...
+bool hand_over(qd_reader* r, int i, size_t len) {
+    std::unique_lock<std::mutex> g(r->hm);
+    r->hlen[i] = len;
+    r->hstate[i] = 1;
+    r->hcv.notify_all();
+    const int nx = i ^ 1;
+    r->hcv.wait(g, [r, nx] { return r->stop || r->hstate[nx] == 0; });
+    return !r->stop;
+}
+
+void inflate_thread(qd_reader* r) {
     Input in(r->fd);
+    int cur = 0;  // scratch block being filled (block 0 starts free)
     bool ok = true;
     if (!r->gz) {
+        r->scratch[0].resize(READ_BYTES);
+        r->scratch[1].resize(READ_BYTES);
         while (ok) {
-            if (!in.refill(1)) {
+            const ssize_t g = read(r->fd, r->scratch[cur].data(), READ_BYTES);
+            if (g < 0) {
+                if (errno == EINTR) continue;
                 fail_reader(r, strerror(errno));
                 break;
             }
-            if (!in.avail()) break;
-            ok = feed(r, in.buf.data() + in.pos, in.avail());
-            in.pos = in.fill;
+            if (g == 0) break;
+            ok = hand_over(r, cur, (size_t)g);
+            cur ^= 1;
         }
     } else {
         LibDeflate& L = deflate_lib();
         void* dec = L.ok ? L.alloc_decompressor() : nullptr;
-        std::vector<uint8_t> scratch;
         bool whole_members = dec != nullptr;  // until a member turns out not to fit the window
         while (ok) {
             if (!in.refill(whole_members ? WINDOW : 1)) {
@@ -630,12 +682,16 @@ void produce(qd_reader* r) {
             for (size_t i = in.pos; all_zero && i < in.fill; ++i) all_zero = in.buf[i] == 0;
             if (all_zero) break;
             if (whole_members) {
-                if (scratch.empty()) scratch.resize(MEMBER_OUT);
+                if (r->scratch[cur].size() < MEMBER_OUT) r->scratch[cur].resize(MEMBER_OUT);
                 size_t ain = 0, aout = 0;
-                const int res = L.gzip_decompress_ex(dec, in.buf.data() + in.pos, in.avail(), scratch.data(), scratch.size(), &ain, &aout);
+                const int res = L.gzip_decompress_ex(dec, in.buf.data() + in.pos, in.avail(), r->scratch[cur].data(),
+                                                     r->scratch[cur].size(), &ain, &aout);
                 if (res == 0) {
-                    ok = feed(r, scratch.data(), aout);
                     in.pos += ain;
+                    if (aout) {
+                        ok = hand_over(r, cur, aout);
+                        cur ^= 1;
+                    }
                     continue;
                 }
                 // the member does not end inside the window, or inflates beyond the scratch, or is damaged:
@@ -648,7 +704,6 @@ void produce(qd_reader* r) {
                 fail_reader(r, "inflateInit2 failed");
                 break;
             }
-            if (scratch.size() < PIECE) scratch.resize(PIECE);
             int zr = Z_OK;
             while (ok && zr != Z_STREAM_END) {
                 if (!in.avail()) {
@@ -663,9 +718,10 @@ void produce(qd_reader* r) {
                         break;
                     }
                 }
+                if (r->scratch[cur].size() < PIECE) r->scratch[cur].resize(PIECE);
                 zs.next_in = in.buf.data() + in.pos;
                 zs.avail_in = (uInt)std::min<size_t>(in.avail(), 1u << 30);
-                zs.next_out = scratch.data();
+                zs.next_out = r->scratch[cur].data();
                 zs.avail_out = (uInt)PIECE;
                 const uInt before = zs.avail_in;
                 zr = inflate(&zs, Z_NO_FLUSH);
@@ -676,12 +732,40 @@ void produce(qd_reader* r) {
                 }
                 in.pos += before - zs.avail_in;
                 const size_t got = PIECE - zs.avail_out;
-                if (got) ok = feed(r, scratch.data(), got);
+                if (got) {
+                    ok = hand_over(r, cur, got);
+                    cur ^= 1;
+                }
             }
             inflateEnd(&zs);
             if (ok && dec && !in.eof) whole_members = true;  // the next member may be a small one again
         }
         if (dec) L.free_decompressor(dec);
+    }
+    std::lock_guard<std::mutex> g(r->hm);
+    r->inflated = true;
+    r->hcv.notify_all();
+}
+
+void batch_thread(qd_reader* r) {
+    r->cur = new_batch(r, 0);
+    bool ok = true;
+    for (int j = 0; ok; j ^= 1) {
+        size_t len;
+        {
+            std::unique_lock<std::mutex> g(r->hm);
+            r->hcv.wait(g, [r, j] { return r->stop || r->hstate[j] == 1 || r->inflated; });
+            if (r->stop) {
+                ok = false;
+                break;
+            }
+            if (r->hstate[j] != 1) break;  // the inflater is done and this block was never filled
+            len = r->hlen[j];
+        }
+        ok = feed(r, r->scratch[j].data(), len);
+        std::lock_guard<std::mutex> g(r->hm);
+        r->hstate[j] = 0;
+        r->hcv.notify_all();
     }
     bool failed;
     {
@@ -734,7 +818,8 @@ int qd_reader_open(const char* path, int64_t batch_records, int32_t queue_depth,
     r->gz = n >= 3 && (path[n - 3] == '.') && (path[n - 2] == 'g' || path[n - 2] == 'G') && (path[n - 1] == 'z' || path[n - 1] == 'Z');
     r->B = batch_records;
     r->depth = (size_t)queue_depth;
-    r->th = std::thread(produce, r);
+    r->th_inflate = std::thread(inflate_thread, r);
+    r->th = std::thread(batch_thread, r);
     *out = r;
     return QD_OK;
 }
@@ -767,9 +852,12 @@ int qd_reader_close(qd_reader* r) {
     if (!r) return QD_OK;
     {
         std::lock_guard<std::mutex> g(r->m);
+        std::lock_guard<std::mutex> h(r->hm);
         r->stop = true;
         r->cv_room.notify_all();
+        r->hcv.notify_all();
     }
+    if (r->th_inflate.joinable()) r->th_inflate.join();
     if (r->th.joinable()) r->th.join();
     for (Batch* b : r->ready) delete b;
     close(r->fd);

@@ -22,9 +22,14 @@ from . import hip_backend as hb
 
 
 def io_threads(n=-1):
-    """Size of the library's I/O pool: n > 0 sets it (before its first use), 0 = one per hardware
-    thread, < 0 = query.  Returns the size in effect."""
+    """Size of the library's I/O pool: n > 0 sets it (before its first use), 0 = one per core this
+    process may use, < 0 = query.  Returns the size in effect."""
     return hb.load_library().qd_io_threads(int(n))
+
+
+def host_cores():
+    """Cores this process may use: the affinity mask capped by the cgroup CPU quota."""
+    return hb.load_library().qd_host_cores()
 
 
 def io_backend():

@@ -110,6 +110,7 @@ SYMBOLS = [
     ("qd_reader_last_error", C.c_char_p, [_P]),
     ("qd_io_threads", C.c_int, [C.c_int32]),
     ("qd_io_backend", C.c_int, []),
+    ("qd_host_cores", C.c_int, []),
     ("qd_sink_create", C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  C.POINTER(_P)]),
     ("qd_sink_set_quiet", C.c_int, [_P, C.c_int32]),

@@ -14,6 +14,7 @@ def _run(eng, torch, seq, qual, n, M):
     mol = torch.empty((n, max(M, 1)), dtype=torch.uint8, device="cuda")
     st = torch.cuda.Stream()
     eng.reset_counts()
+    torch.cuda.synchronize()  # the inputs were produced on torch's default stream; `st` is not ordered behind it
     eng.demux_device(n, [t.data_ptr() for t in seq], [t.data_ptr() for t in qual], codes.data_ptr(),
                      mol.data_ptr() if M else None, stream=st.cuda_stream)
     eng.synchronize()
@@ -75,6 +76,7 @@ def test_more_than_2_31_pairs_in_one_launch():
         eng.set_barcodes(w.barcode_strings())
         codes = torch.empty(n, dtype=torch.int16, device="cuda")
         st = torch.cuda.Stream()
+        torch.cuda.synchronize()
         eng.demux_device(n, [t.data_ptr() for t in w.seq], [t.data_ptr() for t in w.qual], codes.data_ptr(), None,
                          stream=st.cuda_stream)
         eng.synchronize()

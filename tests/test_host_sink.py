@@ -212,13 +212,33 @@ static int run(const char* dir, int seed) {
         if (qd_sink_route(s, n, codes.data(), (const uint8_t*)t.data(), off.data(), (const uint8_t*)t.data(), off.data(), tags.data(), 3, tl.data()) != 0) return 3;
     return qd_sink_close(s);
 }
+static int read_back(const char* path, int64_t want, bool close_early) {
+    qd_reader* rd = nullptr;
+    if (qd_reader_open(path, 777, 2, &rd) != 0) return 20;
+    int64_t n = 0;
+    for (;;) {
+        qd_text_batch b;
+        if (qd_reader_next(rd, &b) != 0) return 21;
+        if (b.n_records == 0) break;
+        if (b.rec_off[b.n_records] != b.text_len || b.text[0] != '@') return 22;
+        n += b.n_records;
+        qd_text_batch_free(b.handle);
+        if (close_early && n > 2000) break;
+    }
+    qd_reader_close(rd);
+    return (close_early || n == want) ? 0 : 23;
+}
 int main(int argc, char** argv) {
     qd_io_threads(6);
-    int r1 = -1, r2 = -1;
+    int r1 = -1, r2 = -1, r3 = -1, r4 = -1;
     std::thread a([&] { r1 = run(argv[1], 0); }), b([&] { r2 = run(argv[2], 1); });
     a.join(); b.join();
-    printf("%d %d\n", r1, r2);
-    return r1 || r2;
+    // the reader's two threads (inflate, scan + batch) and its consumer, on a file the sink just wrote
+    std::string f = std::string(argv[1]) + "/Undetermined_R1.fastq.gz";
+    std::thread c([&] { r3 = read_back(f.c_str(), 6 * 6000, false); }), d([&] { r4 = read_back(f.c_str(), 0, true); });
+    c.join(); d.join();
+    printf("%d %d %d %d\n", r1, r2, r3, r4);
+    return r1 || r2 || r3 || r4;
 }
 ''')
     exe = tmp_path / "drv"

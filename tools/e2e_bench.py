@@ -52,11 +52,11 @@ try:
         Quade(conf_file=conf)()
         dt = time.perf_counter() - t0
         counts = Sample.COUNTS()[:4]
-    from quade_amd.fastq_writer import io_backend, io_threads
+    from quade_amd.fastq_writer import host_cores, io_backend, io_threads
     print(json.dumps({"mode": "end-to-end fastq.gz -> fastq.gz", "chunks": n_chunks, "pairs": n * n_chunks, "seconds": dt,
                       "pairs_per_s": n * n_chunks / dt, "gzip_level": level, "counts": counts, "chunk_workers": workers,
                       "ranks": ranks, "input": "single gzip member" if single else "8 MB gzip members", "gzip_backend": io_backend(),
-                      "io_threads": io_threads(), "host_cores": os.cpu_count(), "dataset_seconds": round(t_gen, 1)}))
+                      "io_threads": io_threads(), "host_cores": host_cores(), "host_logical_cpus": os.cpu_count(), "dataset_seconds": round(t_gen, 1)}))
 finally:
     os.chdir("/")
     shutil.rmtree(work, ignore_errors=True)

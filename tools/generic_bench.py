@@ -16,6 +16,7 @@ for cfg in ["cfg2", "cfg3", "cfg4", "cfg5"]:
     with Engine(0) as e:
         e.set_plan(w.plan); e.set_barcodes(w.barcode_strings())
         st = torch.cuda.Stream()
+        torch.cuda.synchronize()  # inputs were made on the default stream
         for mode in ("force_generic", "with_len_rows"):
             e.set_option("force_generic", 1 if mode == "force_generic" else 0)
             ts = []

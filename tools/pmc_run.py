@@ -27,6 +27,7 @@ with Engine(0) as e:
     if os.environ.get("PMC_FORCE_GENERIC"):
         e.set_option("force_generic", 1)
     st = torch.cuda.Stream()
+    torch.cuda.synchronize()  # inputs were made on the default stream
     for _ in range(launches):
         e.demux_device(n, [t.data_ptr() for t in w.seq], [t.data_ptr() for t in w.qual], codes.data_ptr(),
                        mol.data_ptr() if M else None, stream=st.cuda_stream)

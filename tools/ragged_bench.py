@@ -66,6 +66,7 @@ with Engine(0) as eng:
     short = torch.tensor([123457], dtype=torch.int32, device="cuda")
     codes = torch.empty(B, dtype=torch.int16, device="cuda")
     st = torch.cuda.Stream()
+    torch.cuda.synchronize()  # inputs were made on the default stream
     sp, qp, lp = [t.data_ptr() for t in seq], [t.data_ptr() for t in qual], [t.data_ptr() for t in lens]
     dev = {"all_full": lambda: eng.demux_device(B, sp, qp, codes.data_ptr(), None, stream=st.cuda_stream),
            "one_short_listed": lambda: eng.demux_device_ragged(B, sp, qp, codes.data_ptr(), None, lp, 1, short.data_ptr(), stream=st.cuda_stream),

@@ -36,6 +36,7 @@ M = w.layout.mol_width
 codes = torch.empty(n, dtype=torch.int16, device="cuda")
 mol = torch.empty((n, max(M, 1)), dtype=torch.uint8, device="cuda")
 st = torch.cuda.Stream()
+torch.cuda.synchronize()  # inputs were made on the default stream
 res = {}
 with torch.cuda.stream(st):
     for r in range(rounds):
