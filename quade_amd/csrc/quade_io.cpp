@@ -75,8 +75,27 @@ LibDeflate& deflate_lib() {
     return L;
 }
 
+// byte buffer that is NOT value-initialised (std::vector<uint8_t>::resize writes every byte first)
+struct Bytes {
+    std::unique_ptr<uint8_t[]> p;
+    size_t n = 0, cap = 0;
+    uint8_t* data() { return p.get(); }
+    const uint8_t* data() const { return p.get(); }
+    size_t size() const { return n; }
+    void clear() { n = 0; }
+    void resize(size_t m) {  // contents are kept when growing
+        if (m > cap) {
+            std::unique_ptr<uint8_t[]> q(new uint8_t[m]);
+            if (n) memcpy(q.get(), p.get(), n);
+            p.swap(q);
+            cap = m;
+        }
+        n = m;
+    }
+};
+
 // one gzip member of `n` bytes at `level` (0..9) -> out; false on failure
-bool gzip_member(const uint8_t* in, size_t n, int level, std::vector<uint8_t>& out) {
+bool gzip_member(const uint8_t* in, size_t n, int level, Bytes& out) {
     LibDeflate& L = deflate_lib();
     if (L.ok) {
         thread_local std::map<int, void*> comp;  // one compressor per (thread, level), kept for the thread's life
@@ -221,7 +240,7 @@ struct OutFile {
     std::string path;
     std::mutex m;
     uint64_t next_submit = 0, next_write = 0;
-    std::map<uint64_t, std::vector<uint8_t>> done;  // finished members waiting for their turn
+    std::map<uint64_t, Bytes> done;  // finished members waiting for their turn
 };
 
 struct Dest {
@@ -254,7 +273,7 @@ void sink_error(qd_sink* s, const std::string& msg) {
     if (s->err.empty()) s->err = msg;
 }
 
-bool append_file(const std::string& path, const std::vector<uint8_t>& data, std::string& why) {
+bool append_file(const std::string& path, const Bytes& data, std::string& why) {
     const int fd = open(path.c_str(), O_WRONLY | O_APPEND | O_CREAT | O_CLOEXEC, 0644);
     if (fd < 0) {
         why = path + ": " + strerror(errno);
@@ -279,7 +298,7 @@ bool append_file(const std::string& path, const std::vector<uint8_t>& data, std:
 }
 
 // a finished member takes its place in the file's queue; everything that is next in line is written
-void deliver(qd_sink* s, OutFile* f, uint64_t seq, std::vector<uint8_t>&& member) {
+void deliver(qd_sink* s, OutFile* f, uint64_t seq, Bytes&& member) {
     std::lock_guard<std::mutex> g(f->m);
     f->done.emplace(seq, std::move(member));
     for (auto it = f->done.find(f->next_write); it != f->done.end(); it = f->done.find(f->next_write)) {
@@ -432,7 +451,8 @@ int qd_sink_route(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_t* r
     Pool& P = pool();
     for (const Piece& p : pieces) {
         P.submit([s, p, tag_rows, tag_stride, tag_len, formatted] {
-            std::vector<uint8_t> text((size_t)p.text_bytes + 8 * (size_t)p.n_sel + 16), member;
+            Bytes text, member;
+            text.resize((size_t)p.text_bytes + 8 * (size_t)p.n_sel + 16);
             const int64_t w = qd_format_records(p.text, p.rec_off, p.sel, p.n_sel, tag_rows, tag_stride, tag_len, text.data(),
                                                 (int64_t)text.size());
             formatted->done();  // nothing of the caller's is touched after this line
@@ -494,6 +514,22 @@ int qd_sink_close(qd_sink* s) {
 // finished batches; nothing of this runs on its thread.
 namespace {
 
+// plain allocation, not value-initialised: a vector would write (and so page in) every byte up front --
+// hundreds of MB per reader that are mostly never touched
+struct RawBuf {
+    uint8_t* p = nullptr;
+    size_t n = 0;
+    ~RawBuf() { free(p); }
+    uint8_t* data() { return p; }
+    size_t size() const { return n; }
+    void resize(size_t m) {  // grows only; contents are not preserved
+        if (m <= n) return;
+        free(p);
+        p = (uint8_t*)malloc(m);
+        n = p ? m : 0;
+    }
+};
+
 struct Batch {
     uint8_t* text = nullptr;
     int64_t cap = 0, text_len = 0, n = 0;
@@ -503,6 +539,7 @@ struct Batch {
 
 constexpr size_t READ_BYTES = 8u << 20;     // compressed bytes per read()
 constexpr size_t WINDOW = 32u << 20;        // a member inflated in one piece must lie inside this much input ...
+constexpr size_t LOW_WATER = 4u << 20;      // input is topped up when fewer unread bytes than this remain
 constexpr size_t MEMBER_OUT = 192u << 20;   // ... and inflate to at most this much
 constexpr size_t PIECE = 4u << 20;          // text handed to the scanner at a time
 
@@ -518,7 +555,7 @@ struct qd_reader {
     std::mutex m;
     std::condition_variable cv_room, cv_ready;
     // inflater -> batcher hand-off: two scratch blocks
-    std::vector<uint8_t> scratch[2];
+    RawBuf scratch[2];
     std::mutex hm;
     std::condition_variable hcv;
     int hstate[2] = {0, 0};
@@ -611,12 +648,14 @@ void fail_reader(qd_reader* r, const std::string& msg) {
 // compressed input with a sliding window: [pos, fill) of buf is unread
 struct Input {
     int fd;
-    std::vector<uint8_t> buf;
+    RawBuf buf;
     size_t pos = 0, fill = 0;
     bool eof = false;
-    explicit Input(int f) : fd(f), buf(WINDOW + READ_BYTES) {}
+    explicit Input(int f) : fd(f) { buf.resize(2 * WINDOW); }
     size_t avail() const { return fill - pos; }
-    // tops the window up to `want` unread bytes (or the end of the file); false on a read error
+    // Makes at least `want` unread bytes available (or everything up to the end of the file): only when
+    // fewer are left is the rest moved to the front (a small move) and the buffer filled to its end, so
+    // the moves stay a fraction of the bytes consumed.  false on a read error.
     bool refill(size_t want) {
         if (avail() >= want || eof) return true;
         if (pos) {
@@ -624,7 +663,7 @@ struct Input {
             fill -= pos;
             pos = 0;
         }
-        while (fill < want && !eof) {
+        while (fill < buf.size() && !eof) {
             const ssize_t g = read(fd, buf.data() + fill, std::min(READ_BYTES, buf.size() - fill));
             if (g < 0) {
                 if (errno == EINTR) continue;
@@ -673,19 +712,27 @@ void inflate_thread(qd_reader* r) {
         void* dec = L.ok ? L.alloc_decompressor() : nullptr;
         bool whole_members = dec != nullptr;  // until a member turns out not to fit the window
         while (ok) {
-            if (!in.refill(whole_members ? WINDOW : 1)) {
+            if (!in.refill(whole_members ? LOW_WATER : 1)) {
                 fail_reader(r, strerror(errno));
                 break;
             }
             if (!in.avail()) break;  // clean end: the last member ended where the file ends
             bool all_zero = in.eof;  // zero padding behind the last member is tolerated
-            for (size_t i = in.pos; all_zero && i < in.fill; ++i) all_zero = in.buf[i] == 0;
+            for (size_t i = in.pos; all_zero && i < in.fill; ++i) all_zero = in.buf.data()[i] == 0;
             if (all_zero) break;
             if (whole_members) {
                 if (r->scratch[cur].size() < MEMBER_OUT) r->scratch[cur].resize(MEMBER_OUT);
                 size_t ain = 0, aout = 0;
-                const int res = L.gzip_decompress_ex(dec, in.buf.data() + in.pos, in.avail(), r->scratch[cur].data(),
-                                                     r->scratch[cur].size(), &ain, &aout);
+                int res = L.gzip_decompress_ex(dec, in.buf.data() + in.pos, in.avail(), r->scratch[cur].data(),
+                                               r->scratch[cur].size(), &ain, &aout);
+                if (res != 0 && !in.eof && in.avail() < WINDOW) {  // the member may simply reach beyond what was buffered
+                    if (!in.refill(WINDOW)) {
+                        fail_reader(r, strerror(errno));
+                        break;
+                    }
+                    res = L.gzip_decompress_ex(dec, in.buf.data() + in.pos, in.avail(), r->scratch[cur].data(),
+                                               r->scratch[cur].size(), &ain, &aout);
+                }
                 if (res == 0) {
                     in.pos += ain;
                     if (aout) {
