@@ -199,7 +199,8 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
                 "samples": len(bcs), "gzip_backend": io_backend(), "io_threads": io_threads(), "host_cores": host_cores(),
                 "input_gz_bytes": in_bytes, "output_gz_bytes": out_bytes, "counts_total_pass_fail_undetermined": counts,
                 "dataset_seconds": t_gen,
-                "what": "2x150 bp + dual 8 bp index fastq.gz (8 MB gzip members) -> %d-sample pass/fail/Undetermined fastq.gz + "
+                "input_format": "BGZF (bgzip layout: 64 KiB gzip members, inflated in parallel)",
+                "what": "2x150 bp + dual 8 bp index fastq.gz -> %d-sample pass/fail/Undetermined fastq.gz + "
                         "report through quade_amd.quade (CLI driver), one process, one GPU" % len(bcs)}
     finally:
         shutil.rmtree(work, ignore_errors=True)
@@ -243,7 +244,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=5_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the streamed / end-to-end rates (N = 1 only)")
-    ap.add_argument("--e2e-pairs", type=int, default=1_000_000)
+    ap.add_argument("--e2e-pairs", type=int, default=2_000_000)
     ap.add_argument("--strong-sample", type=int, default=32_000_000)
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()

@@ -300,10 +300,17 @@ int qd_sink_stats(qd_sink* sink, int64_t* members, int64_t* text_bytes, int64_t*
 const char* qd_sink_last_error(const qd_sink* sink);
 int qd_sink_close(qd_sink* sink); /* flush + destroy */
 
+/* Writes n bytes as a gzip file, compressed on the library's pool: member_bytes > 0 = members of that much
+ * text, 0 = one member, -1 = BGZF blocks (bgzip / htslib layout: 64 KiB members that carry their size in a
+ * 'BC' extra subfield, closed by the empty end-of-file block).  Tooling (synthetic inputs); no reference
+ * counterpart. */
+int qd_write_gzip_file(const char* path, const uint8_t* data, int64_t n_bytes, int32_t level, int64_t member_bytes);
+
 /* ---- host I/O: fastq(.gz) file -> batches of whole records ----------------------------------------------
  * Replaces pyFastq.FastqReader as the reference uses it (src/Quade.py:203-214: one .next() per record):
- * a reader owns a thread that reads, inflates ("*.gz": gzip, any number of members; else plain text),
- * scans and batches the file ahead of the consumer.  A batch holds exactly batch_records kept records
+ * a reader owns two threads that read + inflate ("*.gz": gzip, any number of members; BGZF / bgzip files
+ * are cut into blocks by their header fields and inflated in parallel on the library's pool; else plain
+ * text) and scan + batch the file ahead of the consumer.  A batch holds exactly batch_records kept records
  * (fewer at the end of the file only); a record whose sequence and quality lengths differ is skipped
  * inside its own stream, a trailing partial record ends the stream, a last line
  * without newline counts.  text/rec_off stay valid until qd_text_batch_free(handle). */

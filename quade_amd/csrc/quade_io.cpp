@@ -51,6 +51,9 @@ struct LibDeflate {
     void* (*alloc_decompressor)() = nullptr;
     int (*gzip_decompress_ex)(void*, const void*, size_t, void*, size_t, size_t*, size_t*) = nullptr;
     void (*free_decompressor)(void*) = nullptr;
+    size_t (*deflate_compress)(void*, const void*, size_t, void*, size_t) = nullptr;  // raw deflate (BGZF blocks)
+    size_t (*deflate_compress_bound)(void*, size_t) = nullptr;
+    uint32_t (*crc32)(uint32_t, const void*, size_t) = nullptr;
     bool ok = false;
     LibDeflate() {
         const char* off = getenv("QUADE_NO_LIBDEFLATE");
@@ -65,6 +68,9 @@ struct LibDeflate {
         QD_SYM(alloc_decompressor, "libdeflate_alloc_decompressor");
         QD_SYM(gzip_decompress_ex, "libdeflate_gzip_decompress_ex");
         QD_SYM(free_decompressor, "libdeflate_free_decompressor");
+        QD_SYM(deflate_compress, "libdeflate_deflate_compress");
+        QD_SYM(deflate_compress_bound, "libdeflate_deflate_compress_bound");
+        QD_SYM(crc32, "libdeflate_crc32");
 #undef QD_SYM
         ok = alloc_compressor && gzip_compress && gzip_compress_bound && free_compressor && alloc_decompressor &&
              gzip_decompress_ex && free_decompressor;
@@ -150,10 +156,13 @@ class Pool {
         cv_.notify_all();
         for (auto& t : threads_) t.join();
     }
-    void submit(std::function<void()> fn) {
+    void submit(std::function<void()> fn, bool urgent = false) {
         {
             std::lock_guard<std::mutex> g(m_);
-            q_.push_back(std::move(fn));
+            if (urgent)
+                q_.push_front(std::move(fn));  // inflate jobs: everything downstream waits for their text
+            else
+                q_.push_back(std::move(fn));
         }
         cv_.notify_one();
     }
@@ -560,6 +569,8 @@ struct qd_reader {
     std::condition_variable hcv;
     int hstate[2] = {0, 0};
     size_t hlen[2] = {0, 0};
+    const uint8_t* hptr[2] = {nullptr, nullptr};
+    std::shared_ptr<void> held[2];
     bool inflated = false;
     std::deque<Batch*> ready;
     bool done = false, stop = false;
@@ -679,14 +690,132 @@ struct Input {
 // ---- the two threads of a reader: inflate -> (two scratch blocks) -> scan + batch ----------------------
 // state[i]: 0 = scratch i is the inflater's, 1 = it holds len[i] bytes of text for the batcher.  Both sides
 // walk the blocks in the same order 0, 1, 0, 1 ...
-bool hand_over(qd_reader* r, int i, size_t len) {
+bool hand_over(qd_reader* r, int i, size_t len, const uint8_t* ptr = nullptr) {
     std::unique_lock<std::mutex> g(r->hm);
+    r->hptr[i] = ptr ? ptr : r->scratch[i].data();
     r->hlen[i] = len;
     r->hstate[i] = 1;
     r->hcv.notify_all();
     const int nx = i ^ 1;
     r->hcv.wait(g, [r, nx] { return r->stop || r->hstate[nx] == 0; });
     return !r->stop;
+}
+
+// BGZF (bgzip, htslib): gzip members of <= 64 KiB whose header carries their own size in an extra
+// subfield 'B','C' -- so the file can be cut into blocks WITHOUT inflating it, and the blocks inflated
+// in parallel.  Returns the block's total size (header .. ISIZE), 0 when [p, p+avail) does not start with
+// a complete BGZF block header.
+size_t bgzf_block_size(const uint8_t* p, size_t avail) {
+    if (avail < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+    const size_t xlen = p[10] | ((size_t)p[11] << 8);
+    if (avail < 12 + xlen) return 0;
+    for (size_t o = 12; o + 4 <= 12 + xlen;) {
+        const size_t slen = p[o + 2] | ((size_t)p[o + 3] << 8);
+        if (p[o] == 'B' && p[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen) return (size_t)(p[o + 4] | (p[o + 5] << 8)) + 1;
+        o += 4 + slen;
+    }
+    return 0;
+}
+
+struct BgzfRun {  // consecutive blocks inflated by one pool job
+    std::vector<uint8_t> in;  // the compressed blocks (copied out of the window, which moves on)
+    Bytes out;
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false, ok = true;
+};
+
+constexpr size_t BGZF_RUN_BYTES = 2u << 20;  // compressed bytes per job
+constexpr size_t BGZF_RUNS_IN_FLIGHT = 6;
+
+// The whole file as BGZF: the inflater thread only walks the block headers and hands runs of blocks to the
+// pool; it collects the runs in file order.  Returns false when the file stops being BGZF where a block is
+// expected (the caller then continues with the sequential member loop from in.pos).
+bool inflate_bgzf(qd_reader* r, Input& in, int& cur, bool& ok) {
+    LibDeflate& L = deflate_lib();
+    std::deque<std::shared_ptr<BgzfRun>> flight;
+    // r->held[i]: the run whose text the batcher reads out of slot i; it lives in the reader (not on this
+    // stack) so that a close() racing with the batcher's copy cannot free the text under it
+    bool still_bgzf = true, more = true;
+    auto collect_one = [&]() {  // oldest run -> batcher (in file order)
+        std::shared_ptr<BgzfRun> run = flight.front();
+        flight.pop_front();
+        {
+            std::unique_lock<std::mutex> g(run->m);
+            run->cv.wait(g, [&] { return run->done; });
+        }
+        if (!run->ok) {
+            fail_reader(r, "damaged BGZF block");
+            ok = false;
+            return;
+        }
+        if (run->out.size()) {
+            r->held[cur] = run;  // keeps the text alive until this slot is handed over again
+            ok = hand_over(r, cur, run->out.size(), run->out.data());
+            cur ^= 1;
+        }
+    };
+    while (ok && more) {
+        // one run: whole blocks up to BGZF_RUN_BYTES
+        std::shared_ptr<BgzfRun> run = std::make_shared<BgzfRun>();
+        size_t out_bytes = 0;
+        while (run->in.size() < BGZF_RUN_BYTES) {
+            if (!in.refill(1u << 17)) {
+                fail_reader(r, strerror(errno));
+                ok = false;
+                break;
+            }
+            if (!in.avail()) {
+                more = false;
+                break;
+            }
+            const size_t bs = bgzf_block_size(in.buf.data() + in.pos, in.avail());
+            if (!bs || bs > in.avail() || bs < 26) {
+                still_bgzf = more = false;  // not (or no longer) BGZF here: the member loop takes over
+                break;
+            }
+            const uint8_t* b = in.buf.data() + in.pos;
+            out_bytes += (size_t)b[bs - 4] | ((size_t)b[bs - 3] << 8) | ((size_t)b[bs - 2] << 16) | ((size_t)b[bs - 1] << 24);  // ISIZE
+            run->in.insert(run->in.end(), b, b + bs);
+            in.pos += bs;
+        }
+        if (!ok) break;
+        if (!run->in.empty()) {
+            run->out.resize(out_bytes);
+            flight.push_back(run);
+            pool().submit([run, &L] {
+                thread_local void* dec = nullptr;
+                if (!dec) dec = L.alloc_decompressor();
+                size_t ip = 0, op = 0;
+                bool good = dec != nullptr;
+                while (good && ip < run->in.size()) {
+                    size_t ain = 0, aout = 0;
+                    good = L.gzip_decompress_ex(dec, run->in.data() + ip, run->in.size() - ip, run->out.data() + op,
+                                                run->out.size() - op, &ain, &aout) == 0 && ain > 0;
+                    ip += ain;
+                    op += aout;
+                }
+                good = good && op == run->out.size();
+                std::lock_guard<std::mutex> g(run->m);
+                run->ok = good;
+                run->done = true;
+                run->cv.notify_all();
+            }, true);
+        }
+        while (ok && !flight.empty() && (flight.size() >= BGZF_RUNS_IN_FLIGHT || !more)) collect_one();
+    }
+    while (!flight.empty()) {  // stopping early (close / error): the jobs still reference their runs; just wait them out
+        std::shared_ptr<BgzfRun> run = flight.front();
+        flight.pop_front();
+        std::unique_lock<std::mutex> g(run->m);
+        run->cv.wait(g, [&] { return run->done; });
+    }
+    // before anything else reuses the two slots, the batcher must have taken the last runs
+    if (ok) {
+        std::unique_lock<std::mutex> g(r->hm);
+        r->hcv.wait(g, [r] { return r->stop || (r->hstate[0] == 0 && r->hstate[1] == 0); });
+    }
+    return still_bgzf;
 }
 
 void inflate_thread(qd_reader* r) {
@@ -709,6 +838,17 @@ void inflate_thread(qd_reader* r) {
         }
     } else {
         LibDeflate& L = deflate_lib();
+        if (L.ok && in.refill(1u << 17) && bgzf_block_size(in.buf.data() + in.pos, in.avail())) {
+            // bgzip'd input: blocks are indexed by their headers and inflated in parallel; if the file turns
+            // into ordinary gzip members further on, the loop below continues from there
+            const bool to_the_end = inflate_bgzf(r, in, cur, ok);
+            if (to_the_end) {  // (otherwise both slots are free and the alternation simply goes on at `cur`)
+                std::lock_guard<std::mutex> g(r->hm);
+                r->inflated = true;
+                r->hcv.notify_all();
+                return;
+            }
+        }
         void* dec = L.ok ? L.alloc_decompressor() : nullptr;
         bool whole_members = dec != nullptr;  // until a member turns out not to fit the window
         while (ok) {
@@ -809,7 +949,7 @@ void batch_thread(qd_reader* r) {
             if (r->hstate[j] != 1) break;  // the inflater is done and this block was never filled
             len = r->hlen[j];
         }
-        ok = feed(r, r->scratch[j].data(), len);
+        ok = feed(r, r->hptr[j], len);
         std::lock_guard<std::mutex> g(r->hm);
         r->hstate[j] = 0;
         r->hcv.notify_all();
@@ -913,3 +1053,108 @@ int qd_reader_close(qd_reader* r) {
 }
 
 }  // extern "C"
+
+// ---- whole-buffer gzip writer (tooling: synthetic inputs; any binding that holds text in memory) ------------
+namespace {
+
+thread_local std::map<int, void*> g_raw_comp;  // libdeflate compressors of this thread, by level
+
+// BGZF blocks (bgzip / htslib layout) of text[0..n): 0xFF00 text bytes per block, raw deflate, 'BC' size field
+bool bgzf_blocks(const uint8_t* text, size_t n, int level, Bytes& out) {
+    LibDeflate& L = deflate_lib();
+    const size_t BLOCK = 0xFF00;
+    void* c = nullptr;
+    if (L.ok && L.deflate_compress && L.crc32) {
+        void*& slot = g_raw_comp[level];
+        if (!slot) slot = L.alloc_compressor(level);
+        c = slot;
+    }
+    size_t o = 0;
+    out.resize((n / BLOCK + 1) * (BLOCK + 1024));
+    for (size_t a = 0; a < n; a += BLOCK) {
+        const size_t m = std::min(BLOCK, n - a);
+        uint8_t* h = out.data() + o;
+        static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        memcpy(h, head, 16);
+        size_t body = 0;
+        uint32_t crc;
+        if (c) {
+            body = L.deflate_compress(c, text + a, m, h + 18, BLOCK + 1024 - 26);
+            crc = L.crc32(0, text + a, m);
+        } else {
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+            zs.next_in = const_cast<Bytef*>(text + a);
+            zs.avail_in = (uInt)m;
+            zs.next_out = h + 18;
+            zs.avail_out = (uInt)(BLOCK + 1024 - 26);
+            const int zr = deflate(&zs, Z_FINISH);
+            body = zr == Z_STREAM_END ? (BLOCK + 1024 - 26) - zs.avail_out : 0;
+            deflateEnd(&zs);
+            crc = (uint32_t)::crc32(0L, text + a, (uInt)m);
+        }
+        if (!body || body + 25 > 0xFFFF) return false;
+        const size_t bsize = body + 25;  // total block size - 1
+        h[16] = (uint8_t)bsize;
+        h[17] = (uint8_t)(bsize >> 8);
+        uint8_t* t = h + 18 + body;
+        for (int i = 0; i < 4; ++i) t[i] = (uint8_t)(crc >> (8 * i));
+        for (int i = 0; i < 4; ++i) t[4 + i] = (uint8_t)((uint32_t)m >> (8 * i));
+        o += 18 + body + 8;
+    }
+    out.resize(o);
+    return true;
+}
+
+}  // namespace
+
+extern "C" int qd_write_gzip_file(const char* path, const uint8_t* data, int64_t n, int32_t level, int64_t member_bytes) {
+    if (!path || (!data && n) || n < 0 || level < 0 || level > 9 || member_bytes < -1) return QD_ERR_INVALID;
+    const bool bgzf = member_bytes == -1;
+    const int64_t piece = bgzf ? 64 * 0xFF00 : (member_bytes > 0 ? member_bytes : std::max<int64_t>(n, 1));
+    const int64_t np = n ? (n + piece - 1) / piece : 0;
+    std::vector<Bytes> parts((size_t)np);
+    std::vector<char> good((size_t)np, 0);
+    std::shared_ptr<Latch> latch = std::make_shared<Latch>();
+    latch->n = np;
+    for (int64_t i = 0; i < np; ++i) {
+        pool().submit([=, &parts, &good] {
+            const uint8_t* p = data + i * piece;
+            const size_t m = (size_t)std::min<int64_t>(piece, n - i * piece);
+            good[(size_t)i] = bgzf ? bgzf_blocks(p, m, level, parts[(size_t)i]) : gzip_member(p, m, level, parts[(size_t)i]);
+            latch->done();
+        });
+    }
+    if (np) latch->wait();
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+    if (fd < 0) return QD_ERR_FORMAT;
+    bool ok = true;
+    auto put = [&](const uint8_t* p, size_t m) {
+        while (ok && m) {
+            const ssize_t w = write(fd, p, m);
+            if (w < 0) {
+                if (errno == EINTR) continue;
+                ok = false;
+                break;
+            }
+            p += w;
+            m -= (size_t)w;
+        }
+    };
+    for (int64_t i = 0; i < np && ok; ++i) {
+        ok = good[(size_t)i] != 0;
+        if (ok) put(parts[(size_t)i].data(), parts[(size_t)i].size());
+    }
+    if (np == 0 && !bgzf) {  // an empty file is still one (empty) gzip member
+        Bytes e;
+        ok = gzip_member(data, 0, level, e);
+        if (ok) put(e.data(), e.size());
+    }
+    if (bgzf) {
+        static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        put(eof_block, sizeof eof_block);
+    }
+    if (close(fd) != 0) ok = false;
+    return ok ? QD_OK : QD_ERR_FORMAT;
+}

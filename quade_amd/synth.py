@@ -175,34 +175,27 @@ def _digits(vals, width):
     return out
 
 
-def _gzip_members(data, path, level, member_bytes, threads):
-    """Writes `data` as a gzip file: one member (member_bytes = 0) or members of member_bytes of text,
-    compressed in parallel (zlib releases the GIL) -- what parallel compressors produce."""
-    import zlib
-    from concurrent.futures import ThreadPoolExecutor
-
-    def one(chunk):
-        co = zlib.compressobj(level, zlib.DEFLATED, 31)
-        return co.compress(chunk) + co.flush()
-
-    view = memoryview(data).cast("B")
-    if not member_bytes:
-        parts = [one(view)]
-    else:
-        cuts = list(range(0, len(view), member_bytes))
-        with ThreadPoolExecutor(max_workers=threads) as ex:
-            parts = list(ex.map(one, [view[a:a + member_bytes] for a in cuts]))
-    with open(path, "wb") as fh:
-        for p in parts:
-            fh.write(p)
+def _gzip_members(data, path, level, member_bytes, threads=0):
+    """Writes `data` as a gzip file through the library's own compressor pool (qd_write_gzip_file): one
+    member (member_bytes = 0), members of member_bytes of text, or (member_bytes = "bgzf") BGZF blocks
+    as bgzip / htslib write them: 64 KiB members whose header carries the block size in a 'BC' extra
+    subfield, closed by the empty end-of-file block."""
+    import numpy as np
+    from . import hip_backend as hb
+    lib = hb.load_library()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    r = lib.qd_write_gzip_file(str(path).encode(), hb._ptr(buf), buf.size, int(level), -1 if member_bytes == "bgzf" else int(member_bytes))
+    if r != hb.QD_OK:
+        raise IOError("qd_write_gzip_file(%s) failed: %d" % (path, r))
 
 
-def write_fastq_dataset(workdir, n_pairs, n_samples=96, insert_len=150, seed=5, gz_level=1, member_bytes=8 << 20,
-                        threads=8, plain=False):
+def write_fastq_dataset(workdir, n_pairs, n_samples=96, insert_len=150, seed=5, gz_level=1, member_bytes="bgzf",
+                        threads=0, plain=False):
     """2 x insert_len bp insert reads + dual 8 bp index reads of n_pairs pairs as four fastq(.gz) files
     under workdir (SURVEY.md 8d recipe: 90 % carry a sample's barcode pair, 10 % get an N; qualities
     phred 30..40, 15 % of the index reads with one position at phred 2..24).  Names are identical across
-    the four streams.  Returns (paths dict, barcode pairs)."""
+    the four streams.  member_bytes: "bgzf" (bgzip layout, the default), N > 0 (gzip members of N text bytes) or 0
+    (one gzip member).  Returns (paths dict, barcode pairs)."""
     import os
     import numpy as np
     rng = np.random.default_rng(seed)

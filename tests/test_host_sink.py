@@ -189,6 +189,7 @@ def test_sink_thread_sanitizer(tmp_path):
     drv = tmp_path / "drv.cpp"
     drv.write_text(r'''
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -237,8 +238,12 @@ int main(int argc, char** argv) {
     std::string f = std::string(argv[1]) + "/Undetermined_R1.fastq.gz";
     std::thread c([&] { r3 = read_back(f.c_str(), 6 * 6000, false); }), d([&] { r4 = read_back(f.c_str(), 0, true); });
     c.join(); d.join();
-    printf("%d %d %d %d\n", r1, r2, r3, r4);
-    return r1 || r2 || r3 || r4;
+    // a bgzip-style file: block runs inflated on the pool, collected in order, also when closed half-way
+    int r5 = -1, r6 = -1;
+    std::thread e([&] { r5 = read_back(argv[3], atoll(argv[4]), false); }), g([&] { r6 = read_back(argv[3], 0, true); });
+    e.join(); g.join();
+    printf("%d %d %d %d %d %d\n", r1, r2, r3, r4, r5, r6);
+    return r1 || r2 || r3 || r4 || r5 || r6;
 }
 ''')
     exe = tmp_path / "drv"
@@ -249,7 +254,12 @@ int main(int argc, char** argv) {
     assert r.returncode == 0, r.stderr[-3000:]
     (tmp_path / "a").mkdir()
     (tmp_path / "b").mkdir()
-    r = subprocess.run([str(exe), str(tmp_path / "a"), str(tmp_path / "b")], capture_output=True, text=True,
+    from quade_amd.synth import _gzip_members
+    n_bgzf = 60000
+    _gzip_members(b"".join(b"@r%d\nACGTACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n" % i for i in range(n_bgzf)),
+                  str(tmp_path / "bgzf.fastq.gz"), 1, "bgzf", 2)
+    r = subprocess.run([str(exe), str(tmp_path / "a"), str(tmp_path / "b"), str(tmp_path / "bgzf.fastq.gz"), str(n_bgzf)],
+                       capture_output=True, text=True,
                        env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout, r.stderr[-3000:])
     assert len(os.listdir(tmp_path / "a")) == 10
