@@ -280,6 +280,7 @@ const char* qd_comm_last_error(void); /* text of the last qd_comm_* / qd_reduce_
  * caller's buffers are free again); compression and the appends continue behind it.  A sink is driven
  * by one thread at a time; different sinks may be driven concurrently. */
 typedef struct qd_sink qd_sink;
+typedef struct qd_text_batch qd_text_batch; /* a batch of the native reader, below */
 /* Threads of the I/O pool: n_threads > 0 sets it (before the pool's first use), 0 = one per hardware
  * core this process may use (qd_host_cores), < 0 = query only.  Returns the size in effect. */
 int qd_io_threads(int32_t n_threads);
@@ -295,6 +296,12 @@ int qd_sink_set_quiet(qd_sink* sink, int32_t quiet); /* 1: no "Create ... file" 
 int qd_sink_route(qd_sink* sink, int64_t n_pairs, const uint16_t* codes, const uint8_t* r1_text,
                   const int64_t* r1_rec_off, const uint8_t* r2_text, const int64_t* r2_rec_off,
                   const uint8_t* tag_rows, int32_t tag_stride, const uint8_t* tag_len);
+/* Same, for insert reads that came from the native reader (qd_reader_next): the sink takes the two text
+ * batches over (the caller must NOT free their handles afterwards, whatever the return code) and copies the
+ * tags, so the call returns right after the scatter; formatting and compression run behind it. */
+int qd_sink_route_batches(qd_sink* sink, int64_t n_pairs, const uint16_t* codes, const qd_text_batch* r1,
+                          const qd_text_batch* r2, const uint8_t* tag_rows, int32_t tag_stride,
+                          const uint8_t* tag_len);
 int qd_sink_flush(qd_sink* sink); /* waits until every member is in its file (src/Sample.py:93-102 FLUSH_ALL) */
 int qd_sink_stats(qd_sink* sink, int64_t* members, int64_t* text_bytes, int64_t* gzip_bytes, int64_t* files);
 const char* qd_sink_last_error(const qd_sink* sink);
@@ -315,13 +322,13 @@ int qd_write_gzip_file(const char* path, const uint8_t* data, int64_t n_bytes, i
  * inside its own stream, a trailing partial record ends the stream, a last line
  * without newline counts.  text/rec_off stay valid until qd_text_batch_free(handle). */
 typedef struct qd_reader qd_reader;
-typedef struct qd_text_batch {
+struct qd_text_batch {
     const uint8_t* text;    /* whole records, 4 lines each */
     int64_t text_len;
     const int64_t* rec_off; /* n_records + 1 offsets into text, as qd_fastq_index gives them */
     int64_t n_records;      /* 0 = end of the stream (handle is NULL then) */
     void* handle;
-} qd_text_batch;
+};
 int qd_reader_open(const char* path, int64_t batch_records, int32_t queue_depth, qd_reader** out);
 int qd_reader_next(qd_reader* reader, qd_text_batch* out); /* blocks until a batch is ready */
 int qd_text_batch_free(void* handle);

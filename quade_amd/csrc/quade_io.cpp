@@ -371,15 +371,39 @@ int qd_sink_set_quiet(qd_sink* s, int32_t quiet) {
     return QD_OK;
 }
 
-int qd_sink_route(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_t* r1_text, const int64_t* r1_off,
-                  const uint8_t* r2_text, const int64_t* r2_off, const uint8_t* tag_rows, int32_t tag_stride,
-                  const uint8_t* tag_len) {
+// what a batch's jobs need until the last of them has formatted its piece
+struct RouteRes {
+    std::vector<int64_t> order;
+    std::vector<uint8_t> tags, tag_len;  // copies (owned mode only)
+    void* owned[2] = {nullptr, nullptr};  // text batches of the reader handed over by the caller
+    Latch formatted;
+    ~RouteRes() {
+        for (void* h : owned)
+            if (h) qd_text_batch_free(h);
+    }
+};
+
+// owned == false: returns when every piece has been formatted (the caller's buffers are free again);
+// owned == true: the text batches, and copies of the tags, belong to the jobs -- returns after the scatter
+static int route_impl(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_t* r1_text, const int64_t* r1_off,
+                      const uint8_t* r2_text, const int64_t* r2_off, const uint8_t* tag_rows, int32_t tag_stride,
+                      const uint8_t* tag_len, void* own1, void* own2) {
+    const bool owned = own1 != nullptr || own2 != nullptr;
+    std::shared_ptr<RouteRes> res = std::make_shared<RouteRes>();
+    res->owned[0] = own1;  // from here on the handles are freed with `res`, whatever happens
+    res->owned[1] = own2;
     if (!s || n < 0) return QD_ERR_INVALID;
     if (n == 0) return QD_OK;
     if (!codes || !r1_text || !r1_off || !r2_text || !r2_off || !tag_rows || !tag_len) return QD_ERR_INVALID;
     {
         std::lock_guard<std::mutex> g(s->m);
         if (!s->err.empty()) return QD_ERR_FORMAT;
+    }
+    if (owned) {
+        res->tags.assign(tag_rows, tag_rows + (size_t)n * (size_t)tag_stride);
+        res->tag_len.assign(tag_len, tag_len + n);
+        tag_rows = res->tags.data();
+        tag_len = res->tag_len.data();
     }
     // 1. counting scatter by routing code (src/Sample.py:74-91 decides per pair; here per batch), stable
     const uint32_t S = (uint32_t)s->names.size(), nb = 2 * S + 1;
@@ -394,7 +418,9 @@ int qd_sink_route(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_t* r
         ++start[b + 1];
     }
     for (uint32_t b = 0; b < nb; ++b) start[b + 1] += start[b];
-    std::vector<int64_t> order((size_t)n), fill(start.begin(), start.end() - 1);
+    std::vector<int64_t>& order = res->order;
+    order.resize((size_t)n);
+    std::vector<int64_t> fill(start.begin(), start.end() - 1);
     for (int64_t i = 0; i < n; ++i) {
         const uint32_t c = codes[i];
         order[(size_t)fill[c == QD_CODE_UNDETERMINED ? 2 * S : c]++] = i;
@@ -454,17 +480,16 @@ int qd_sink_route(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_t* r
         s->pending_bytes += batch_bytes;
         s->pending_jobs += (int64_t)pieces.size();
     }
-    // shared: the last job may still be inside done() when this call has already been woken
-    std::shared_ptr<Latch> formatted = std::make_shared<Latch>();
-    formatted->n = (int64_t)pieces.size();
+    res->formatted.n = (int64_t)pieces.size();
     Pool& P = pool();
     for (const Piece& p : pieces) {
-        P.submit([s, p, tag_rows, tag_stride, tag_len, formatted] {
+        P.submit([s, p, tag_rows, tag_stride, tag_len, res]() mutable {
             Bytes text, member;
             text.resize((size_t)p.text_bytes + 8 * (size_t)p.n_sel + 16);
             const int64_t w = qd_format_records(p.text, p.rec_off, p.sel, p.n_sel, tag_rows, tag_stride, tag_len, text.data(),
                                                 (int64_t)text.size());
-            formatted->done();  // nothing of the caller's is touched after this line
+            res->formatted.done();
+            res.reset();  // nothing of the batch is touched after this line: the last job to get here frees it
             bool ok = w >= 0;
             if (!ok) sink_error(s, "qd_format_records failed (malformed record text)");
             if (ok && !gzip_member(text.data(), (size_t)w, s->level, member)) {
@@ -483,8 +508,26 @@ int qd_sink_route(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_t* r
             s->cv.notify_all();
         });
     }
-    formatted->wait();
+    if (!owned) res->formatted.wait();  // the caller's buffers are free again
     return QD_OK;
+}
+
+int qd_sink_route(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_t* r1_text, const int64_t* r1_off,
+                  const uint8_t* r2_text, const int64_t* r2_off, const uint8_t* tag_rows, int32_t tag_stride,
+                  const uint8_t* tag_len) {
+    return route_impl(s, n, codes, r1_text, r1_off, r2_text, r2_off, tag_rows, tag_stride, tag_len, nullptr, nullptr);
+}
+
+int qd_sink_route_batches(qd_sink* s, int64_t n, const uint16_t* codes, const qd_text_batch* r1, const qd_text_batch* r2,
+                          const uint8_t* tag_rows, int32_t tag_stride, const uint8_t* tag_len) {
+    if (!r1 || !r2 || !r1->handle || !r2->handle) return QD_ERR_INVALID;
+    if (n > r1->n_records || n > r2->n_records) {
+        qd_text_batch_free(r1->handle);
+        qd_text_batch_free(r2->handle);
+        return QD_ERR_INVALID;
+    }
+    return route_impl(s, n, codes, r1->text, r1->rec_off, r2->text, r2->rec_off, tag_rows, tag_stride, tag_len, r1->handle,
+                      r2->handle);
 }
 
 int qd_sink_flush(qd_sink* s) {

@@ -22,15 +22,23 @@ from . import hip_backend as hb
 class TextBatch(object):
     """n whole records: `text` (uint8 view) and `off` (int64[n+1] view) over memory the library owns
     until release() -- or until the object goes away."""
-    __slots__ = ("n", "text", "off", "_handle", "_lib")
+    __slots__ = ("n", "text", "off", "_handle", "_lib", "_tb")
 
     def __init__(self, lib, tb):
-        self._lib, self._handle, self.n = lib, tb.handle, int(tb.n_records)
+        self._lib, self._handle, self.n, self._tb = lib, tb.handle, int(tb.n_records), tb
         if self.n:
             self.text = np.frombuffer((C.c_uint8 * tb.text_len).from_address(tb.text), dtype=np.uint8)
             self.off = np.frombuffer((C.c_int64 * (self.n + 1)).from_address(tb.rec_off), dtype=np.int64)
         else:
             self.text, self.off = np.empty(0, np.uint8), np.zeros(1, np.int64)
+
+    def give_away(self):
+        """The native struct of this batch for a callee that takes the memory over (qd_sink_route_batches);
+        this object no longer frees it."""
+        assert self._handle, "batch already released"
+        self.text = self.off = None
+        self._handle = None
+        return self._tb
 
     def release(self):
         if self._handle:

@@ -67,6 +67,18 @@ class FastqSink(object):
                                          hb._ptr(r2_text), hb._ptr(r2_off), hb._ptr(tags), tags.shape[1],
                                          hb._ptr(tag_len)))
 
+    def route_batches(self, n, codes, r1_batch, r2_batch, tags, tag_len):
+        """Same for insert reads held as TextBatch objects of the native reader: the sink takes their
+        memory over (they must not be used afterwards) and returns right after the scatter."""
+        if n == 0:
+            r1_batch.release()
+            r2_batch.release()
+            return
+        codes = np.ascontiguousarray(codes[:n], dtype=np.uint16)
+        t1, t2 = r1_batch.give_away(), r2_batch.give_away()
+        self._chk(self.lib.qd_sink_route_batches(self._h, int(n), hb._ptr(codes), C.byref(t1), C.byref(t2), hb._ptr(tags),
+                                                 tags.shape[1], hb._ptr(tag_len)))
+
     def flush(self):
         self._chk(self.lib.qd_sink_flush(self._h))
 

@@ -116,6 +116,7 @@ SYMBOLS = [
                                  C.POINTER(_P)]),
     ("qd_sink_set_quiet", C.c_int, [_P, C.c_int32]),
     ("qd_sink_route", C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    ("qd_sink_route_batches", C.c_int, [_P, C.c_int64, _P, C.POINTER(qd_text_batch), C.POINTER(qd_text_batch), _P, C.c_int32, _P]),
     ("qd_sink_flush", C.c_int, [_P]),
     ("qd_sink_stats", C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("qd_sink_last_error", C.c_char_p, [_P]),

@@ -353,9 +353,8 @@ class Quade(object):
             tags, tag_len = hb.build_tags(self.layout, self.plan, n, v["seq"], v["len"] if has_len else None,
                                           mol_rows=v["mol"])
         with _timed("route + format + queue gzip"):
-            Sample.FINDER(Batch(n, r1b.text, r1b.off, r2b.text, r2b.off, v["codes"], tags, tag_len), writers)
-        r1b.release()  # the sink has consumed the text: the blocks go back to the allocator now
-        r2b.release()
+            # the sink takes the two text batches over and frees them when their last piece is formatted
+            Sample.FINDER(Batch(n, r1b, r2b, v["codes"], tags, tag_len), writers)
 
 
 def main(argv=None):

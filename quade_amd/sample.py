@@ -17,10 +17,12 @@ from .fastq_writer import FastqSink
 class Batch(object):
     """What FINDER needs of one batch of n pairs: insert-read text + record offsets, routing codes,
     name tags."""
-    __slots__ = ("n", "r1_text", "r1_off", "r2_text", "r2_off", "codes", "tags", "tag_len")
+    __slots__ = ("n", "r1", "r2", "codes", "tags", "tag_len")
 
-    def __init__(self, n, r1_text, r1_off, r2_text, r2_off, codes, tags, tag_len):
-        self.n, self.r1_text, self.r1_off, self.r2_text, self.r2_off = n, r1_text, r1_off, r2_text, r2_off
+    def __init__(self, n, r1, r2, codes, tags, tag_len):
+        """r1 / r2: TextBatch objects of the native reader (quade_amd/fastq_reader.py); routing hands
+        their memory to the sink."""
+        self.n, self.r1, self.r2 = n, r1, r2
         self.codes, self.tags, self.tag_len = codes, tags, tag_len
 
 
@@ -38,8 +40,7 @@ class WriterSet(object):
         """src/Sample.py:56-91 for every pair of the batch, counters excluded (they come from the
         device): scatter by routing code (write_* flags honoured), format, gzip, append.  Within a
         destination the input order is kept."""
-        self._sink.route(batch.n, batch.codes, batch.r1_text, batch.r1_off, batch.r2_text, batch.r2_off,
-                         batch.tags, batch.tag_len)
+        self._sink.route_batches(batch.n, batch.codes, batch.r1, batch.r2, batch.tags, batch.tag_len)
 
     def flush(self):
         self._sink.flush()

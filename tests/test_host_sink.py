@@ -263,3 +263,41 @@ int main(int argc, char** argv) {
                        env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout, r.stderr[-3000:])
     assert len(os.listdir(tmp_path / "a")) == 10
+
+
+def test_reader_to_sink_owned_batches_equal_plain_routing(tmp_path):
+    """The driver's path: text batches of the native reader are handed over to the sink
+    (qd_sink_route_batches: returns after the scatter, frees the batches when their last piece has been
+    formatted) -- same files as routing the same buffers with the blocking call."""
+    from quade_amd import synth
+    from quade_amd.fastq_reader import FastqStream
+    paths, bcs = synth.write_fastq_dataset(str(tmp_path), 30000)
+    outs = []
+    for mode in ("plain", "owned"):
+        o = tmp_path / mode
+        o.mkdir()
+        sink = FastqSink(str(o), ["S%d" % i for i in range(len(bcs))], 1, quiet=True)
+        s1, s2 = FastqStream(paths["seq_R1"], 7000), FastqStream(paths["seq_R2"], 7000)
+        rng = np.random.default_rng(0)
+        while True:
+            b1, b2 = s1.take(), s2.take()
+            n = min(b1.n, b2.n)
+            codes = rng.integers(0, 2 * len(bcs) + 9, max(n, 1)).astype(np.uint16)
+            codes[codes >= 2 * len(bcs)] = 0xFFFF
+            tags = np.zeros((max(n, 1), 5), np.uint8)
+            tags[:] = np.frombuffer(b":ACGT", np.uint8)
+            tl = np.full(max(n, 1), 5, np.uint8)
+            if mode == "plain":
+                sink.route(n, codes, b1.text, b1.off, b2.text, b2.off, tags, tl)
+                b1.release()
+                b2.release()
+            else:
+                sink.route_batches(n, codes, b1, b2, tags, tl)
+                assert b1.text is None and b2.text is None  # given away
+            if n < 7000:
+                break
+        sink.close()
+        s1.close()
+        s2.close()
+        outs.append({f: _gz(str(o / f)) for f in sorted(os.listdir(o))})
+    assert len(outs[0]) == 2 * (2 * len(bcs) + 1) and outs[0] == outs[1]
