@@ -17,6 +17,9 @@
 #ifndef QD_FAST_NT
 #define QD_FAST_NT 1       /* non-temporal row loads                   */
 #endif
+#ifndef QD_FASTX_NT
+#define QD_FASTX_NT QD_FAST_NT /* exact-width rows: their lines are touched by two load instructions */
+#endif
 #ifndef QD_FAST_PREFETCH
 #define QD_FAST_PREFETCH 1 /* register double buffering of tiles       */
 #endif

@@ -344,7 +344,7 @@ __device__ __forceinline__ U128 ld16s(const uint8_t* p) {
 // 16 bytes from a 4-byte-aligned address (global_load_dwordx4 needs dword alignment only)
 __device__ __forceinline__ U128 ld16u(const uint8_t* p) {
     typedef unsigned int v4u32a __attribute__((ext_vector_type(4), aligned(4)));
-#if QD_FAST_NT
+#if QD_FASTX_NT
     const v4u32a v = __builtin_nontemporal_load(reinterpret_cast<const v4u32a*>(p));
 #else
     const v4u32a v = *reinterpret_cast<const v4u32a*>(p);
