@@ -331,23 +331,34 @@ def main():
     # the barriers and the max-over-ranks of the timing.  Rehearsals with several ranks on one GPU
     # (QUADE_BENCH_BACKEND=gloo; RCCL wants one rank per device) sum through gloo instead.
     comm = None
+    comm_note = None
 
     def reduce_counts():
         if comm is not None:
             return comm.reduce_counts()          # reduce of the partial rows + RCCL all-reduce + D2H
         c = eng.counts()
-        if dist and world > 1:                   # rehearsal transport
+        if dist and world > 1:                   # rehearsal transport (gloo), or torch's RCCL group (see comm_note)
             t = torch.from_numpy(c.astype(np.int64))
+            if backend == "nccl":
+                t = t.cuda()
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            c = t.numpy().astype(np.uint64)
+            c = t.cpu().numpy().astype(np.uint64)
         return c
 
     if dist:
         with stdout_to_stderr():
             if backend == "nccl":
-                box = [comm_unique_id() if rank == 0 else None]
+                # every rank must take the same branch: agree on success before the first collective
+                try:
+                    box = [comm_unique_id() if rank == 0 else None]
+                except Exception as e:  # librccl not loadable through the library: say so, measure with torch's
+                    box = ["qd_comm_unique_id failed: %r" % (e,)]
                 dist.broadcast_object_list(box, src=0)
-                comm = Comm.rank(eng, world, rank, box[0])
+                if isinstance(box[0], bytes):
+                    comm = Comm.rank(eng, world, rank, box[0])
+                else:
+                    comm_note = box[0]
+                    log("[rank %d] %s -- counts go through torch.distributed's RCCL group instead" % (rank, comm_note))
             reduce_counts()  # warm the communicator up too: its first collective builds the rings
             warm = torch.zeros(1, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(warm, op=dist.ReduceOp.MAX)
@@ -450,6 +461,7 @@ def main():
                      "kernel_ms": kern_ms_mean, "algorithmic_bytes_per_pair": algo_bytes},
         "world": comm_world,  # as the communicator reports it (1 = no process group)
         "count_reduce": {"backend": ("rccl via qd_reduce_counts" if comm is not None else backend) if dist else None,
+                         "note": comm_note,
                          "ms_max_over_ranks": max(r["allreduce_ms"] for r in per_rank) if dist else 0.0},
         "ranks": per_rank,
         "launched_by": "self-spawn" if os.environ.get("QUADE_BENCH_SPAWNED") else

@@ -19,7 +19,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else default_n[cfg]
 blocks = [int(x) for x in os.environ.get("TUNE_BLOCKS", "0,256,512,1024").split(",")]
 wgs = [int(x) for x in os.environ.get("TUNE_WG", "0,4,16,64").split(",")]
 libs = [LIB_PATH] + [p for p in os.environ.get("TUNE_LIBS", "").split(",") if p]
-rounds, reps = 3, 4
+rounds, reps = int(os.environ.get("TUNE_ROUNDS", "3")), 4
 
 engines, loads = [], {}
 for lp in libs:
