@@ -32,7 +32,8 @@ pairs = bench["config"]["pairs_per_gpu"] if bench else None
 
 # 1. per-dispatch durations of the demux kernel: all launches and the steady state (first WARM dropped)
 out = {"config": cfg, "n_pairs": pairs, "algorithmic_bytes_per_pair": ALGO[cfg]}
-trace = glob.glob(os.path.join(src, "*_kernel_trace.csv"))
+newest = lambda pat: sorted(glob.glob(os.path.join(src, pat)), key=os.path.getmtime, reverse=True)  # noqa: E731 (merged runs pile up)
+trace = newest("*_kernel_trace.csv")
 if trace:
     durs, name = [], None
     for r in csv.DictReader(open(trace[0])):
@@ -50,7 +51,7 @@ if trace:
         out["kernel_min_ns"], out["kernel_max_ns"] = min(durs), max(durs)
         out["steady_definition"] = "launches %d.. of the rocprofv3 --kernel-trace run (the first %d are bench.py's untimed warm-up: clock ramp)" % (WARM, WARM)
         print("kernel %s: %d launches, avg all %.1f us, steady %.1f us" % (name[:50], len(durs), out["kernel_avg_ns_all_launches"] / 1e3, out["kernel_avg_ns_steady"] / 1e3))
-stats = glob.glob(os.path.join(src, "*_kernel_stats.csv"))
+stats = newest("*_kernel_stats.csv")
 if stats:
     rows = list(csv.reader(open(stats[0])))
     ours = [r for r in rows[1:] if "demux_" in r[0] or "reduce_partials" in r[0]]
