@@ -708,7 +708,9 @@ static int submit_impl(qd_ctx* c, int32_t slot, int64_t n, int32_t has_len, cons
             if (m == 0) has_len = 0;  // every short read lies beyond the batch
         }
     }
-    const bool listed = has_len && m > 0 && m <= n / 2;  // a listed minority: only their lengths travel, not the len rows
+    // a listed minority on a fast-eligible plan: only their lengths travel, not the len rows (the generic
+    // kernel, which reads a length per pair, gets the rows)
+    const bool listed = has_len && m > 0 && m <= n / 2 && pick_kernel(c, false) == K_FAST;
     qd_rows rows{};
     for (int k = 0; k < L.n_streams; ++k) {
         HIPCHK(c, hipMemcpyAsync(s.d.seq[k], s.h.seq[k], (size_t)n * L.seq_stride[k], hipMemcpyHostToDevice, s.stream));

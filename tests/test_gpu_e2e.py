@@ -165,6 +165,9 @@ SCENARIOS = {
     # "all": every device the library sees (one on this box)
     "devices_all": dict(dual=False, idx_len=8, pos=((1, 8), None, None, None), minq=20, gpu="[gpu]\ndevices : all\n"),
     "wide_window_generic": dict(dual=False, idx_len=24, pos=((1, 20), None, (21, 24), None), minq=10),
+    # truncated reads on a plan the fast kernel does not take: the generic kernel needs every read's length
+    "wide_window_truncated": dict(dual=False, idx_len=24, pos=((1, 20), None, (21, 24), None), minq=10, trunc=True,
+                                  gpu="[gpu]\nbatch_pairs : 64\n"),
 }
 
 
