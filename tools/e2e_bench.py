@@ -3,7 +3,7 @@
 the CLI driver.  Host bound (gunzip, scan, format, gzip); printed as one JSON line.
 usage: python tools/e2e_bench.py [pairs] [gzip level] [chunks] [--single-member | --members] [--ranks N]
 input files: BGZF (bgzip layout) by default, --members = 8 MB gzip members, --single-member = one gzip member
-env: E2E_WORKERS (chunk_workers), E2E_IO_THREADS, QUADE_PROFILE=1 (stage timers)"""
+env: E2E_WORKERS (chunk_workers), E2E_IO_THREADS, E2E_SAMPLES (96), E2E_BATCH (1000000), QUADE_PROFILE=1 (stage timers)"""
 import json
 import os
 import shutil
@@ -25,14 +25,16 @@ fmt = 0 if single else ((8 << 20) if "--members" in sys.argv else "bgzf")
 ranks = int(sys.argv[sys.argv.index("--ranks") + 1]) if "--ranks" in sys.argv else 1
 workers = int(os.environ.get("E2E_WORKERS", "1"))
 io_thr = int(os.environ.get("E2E_IO_THREADS", "0"))
+n_samples = int(os.environ.get("E2E_SAMPLES", "96"))
+batch = int(os.environ.get("E2E_BATCH", "1000000"))
 work = tempfile.mkdtemp(prefix="quade_e2e_")
 try:
     t0 = time.perf_counter()
-    paths, bcs = synth.write_fastq_dataset(work, n, member_bytes=fmt)
+    paths, bcs = synth.write_fastq_dataset(work, n, n_samples=n_samples, member_bytes=fmt)
     t_gen = time.perf_counter() - t0
     conf = os.path.join(work, "conf.txt")
-    synth.write_conf(conf, paths, bcs, n_chunks, gpu="[gpu]\nbatch_pairs : 1000000\ngzip_level : %d\nchunk_workers : %d\nio_threads : %d\n"
-                     % (level, workers, io_thr))
+    synth.write_conf(conf, paths, bcs, n_chunks, gpu="[gpu]\nbatch_pairs : %d\ngzip_level : %d\nchunk_workers : %d\nio_threads : %d\n"
+                     % (batch, level, workers, io_thr))
     out = os.path.join(work, "out")
     os.mkdir(out)
     os.chdir(out)
@@ -57,7 +59,7 @@ try:
     from quade_amd.fastq_writer import host_cores, io_backend, io_threads
     print(json.dumps({"mode": "end-to-end fastq.gz -> fastq.gz", "chunks": n_chunks, "pairs": n * n_chunks, "seconds": dt,
                       "pairs_per_s": n * n_chunks / dt, "gzip_level": level, "counts": counts, "chunk_workers": workers,
-                      "ranks": ranks, "input": {0: "single gzip member", "bgzf": "BGZF"}.get(fmt, "8 MB gzip members"), "gzip_backend": io_backend(),
+                      "ranks": ranks, "samples": n_samples, "batch_pairs": batch, "input": {0: "single gzip member", "bgzf": "BGZF"}.get(fmt, "8 MB gzip members"), "gzip_backend": io_backend(),
                       "io_threads": io_threads(), "host_cores": host_cores(), "host_logical_cpus": os.cpu_count(), "dataset_seconds": round(t_gen, 1)}))
 finally:
     os.chdir("/")
