@@ -21,6 +21,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m quade_amd.launch")
     ap.add_argument("-n", "--nproc", type=int, required=True, help="number of ranks = GPUs")
     ap.add_argument("-c", dest="conf_file", required=True, help="configuration file (as for Quade.py -c)")
+    ap.add_argument("--module", default="quade_amd.quade", help="module run by every rank (default: the command line driver)")
     args = ap.parse_args(argv)
     token = uuid.uuid4().hex[:16]
     procs = []
@@ -28,7 +29,7 @@ def main(argv=None):
         env = dict(os.environ, QUADE_RANK=str(r), QUADE_WORLD=str(args.nproc), QUADE_LOCAL_RANK=str(r),
                    QUADE_RUN_TOKEN=token)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, "-m", "quade_amd.quade", "-c", args.conf_file], env=env))
+        procs.append(subprocess.Popen([sys.executable, "-m", args.module, "-c", args.conf_file], env=env))
     rc = 0
     live = list(procs)
     while live:

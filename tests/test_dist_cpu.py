@@ -98,3 +98,25 @@ def test_merge_parts_keeps_chunk_order_and_lazy_creation(tmp_path):
     assert rd("A_pass_R1.fastq.gz") == b"a0a2a3"
     assert rd("Undetermined_R1.fastq.gz") == b"u0u3"
     assert rd("B_fail_R1.fastq.gz") == b"b2"
+
+
+def test_launcher_tears_the_job_down_when_a_rank_fails(tmp_path):
+    """quade_amd.launch: one process per rank with QUADE_RANK / QUADE_WORLD / a shared run token; when one
+    rank exits non-zero the others are terminated (they would otherwise wait for it in the count
+    all-reduce) and the launcher returns that rank's code."""
+    import time
+    mod = tmp_path / "fake_rank.py"
+    mod.write_text(
+        "import os, sys, time\n"
+        "r, w = int(os.environ['QUADE_RANK']), int(os.environ['QUADE_WORLD'])\n"
+        "open(os.path.join(os.path.dirname(__file__), 'seen.%d' % r), 'w').write(os.environ['QUADE_RUN_TOKEN'] + ' %d' % w)\n"
+        "if r == 1:\n"
+        "    time.sleep(0.5); sys.exit(7)\n"
+        "time.sleep(120)\n")
+    env = dict(os.environ, PYTHONPATH=str(tmp_path) + os.pathsep + ROOT)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "quade_amd.launch", "-n", "3", "-c", "unused.txt", "--module", "fake_rank"],
+                       env=env, capture_output=True, text=True, timeout=100)
+    assert r.returncode == 7 and time.time() - t0 < 60
+    seen = [(tmp_path / ("seen.%d" % i)).read_text().split() for i in range(3)]
+    assert len({s[0] for s in seen}) == 1 and all(s[1] == "3" for s in seen)
