@@ -21,8 +21,13 @@
 //     rows are summed when the host asks for the counts.
 //   * outputs: routing codes as coalesced write-through dword stores; molecular bytes staged per
 //     wave through LDS and written as 16-byte pieces.
+//   * static row shapes: the common layouts (barcode at the window start, molecular index behind it)
+//     are instantiated with their slice positions as compile-time constants -- the generic code kept
+//     ~100 scalars live and spilled them through VGPR lanes.
 //   * demux_generic: any stride, optional per-read lengths (truncated index reads), barcodes up to
 //     32 bytes, table in global memory (L2 resident).  Correctness path.
+//   * demux_fixup: the listed short reads of a batch redone with the generic semantics after a fast
+//     launch (one short read no longer sends its batch to the generic kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -701,8 +706,8 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
 // ------------------------------------------------------------------------------------------------
 // Generic path: one pair per lane, byte-granular, per-read lengths honoured (Python slice clamping
 // of a short index read: src/Quade.py:217-218 on a read shorter than `end`).  generic_pair() is the
-// whole of it for one pair; it serves the generic kernel (any plan inside the envelope), the tail
-// pairs of the wave kernel and the exception pairs (short reads) redone after a fast launch.
+// whole of it for one pair; it serves the generic kernel (any plan inside the envelope) and the
+// exception pairs (short reads) redone after a fast launch.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
