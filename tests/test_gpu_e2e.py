@@ -361,3 +361,45 @@ def test_random_conf_end_to_end_fuzz(tmp_path):
         _compare_dirs(str(my_dir), str(ref_dir))
         seen += np.array(sset.counts()[:4])
     assert seen[1] > 0 and seen[2] > 0 and seen[3] > 0, seen  # passes, fails and undetermined all occurred
+
+
+def test_rccl_reduce_in_a_process_without_torch():
+    """The product path never imports torch: a fresh interpreter creates a context, a communicator
+    (librccl bound by the library itself) and reduces the counters -- with torch absent from
+    sys.modules from start to end."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+from quade_amd import hip_backend as hb
+plan = hb.make_plan(True, 25, (0, 8), (0, 8))
+with hb.Engine(0) as e:
+    lay = e.set_plan(plan)
+    e.set_barcodes(["ACGTACGTTTTTCCCC", "GGGGGGGGAAAAAAAA"])
+    e.slots_create(1, 1000)
+    v = e.slot(0)
+    reads = [[b"ACGTACGT", b"GGGGGGGG", b"NNNNNNNN"] * 100, [b"TTTTCCCC", b"AAAAAAAA", b"TTTTCCCC"] * 100]
+    for k in range(2):
+        s, q, l, full = hb.pack_index_reads(lay, k, reads[k], [b"IIIIIIII"] * 300)
+        assert full
+        v["seq"][k][:300] = s
+        v["qual"][k][:300] = q
+    e.submit(0, 300)
+    e.wait(0)
+    assert v["codes"][:3].tolist() == [0, 2, 0xFFFF], v["codes"][:3].tolist()
+    comm = hb.Comm.local([e])
+    c = comm.reduce_counts()
+    comm.close()
+    uid = hb.comm_unique_id()
+    comm = hb.Comm.rank(e, 1, 0, uid)
+    c2 = comm.reduce_counts()
+    comm.close()
+    assert c.tolist() == c2.tolist() == e.counts().tolist(), (c.tolist(), c2.tolist())
+    assert int(c[0]) == 300 and sorted(c.tolist()) == [0, 0, 0, 100, 100, 100, 200, 300], c.tolist()
+assert "torch" not in sys.modules
+print("ok")
+''' % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
