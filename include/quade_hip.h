@@ -160,7 +160,10 @@ int qd_kernel_kind(const qd_ctx* ctx, int has_len);
  *   "fast_block"              0 = automatic (default), 256 / 512 / 1024 threads per workgroup
  *   "mol_strips"              1 = stage molecular bytes through LDS for 16-byte stores (default), 0 = off
  *   "force_generic"           1 = always launch the generic kernel
- *   "kernel"                  0 = automatic (default), 1 = fast (when the plan is eligible), 2 = generic */
+ *   "kernel"                  0 = automatic (default), 1 = fast (when the plan is eligible), 2 = generic
+ *   "fold_pairs"              the device counts into 32-bit per-workgroup rows that are folded into 64-bit totals
+ *                             before this many pairs have been launched since the last fold (default and
+ *                             maximum 2^32 - 1; tests lower it) */
 int qd_set_option(qd_ctx* ctx, const char* name, int64_t value);
 
 /* ---- counters: replace the class counters of src/Sample.py:32,144 and feed Sample.REPORT ---------

@@ -78,11 +78,15 @@ struct qd_ctx {
     std::vector<std::pair<hipStream_t, hipEvent_t>> tracked;
 
     // counters
-    u64* d_partial = nullptr;
+    qd_row_t* d_partial = nullptr;  // [partial_rows][cnt_stride] 32-bit rows the kernels flush into
+    u64* d_acc = nullptr;      // [cnt_stride] 64-bit totals: rows folded so far + demux_fixup's signed moves
     u64* d_counts = nullptr;   // [cnt_stride + 4]: 2S+1 counters, then TOTAL at [cnt_stride] (reduce scratch)
     u64* d_total = nullptr;    // all-reduce result, same shape
     uint32_t partial_rows = 0, cnt_stride = 0;
     uint64_t total_pairs = 0;
+    uint64_t pairs_in_rows = 0;             // pairs launched since the rows were last folded (bounds every row counter)
+    uint64_t fold_limit = 0xFFFFFFFFull;    // option "fold_pairs": fold before pairs_in_rows would pass this
+    uint64_t folds = 0;
 
     std::vector<Slot> slots;
     int64_t slot_pairs = 0;
@@ -191,13 +195,16 @@ void free_table(qd_ctx* c) {
     if (c->d_bk32) (void)hipFree(c->d_bk32);
     if (c->d_blen) (void)hipFree(c->d_blen);
     if (c->d_partial) (void)hipFree(c->d_partial);
+    if (c->d_acc) (void)hipFree(c->d_acc);
+    c->d_acc = nullptr;
     if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->d_total) (void)hipFree(c->d_total);
     c->d_total = nullptr;
     c->d_slots_fast = c->d_slots_gen = nullptr;
     c->d_bk16 = c->d_bk32 = nullptr;
     c->d_blen = nullptr;
-    c->d_partial = c->d_counts = nullptr;
+    c->d_partial = nullptr;
+    c->d_counts = nullptr;
     c->have_table = false;
 }
 
@@ -266,12 +273,15 @@ int rebuild(qd_ctx* c) {
 
     c->cnt_stride = (uint32_t)((2 * S + 1 + 3) & ~3);
     // one counter row per workgroup (modulo), capped at 64 MiB of rows for very large tables
-    c->partial_rows = (uint32_t)std::max<size_t>(8, std::min<size_t>((size_t)c->cu * 8, ((size_t)64 << 20) / ((size_t)c->cnt_stride * 8)));
-    HIPCHK(c, hipMalloc(&c->d_partial, (size_t)c->partial_rows * c->cnt_stride * 8));
+    c->partial_rows = (uint32_t)std::max<size_t>(8, std::min<size_t>((size_t)c->cu * 8, ((size_t)64 << 20) / ((size_t)c->cnt_stride * sizeof(qd_row_t))));
+    HIPCHK(c, hipMalloc(&c->d_partial, (size_t)c->partial_rows * c->cnt_stride * sizeof(qd_row_t)));
+    HIPCHK(c, hipMalloc(&c->d_acc, (size_t)c->cnt_stride * 8));
     HIPCHK(c, hipMalloc(&c->d_counts, ((size_t)c->cnt_stride + 4) * 8));
     HIPCHK(c, hipMalloc(&c->d_total, ((size_t)c->cnt_stride + 4) * 8));
-    HIPCHK(c, hipMemset(c->d_partial, 0, (size_t)c->partial_rows * c->cnt_stride * 8));
+    HIPCHK(c, hipMemset(c->d_partial, 0, (size_t)c->partial_rows * c->cnt_stride * sizeof(qd_row_t)));
+    HIPCHK(c, hipMemset(c->d_acc, 0, (size_t)c->cnt_stride * 8));
     c->total_pairs = 0;
+    c->pairs_in_rows = 0;
     c->have_table = true;
     return QD_OK;
 }
@@ -281,6 +291,7 @@ void fill_params(const qd_ctx* c, DemuxParams& p, bool fast) {
     const qd_layout& L = c->lay;
     const qd_plan& P = c->plan;
     p.partial = c->d_partial;
+    p.adjust = c->d_acc;
     p.slots = fast ? c->d_slots_fast : c->d_slots_gen;
     p.slot_mask = fast ? c->mask_fast : c->mask_gen;
     p.seed = fast ? c->seed_fast : c->seed_gen;
@@ -327,6 +338,21 @@ int pick_kernel(const qd_ctx* c, bool dense_len) {
 
 // n_short < 0: no exception list (len rows, if any, apply to every pair -> generic kernel)
 // short_len: the listed reads' lengths, compact ([k][i] for short_idx[i]); NULL: rows->len holds them per pair
+// The kernels count into 32-bit rows.  A row counter never exceeds the number of pairs launched since the rows
+// were last emptied, so before that number could pass 2^32 - 1 the rows are added to the 64-bit totals and
+// zeroed: once per ~4.3 G pairs, behind everything the context has in flight (a host wait, ~tens of us).
+int fold_rows(qd_ctx* c) {
+    HIPCHK(c, wait_all(c));
+    const uint32_t ncnt = (uint32_t)(2 * c->S + 1);
+    hipError_t e = qd_launch_reduce(c->d_partial, c->partial_rows, c->cnt_stride, ncnt, c->d_acc, c->d_acc, c->stream);
+    if (e != hipSuccess) return fail(c, QD_ERR_HIP, std::string("fold launch: ") + hipGetErrorString(e));
+    HIPCHK(c, hipMemsetAsync(c->d_partial, 0, (size_t)c->partial_rows * c->cnt_stride * sizeof(qd_row_t), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pairs_in_rows = 0;
+    ++c->folds;
+    return QD_OK;
+}
+
 int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* mol, hipStream_t st,
            int64_t n_short = -1, const uint32_t* short_idx = nullptr, const uint8_t* const* short_len = nullptr) {
     const qd_layout& L = c->lay;
@@ -342,6 +368,10 @@ int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* 
     if (L.mol_width > 0 && (!mol || !aligned16(mol)))
         return fail(c, QD_ERR_INVALID, "mol buffer NULL or not 16-byte aligned");
     if (n > (int64_t)0xFFFFFFFF) return fail(c, QD_ERR_INVALID, "more than 2^32-1 pairs in one batch");
+    if (c->pairs_in_rows + (uint64_t)n > c->fold_limit) {
+        const int r = fold_rows(c);
+        if (r != QD_OK) return r;
+    }
     // a listed minority of short reads: fast kernel for everybody, the listed pairs redone afterwards
     const bool sparse = has_len && n_short >= 0 && n_short <= n / 2;
     const int kind = pick_kernel(c, has_len && !sparse);
@@ -372,6 +402,7 @@ int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* 
         if (e != hipSuccess) return fail(c, QD_ERR_HIP, std::string("fixup launch: ") + hipGetErrorString(e));
     }
     c->total_pairs += (uint64_t)n;
+    c->pairs_in_rows += (uint64_t)n;
     e = track(c, st);
     if (e != hipSuccess) return fail(c, QD_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e));
     return QD_OK;
@@ -526,6 +557,11 @@ int qd_set_option(qd_ctx* c, const char* name, int64_t value) {
         c->opt_kernel = (int)value;
         return QD_OK;
     }
+    if (!strcmp(name, "fold_pairs")) {  // test knob: fold the 32-bit counter rows this often (default 2^32 - 1)
+        if (value < 1 || value > (int64_t)0xFFFFFFFF) return fail(c, QD_ERR_INVALID, "fold_pairs must be 1..2^32-1");
+        c->fold_limit = (uint64_t)value;
+        return QD_OK;
+    }
     return fail(c, QD_ERR_INVALID, std::string("unknown option ") + name);
 }
 
@@ -560,7 +596,7 @@ static int counts_to_device(qd_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, join_into_own_stream(c));  // the reduce runs behind this context's launches, whatever stream they used
     const uint32_t ncnt = (uint32_t)(2 * c->S + 1);
-    hipError_t e = qd_launch_reduce(c->d_partial, c->partial_rows, c->cnt_stride, ncnt, c->d_counts, c->stream);
+    hipError_t e = qd_launch_reduce(c->d_partial, c->partial_rows, c->cnt_stride, ncnt, c->d_acc, c->d_counts, c->stream);
     if (e != hipSuccess) return fail(c, QD_ERR_HIP, std::string("reduce launch: ") + hipGetErrorString(e));
     HIPCHK(c, hipMemcpyAsync(c->d_counts + c->cnt_stride, &c->total_pairs, 8, hipMemcpyHostToDevice, c->stream));
     return QD_OK;
@@ -599,10 +635,12 @@ int qd_reset_counts(qd_ctx* c) {
     if (!c->have_table) return QD_OK;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, join_into_own_stream(c));
-    HIPCHK(c, hipMemsetAsync(c->d_partial, 0, (size_t)c->partial_rows * c->cnt_stride * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_partial, 0, (size_t)c->partial_rows * c->cnt_stride * sizeof(qd_row_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_acc, 0, (size_t)c->cnt_stride * 8, c->stream));
     HIPCHK(c, track(c, c->stream));  // later launches on other streams are not ordered behind this: wait here
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->total_pairs = 0;
+    c->pairs_in_rows = 0;
     return QD_OK;
 }
 

@@ -20,6 +20,24 @@
 #ifndef QD_FASTX_NT
 #define QD_FASTX_NT QD_FAST_NT /* exact-width rows: their lines are touched by two load instructions */
 #endif
+#ifndef QD_FASTX_TIGHT
+#define QD_FASTX_TIGHT 1   /* exact-width rows: a lane's second 16-byte block ends with its second row */
+#endif
+#ifndef QD_FAST_RUNS
+#define QD_FAST_RUNS 4     /* R > 0: a wave walks R * 128 consecutive pairs in R steps (see demux_fast)   */
+#endif
+#ifndef QD_FAST_SMALL_BATCH
+#define QD_FAST_SMALL_BATCH (16ll << 20) /* pairs: at most this many -> 256-thread workgroups               */
+#endif
+#ifndef QD_STATIC80_ALWAYS
+#define QD_STATIC80_ALWAYS 0 /* A/B: the static 8+0 shape for small tables too                              */
+#endif
+#ifndef QD_FAST_CODE_STRIPS
+#define QD_FAST_CODE_STRIPS 1 /* with runs: codes leave through the wave's LDS strip, 16 B per lane          */
+#endif
+#ifndef QD_FAST_GRID_FILLS
+#define QD_FAST_GRID_FILLS 1 /* automatic grid = a whole number of device fills                     */
+#endif
 #ifndef QD_FAST_PREFETCH
 #define QD_FAST_PREFETCH 1 /* register double buffering of tiles       */
 #endif
@@ -40,6 +58,13 @@
 #endif
 #define QD_GEN_BLOCK 256
 
+// counter rows the kernels flush into: 32-bit (folded into 64-bit totals by the host), or 64-bit for A/B builds
+#ifdef QD_ROWS64
+typedef unsigned long long qd_row_t;
+#else
+typedef uint32_t qd_row_t;
+#endif
+
 struct DemuxParams {
     // packed rows (device)
     const uint8_t* seq[2];
@@ -48,7 +73,8 @@ struct DemuxParams {
     // outputs (device)
     uint16_t* codes;
     uint8_t* mol;
-    uint64_t* partial;  // [partial_rows][cnt_stride] per-workgroup counter rows
+    qd_row_t* partial;  // [partial_rows][cnt_stride] per-workgroup counter rows (folded into 64-bit totals by the host)
+    uint64_t* adjust;   // [cnt_stride] the 64-bit totals: demux_fixup moves counts here
     // barcode table (device, global memory)
     const uint32_t* slots;              // [slot_mask+1]  (fingerprint<<16 | ordinal), 0xFFFFFFFF empty
     const uint64_t* bk16;     // [S][2]  canonical keys of the barcodes whose length == K
@@ -58,6 +84,7 @@ struct DemuxParams {
     uint32_t slot_mask, seed, n_samples, cnt_stride, partial_rows;
     uint32_t lds_bk_off, lds_hist_off;
     uint32_t mol_strip_off;  // LDS offset of the per-wave molecular staging strips, 0 = not used
+    uint32_t code_strip_off; // LDS offset of the per-wave code strips (wave runs), 0 = one dword store per step; set by the launcher
     uint32_t thr;  // minimal_qual + 33, compared with raw quality bytes
     int32_t n_streams, K, M;
     int32_t seq_stride[2], qual_stride[2];
@@ -91,5 +118,5 @@ hipError_t qd_launch_fast(const DemuxParams& p, QdKernelCache& cache, int cus, i
                           size_t lds_bytes, size_t strip_bytes_per_wave, hipStream_t st);
 hipError_t qd_launch_generic(const DemuxParams& p, int grid, hipStream_t st);
 hipError_t qd_launch_fixup(const DemuxParams& p, hipStream_t st);
-hipError_t qd_launch_reduce(const uint64_t* partial, uint32_t rows, uint32_t cnt_stride,
-                            uint32_t ncnt, uint64_t* out, hipStream_t st);
+hipError_t qd_launch_reduce(const qd_row_t* partial, uint32_t rows, uint32_t cnt_stride, uint32_t ncnt,
+                            const uint64_t* base, uint64_t* out, hipStream_t st);

@@ -159,6 +159,42 @@ __device__ __forceinline__ void st_wt(T* p, T v) {
 #endif
 }
 
+// Where a full tile's routing codes go.  With wave runs (QD_FAST_RUNS = R) a wave's R consecutive steps
+// produce R x 256 contiguous bytes of codes: each step drops its dword per lane into the wave's private LDS
+// strip and the last step writes the strip out 16 bytes per lane (R/4 KiB-sized write-through stores instead
+// of R quarter-KiB ones).  strip == nullptr: one dword store per lane per step.
+struct CodeOut {
+    uint32_t* strip;  // the wave's R * 64 dwords
+    int step;         // which quarter-KiB of the run this step is, 0 .. R-1, wave-uniform
+    bool last;        // the wave's R-th step on this run: write the strip out
+};
+template <int R>
+__device__ __forceinline__ void store_codes_full(const DemuxParams& p, const CodeOut& co, int64_t p0, uint32_t word) {
+    if (R >= 4 && co.strip) {
+        const uint32_t lane = threadIdx.x & 63u;
+        co.strip[co.step * 64 + lane] = word;
+        if (co.last) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+            uint16_t* run = p.codes + (p0 - 2 * (int64_t)lane - (int64_t)co.step * 128);  // the run's first pair
+#pragma unroll
+            for (int r = 0; r < R / 4; ++r) {
+                const v4u32 v = *reinterpret_cast<const v4u32*>(co.strip + (r * 64 + lane) * 4);
+                uint16_t* dst = run + (r * 64 + lane) * 8;
+#if QD_FAST_WT_STORES
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");  // pad: 5.7
+#else
+                *reinterpret_cast<v4u32*>(dst) = v;
+#endif
+            }
+            __builtin_amdgcn_wave_barrier();  // the strip is reused by the wave's next run
+        }
+    } else {
+        st_wt(reinterpret_cast<uint32_t*>(p.codes + p0), word);
+    }
+}
+
 __device__ __forceinline__ void store_mol(uint8_t* dst, u64 lo, u64 hi, int M) {
     // dst = mol + pair*M.  M is wave-uniform.
     if ((M & 3) == 0) {
@@ -435,6 +471,7 @@ struct Rows8 {
     typedef SH Shape;
     static constexpr int BLOCK = BLOCK_;
     static constexpr bool PREFETCH = QD_FAST_PREFETCH != 0;   // 64 B per lane per tile: double-buffer
+    static constexpr int RUNS = (DUAL && UNITS == 1) ? QD_FAST_RUNS : 0;  // wave runs, see demux_fast
     static constexpr bool GUARD_LAST = false;                 // aligned loads never leave the rows
     struct Tile {
         U128 s1[UNITS], q1[UNITS], s2[UNITS], q2[UNITS];
@@ -469,7 +506,7 @@ struct Rows8 {
     // a folded copy has to assume the younger loads are missing and waits for everything.
     template <bool FULL, int TAG>
     static __device__ __forceinline__ uint32_t compute(const Tile& T, const DemuxParams& p, const LdsTable& t,
-                                                       int64_t base, uint32_t tid) {
+                                                       int64_t base, uint32_t tid, const CodeOut& co) {
         asm volatile("; demux tile copy %0" ::"i"(TAG));
         const int64_t n = p.n;
         uint32_t undet = 0;
@@ -514,8 +551,10 @@ struct Rows8 {
             }
             undet += (c0 == QD_CODE_UNDET) + (two && c1 == QD_CODE_UNDET);
             if (FULL && p.mol_strip_off) {
-                st_wt(reinterpret_cast<uint32_t*>(p.codes + p0), c0 | (c1 << 16));
+                store_codes_full<RUNS>(p, co, p0, c0 | (c1 << 16));
                 store_mol_wave(p, t.strips + (tid >> 6) * (128 * p.M), p0, m0lo, m0hi, m1lo, m1hi);
+            } else if (FULL && p.M == 0) {
+                store_codes_full<RUNS>(p, co, p0, c0 | (c1 << 16));
             } else {
                 store_unit(p, p0, two, c0, c1, m0lo, m0hi, m1lo, m1hi);
             }
@@ -533,6 +572,7 @@ struct RowsX {
     // loads in flight pay: -3 % on cfg4), for dynamic shapes only while the tile is small
     static constexpr bool PREFETCH = QD_FAST_PREFETCH != 0 && (SH::STATIC || (NL1 + (DUAL ? NL2 : 0)) <= QD_FASTX_PREFETCH_MAXNL);
     static constexpr bool GUARD_LAST = true;  // a 16-byte load of the batch's last rows could pass the array end
+    static constexpr int RUNS = (DUAL && UNITS == 1) ? QD_FAST_RUNS : 0;
     struct Tile {
         u64 s1[UNITS][2 * NL1], q1[UNITS][2], s2[UNITS][2 * NL2], q2[UNITS][2];
     };
@@ -542,9 +582,14 @@ struct RowsX {
                                                       int64_t n) {
         const uint8_t* src = rows + p0 * stride;  // p0 even, stride even: 4-byte aligned
         if (FULL) {
+            // NL == 2: the second block ENDS with the lane's second row (bytes [2*stride-16, 2*stride)) instead
+            // of starting at byte 16: nothing beyond the lane's own 2*stride bytes is read, so a wave touches
+            // exactly the lines of its own span (with block 2 at byte 16 its last lane reached 32-2*stride
+            // bytes into the next wave's first line, which a non-temporal load fetches from HBM again:
+            // one line in fifteen on 14-byte rows). compute() reads row 1 at +tight_shift().
 #pragma unroll
             for (int j = 0; j < NL; ++j) {
-                const U128 v = ld16u(src + 16 * j);
+                const U128 v = ld16u(src + (NL == 2 && j == 1 && QD_FASTX_TIGHT ? 2 * stride - 16 : 16 * j));
                 w[2 * j] = v.lo;
                 w[2 * j + 1] = v.hi;
             }
@@ -572,7 +617,7 @@ struct RowsX {
 
     template <bool FULL, int TAG>
     static __device__ __forceinline__ uint32_t compute(const Tile& T, const DemuxParams& p, const LdsTable& t,
-                                                       int64_t base, uint32_t tid) {
+                                                       int64_t base, uint32_t tid, const CodeOut& co) {
         asm volatile("; demux tile copy %0" ::"i"(TAG));
         const int64_t n = p.n;
         uint32_t undet = 0;
@@ -586,7 +631,9 @@ struct RowsX {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {  // h = 0: pair p0 (row at byte 0), h = 1: pair p0+1 (row at byte stride)
                 if (h == 1 && !two) break;
-                const int r1 = h * p.seq_stride[0], r2 = h * p.seq_stride[1];
+                // row h of a stream inside its loaded block(s); a full tile's second block is end-aligned
+                const int r1 = h * (p.seq_stride[0] + ((FULL && QD_FASTX_TIGHT && NL1 == 2) ? 32 - 2 * p.seq_stride[0] : 0));
+                const int r2 = h * (p.seq_stride[1] + ((FULL && QD_FASTX_TIGHT && NL2 == 2) ? 32 - 2 * p.seq_stride[1] : 0));
                 const u64 k1 = take8(T.s1[u], r1 + p.idx_off[0]) & p.idx_mask[0];
                 const u64 m1 = take8(T.s1[u], r1 + p.mol_off[0]) & p.mol_mask[0];
                 const u64 q1 = take8(T.q1[u], h * p.qual_stride[0]) | ~p.idx_mask[0];  // beyond the slice: 0xFF
@@ -600,8 +647,10 @@ struct RowsX {
             }
             undet += (c[0] == QD_CODE_UNDET) + (two && c[1] == QD_CODE_UNDET);
             if (FULL && p.mol_strip_off) {
-                st_wt(reinterpret_cast<uint32_t*>(p.codes + p0), c[0] | (c[1] << 16));
+                store_codes_full<RUNS>(p, co, p0, c[0] | (c[1] << 16));
                 store_mol_wave(p, t.strips + (tid >> 6) * (128 * p.M), p0, m0lo, m0hi, m1lo, m1hi);
+            } else if (FULL && p.M == 0) {
+                store_codes_full<RUNS>(p, co, p0, c[0] | (c[1] << 16));
             } else {
                 store_unit(p, p0, two, c[0], c[1], m0lo, m0hi, m1lo, m1hi);
             }
@@ -636,9 +685,37 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
     // else, so HBM latency overlaps the staging of the table.
     const int64_t ntiles = (p.n + TILE - 1) / TILE;
     const int64_t nfull = OPS::GUARD_LAST ? (p.n >= 8 ? (p.n - 8) / TILE : 0) : p.n / TILE;
-    int64_t tile = blockIdx.x;
+    const int64_t G = gridDim.x;
+    // Work of this workgroup, numbered it = 0, 1, ...:
+    //  RUNS == 0: full tile blockIdx.x + it * G; lane tid takes the pairs tile * TILE + 2 * tid (+1);
+    //  RUNS == R: the full tiles are grouped R by R into super-tiles strided over the grid; inside one, WAVE w
+    //             owns the R * 128 consecutive pairs behind w * R * 128 and walks them in R steps, so a wave's
+    //             consecutive steps read (and write) consecutive KiBs.  Measured (profiles/r02_wave_runs_*.txt):
+    //             dual-index kernels -3..-6 % at the BASELINE batch sizes (>= 2 GB of rows), within +-1 % on
+    //             small batches; single-index kernels +20 % at every size -- so OPS::RUNS is R for the dual
+    //             forms and 0 for the single-index ones.
+    // base_of(it) + 2 * tid is the lane's first pair either way.
+    constexpr int RUNS = OPS::RUNS;
+    const int64_t nunits = RUNS ? nfull / (RUNS ? RUNS : 1) : nfull;  // super-tiles / tiles dealt out below
+    const int64_t wave128 = (int64_t)(tid >> 6) * 128;
+    auto live = [&](int64_t it) -> bool { return (int64_t)blockIdx.x + (RUNS ? it / (RUNS ? RUNS : 1) : it) * G < nunits; };
+    auto step_of = [&](int64_t it) -> int64_t { return RUNS ? it % (RUNS ? RUNS : 1) : 0; };
+    auto base_of = [&](int64_t it) -> int64_t {
+        if (!RUNS) return ((int64_t)blockIdx.x + it * G) * TILE;
+        const int64_t sup = (int64_t)blockIdx.x + it / (RUNS ? RUNS : 1) * G;
+        return sup * (RUNS * TILE) + wave128 * (RUNS - 1) + step_of(it) * 128;
+    };
+    // codes of full tiles: through the wave's LDS strip when the launch gave it one
+    uint32_t* const code_strip = (RUNS >= 4 && p.code_strip_off)
+                                     ? reinterpret_cast<uint32_t*>(lds_raw + p.code_strip_off) + (tid >> 6) * (RUNS * 64)
+                                     : nullptr;
+    auto out_of = [&](int64_t it) -> CodeOut {
+        return CodeOut{code_strip, (int)step_of(it), RUNS ? (it % (RUNS ? RUNS : 1)) == RUNS - 1 : false};
+    };
+    const CodeOut direct{nullptr, 0, false};
+    int64_t it = 0;
     TileT A, B;
-    if (tile < nfull) OPS::template load<true>(A, p, tile * TILE, tid);
+    if (live(0)) OPS::template load<true>(A, p, base_of(0), tid);
 
     // stage the table: global (L2) -> LDS, once per workgroup
     for (uint32_t i = tid; i <= p.slot_mask; i += BLOCK) slots[i] = p.slots[i];
@@ -654,38 +731,38 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
     // younger loads and consuming the older ones): with a join the compiler must assume the younger
     // loads may be missing and waits for them too (s_waitcnt vmcnt(3..0) instead of vmcnt(4+)),
     // which serialises the two tiles.
-    const int64_t G = gridDim.x;
-    if (tile < nfull) {
+    if (live(0)) {
         if (OPS::PREFETCH) {
             for (;;) {
-                const int64_t next = tile + G;
-                if (next >= nfull) {
-                    undet += OPS::template compute<true, 0>(A, p, t, tile * TILE, tid);
+                if (!live(it + 1)) {
+                    undet += OPS::template compute<true, 0>(A, p, t, base_of(it), tid, out_of(it));
                     break;
                 }
-                OPS::template load<true>(B, p, next * TILE, tid);
-                undet += OPS::template compute<true, 1>(A, p, t, tile * TILE, tid);
-                tile = next + G;
-                if (tile >= nfull) {
-                    undet += OPS::template compute<true, 2>(B, p, t, next * TILE, tid);
+                OPS::template load<true>(B, p, base_of(it + 1), tid);
+                undet += OPS::template compute<true, 1>(A, p, t, base_of(it), tid, out_of(it));
+                if (!live(it + 2)) {
+                    undet += OPS::template compute<true, 2>(B, p, t, base_of(it + 1), tid, out_of(it + 1));
                     break;
                 }
-                OPS::template load<true>(A, p, tile * TILE, tid);
-                undet += OPS::template compute<true, 3>(B, p, t, next * TILE, tid);
+                OPS::template load<true>(A, p, base_of(it + 2), tid);
+                undet += OPS::template compute<true, 3>(B, p, t, base_of(it + 1), tid, out_of(it + 1));
+                it += 2;
             }
         } else {
             for (;;) {
-                undet += OPS::template compute<true, 4>(A, p, t, tile * TILE, tid);
-                tile += G;
-                if (tile >= nfull) break;
-                OPS::template load<true>(A, p, tile * TILE, tid);
+                undet += OPS::template compute<true, 4>(A, p, t, base_of(it), tid, out_of(it));
+                ++it;
+                if (!live(it)) break;
+                OPS::template load<true>(A, p, base_of(it), tid);
             }
         }
     }
-    for (int64_t last = nfull; last < ntiles; ++last) {  // at most two lane-guarded tiles
+    // what is left: the lane-guarded tiles at the end of the batch (at most two) and, with runs, the full
+    // tiles behind the last whole super-tile
+    for (int64_t last = RUNS ? nunits * RUNS : nfull; last < ntiles; ++last) {
         if ((int64_t)blockIdx.x != last % G) continue;
         OPS::template load<false>(A, p, last * TILE, tid);
-        undet += OPS::template compute<false, 5>(A, p, t, last * TILE, tid);
+        undet += OPS::template compute<false, 5>(A, p, t, last * TILE, tid, direct);
     }
 
     // undetermined count: wavefront shuffle-reduce (64 lanes), then one LDS add per wave
@@ -694,11 +771,14 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
     if ((tid & 63) == 0 && undet) atomicAdd(&hist[2 * S], undet);
     __syncthreads();
     // flush this workgroup's histogram into its own row of the partial-count matrix
-    u64* row = p.partial + (size_t)(blockIdx.x % p.partial_rows) * p.cnt_stride;
+    // (32-bit rows: an atomic that leaves the L2 is counted -- and paid -- by its width, and a launch of the
+    // molecular-index config flushes ~3 M of them; the host folds the rows into 64-bit totals before any
+    // row counter could pass 2^32, see fold_rows() in quade_api.cpp)
+    qd_row_t* row = p.partial + (size_t)(blockIdx.x % p.partial_rows) * p.cnt_stride;
 #ifndef QD_ABLATE_FLUSH
     for (uint32_t i = tid; i < 2 * S + 1; i += BLOCK) {
         const uint32_t v = hist[i];
-        if (v) atomicAdd(reinterpret_cast<unsigned long long*>(&row[i]), (unsigned long long)v);
+        if (v) atomicAdd(&row[i], (qd_row_t)v);
     }
 #endif
 }
@@ -791,7 +871,7 @@ __global__ __launch_bounds__(QD_GEN_BLOCK) void demux_generic(const DemuxParams 
     uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw);
     const int64_t stride = (int64_t)gridDim.x * QD_GEN_BLOCK;
     const uint32_t S = p.n_samples;
-    u64* row = p.partial + (size_t)(blockIdx.x % p.partial_rows) * p.cnt_stride;
+    qd_row_t* row = p.partial + (size_t)(blockIdx.x % p.partial_rows) * p.cnt_stride;
     for (uint32_t i = threadIdx.x; i < hist_entries; i += QD_GEN_BLOCK) hist[i] = 0;
     if (hist_entries) __syncthreads();
     uint32_t undet = 0;
@@ -802,16 +882,16 @@ __global__ __launch_bounds__(QD_GEN_BLOCK) void demux_generic(const DemuxParams 
         else if (hist_entries)
             atomicAdd(&hist[code], 1u);
         else
-            atomicAdd(reinterpret_cast<unsigned long long*>(&row[code]), 1ull);
+            atomicAdd(&row[code], (qd_row_t)1);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) undet += __shfl_xor(undet, o, 64);
-    if ((threadIdx.x & 63) == 0 && undet) atomicAdd(reinterpret_cast<unsigned long long*>(&row[2 * S]), (unsigned long long)undet);
+    if ((threadIdx.x & 63) == 0 && undet) atomicAdd(&row[2 * S], (qd_row_t)undet);
     if (hist_entries) {
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < hist_entries; i += QD_GEN_BLOCK) {
             const uint32_t v = hist[i];
-            if (v) atomicAdd(reinterpret_cast<unsigned long long*>(&row[i]), (unsigned long long)v);
+            if (v) atomicAdd(&row[i], (qd_row_t)v);
         }
     }
 }
@@ -821,7 +901,7 @@ __global__ __launch_bounds__(QD_GEN_BLOCK) void demux_generic(const DemuxParams 
 // them with the generic semantics and move one count from the old code's counter to the new one.
 __global__ __launch_bounds__(QD_GEN_BLOCK) void demux_fixup(const DemuxParams p) {
     const uint32_t S = p.n_samples;
-    u64* row = p.partial + (size_t)(blockIdx.x % p.partial_rows) * p.cnt_stride;
+    u64* row = p.adjust;  // signed moves go to the 64-bit totals (a -1 in a 32-bit row of its own would not cancel)
     for (uint32_t i = blockIdx.x * QD_GEN_BLOCK + threadIdx.x; i < p.n_exc; i += gridDim.x * QD_GEN_BLOCK) {
         const int64_t r = p.exc[i];
         if (r >= p.n) continue;
@@ -835,11 +915,11 @@ __global__ __launch_bounds__(QD_GEN_BLOCK) void demux_fixup(const DemuxParams p)
     }
 }
 
-// sum the partial rows -> out[ncnt] (out zeroed by the caller).  blockIdx.y = a group of
+// add the partial rows to out[ncnt].  blockIdx.y = a group of
 // QD_REDUCE_ROWS rows, thread = one counter: row reads are coalesced across the threads and
 // independent across the rows; one 64-bit atomic per (row group, counter).
 #define QD_REDUCE_ROWS 32
-__global__ void reduce_partials(const u64* partial, uint32_t rows, uint32_t cnt_stride, uint32_t ncnt, u64* out) {
+__global__ void reduce_partials(const qd_row_t* partial, uint32_t rows, uint32_t cnt_stride, uint32_t ncnt, u64* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ncnt) return;
     const uint32_t r0 = blockIdx.y * QD_REDUCE_ROWS;
@@ -853,11 +933,18 @@ __global__ void reduce_partials(const u64* partial, uint32_t rows, uint32_t cnt_
 // lds = dynamic LDS of the launch (table image + histogram + molecular strips); table_lds = the part
 // every workgroup has to stage and flush (decides the grid form)
 template <class OPS>
-hipError_t launch_fast_t(const DemuxParams& p, QdKernelCache& cache, int cus, int wg_per_cu, size_t lds, size_t table_lds,
+hipError_t launch_fast_t(const DemuxParams& p_launch, QdKernelCache& cache, int cus, int wg_per_cu, size_t lds, size_t table_lds,
                          hipStream_t st) {
     constexpr int BLOCK = OPS::BLOCK;
     auto k = demux_fast<OPS>;
     // the attribute and the occupancy answer belong to (device, instantiation): kept in the context
+    // code strips (wave runs): R x 256 B per wave behind the table image and the molecular strips, while the
+    // table image is small (a large one leaves no room without giving up a co-resident workgroup)
+    DemuxParams p = p_launch;
+    if (OPS::RUNS >= 4 && QD_FAST_CODE_STRIPS && table_lds <= 24 * 1024) {
+        p.code_strip_off = (uint32_t)lds;
+        lds += (size_t)OPS::RUNS * 256 * (BLOCK / 64);
+    }
     QdKernelCache::Entry& ce = cache.entries[reinterpret_cast<const void*>(k)];
     if (!ce.attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
@@ -876,8 +963,9 @@ hipError_t launch_fast_t(const DemuxParams& p, QdKernelCache& cache, int cus, in
     const int64_t tile = (int64_t)BLOCK * 2 * QD_FAST_UNITS;
     const int64_t ntiles = (p.n + tile - 1) / tile;
     // Grid (automatic), from the measurements in profiles/r01_tune*_*.txt:
-    //  * small table image (<= 24 KB of LDS): oversubscribe -- up to 64 workgroups per CU, at least 8
-    //    tiles each (16 with molecular output); surplus workgroups start as earlier ones retire, which keeps the streams'
+    //  * small table image (<= 24 KB of LDS): oversubscribe -- up to 64 workgroups per CU, about 8 tiles
+    //    each, a whole number of device fills (the last fill of a grid that is not one runs partly empty:
+    //    7.45 fills cost what 8 do); surplus workgroups start as earlier ones retire, which keeps the streams'
     //    active window compact and evens out the tail; re-staging a few KB per workgroup is free;
     //  * large table image: a persistent grid of at most 2 co-resident workgroups per CU (staging
     //    tens of KB and flushing thousands of counters per workgroup is not free).
@@ -887,9 +975,17 @@ hipError_t launch_fast_t(const DemuxParams& p, QdKernelCache& cache, int cus, in
     } else if (table_lds > 24 * 1024) {
         grid = (int64_t)cus * (occ_blocks < 2 ? occ_blocks : 2);
     } else {
-        grid = ntiles / (p.M > 0 ? 16 : 8);  // molecular output: fewer, longer-lived workgroups measured better
+        const int64_t fill = (int64_t)cus * occ_blocks;  // workgroups resident at once
         const int64_t lo = (int64_t)cus * (occ_blocks < 2 ? occ_blocks : 2), hi = (int64_t)cus * 64;
-        if (grid < lo) grid = lo;
+        // the kernel deals out super-tiles of R tiles (wave runs): every workgroup the same number of them
+        // (a batch that fills the device about once must not leave one workgroup with an extra super-tile)
+        constexpr int64_t R = OPS::RUNS > 0 ? OPS::RUNS : 1;
+        const int64_t nunits = ntiles / R > 0 ? ntiles / R : 1;
+        int64_t per = R >= 8 ? 1 : 8 / R;  // about 8 tiles per workgroup
+        if ((nunits + per - 1) / per > hi) per = (nunits + hi - 1) / hi;
+        while (per > 1 && (nunits + per - 1) / per < lo) --per;
+        grid = (nunits + per - 1) / per;
+        if (QD_FAST_GRID_FILLS && grid >= 4 * fill) grid = (grid + fill / 2) / fill * fill;
         if (grid > hi) grid = hi;
     }
     if (grid > ntiles) grid = ntiles;
@@ -910,7 +1006,7 @@ hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, in
         // dual 8 + 8 bp index, no molecular index (BASELINE cfg3, cfg5): measured +2.6 % for the large-table
         // launch form (cfg5), -1.4 % for the small-table one (cfg3) -> used where it pays
         // (profiles/r02_static_vs_dynamic_shape_cfg{3,5}.txt)
-        if (StaticShape<8, 0>::matches(p) && table_lds > 24 * 1024)
+        if (StaticShape<8, 0>::matches(p) && (table_lds > 24 * 1024 || QD_STATIC80_ALWAYS))
             return launch_fast_t<Rows8<BLOCK, true, U, StaticShape<8, 0>>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
 #endif
         if (dual) return launch_fast_t<Rows8<BLOCK, true, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
@@ -940,10 +1036,13 @@ hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, in
 }  // namespace
 
 // Workgroup size: 512 threads; 1024 when the LDS image of the table is large (few workgroups fit a
-// CU then, and bigger ones keep the wave count up).  block_override: 0 = this rule.
+// CU then, and bigger ones keep the wave count up); 256 for batches of at most 16 M pairs with a small
+// table (a 4 M-pair batch is 3906 tiles of 512 threads: too few to fill 256 CUs evenly; measured -6 % at
+// 4 M pairs, -1.4 % at 10 M, nothing at 100 M: profiles/r02_small_batch_block.txt).  block_override: 0 = this rule.
 hipError_t qd_launch_fast(const DemuxParams& p, QdKernelCache& cache, int cus, int wg_per_cu, int block_override,
                           size_t lds_bytes, size_t strip_bytes_per_wave, hipStream_t st) {
-    int block = block_override ? block_override : (lds_bytes > QD_FAST_BIG_LDS ? 1024 : QD_FAST_BLOCK);
+    int block = block_override ? block_override
+                               : (lds_bytes > QD_FAST_BIG_LDS ? 1024 : (p.n <= QD_FAST_SMALL_BATCH ? 256 : QD_FAST_BLOCK));
     const size_t lds = lds_bytes + strip_bytes_per_wave * (size_t)(block / 64);  // table | histogram | strips
     if (block == 1024) return launch_fast_b<1024>(p, cache, cus, wg_per_cu, lds, lds_bytes, st);
     if (block == 256) return launch_fast_b<256>(p, cache, cus, wg_per_cu, lds, lds_bytes, st);
@@ -963,11 +1062,14 @@ hipError_t qd_launch_fixup(const DemuxParams& p, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t qd_launch_reduce(const uint64_t* partial, uint32_t rows, uint32_t cnt_stride,
-                            uint32_t ncnt, uint64_t* out, hipStream_t st) {
+// out[0..ncnt) = base[0..ncnt) + the sum of the partial rows (out == base: the rows are added in place)
+hipError_t qd_launch_reduce(const qd_row_t* partial, uint32_t rows, uint32_t cnt_stride, uint32_t ncnt,
+                            const uint64_t* base, uint64_t* out, hipStream_t st) {
     const int b = 256;
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)ncnt * 8, st);
-    if (e != hipSuccess) return e;
+    if (out != base) {
+        hipError_t e = hipMemcpyAsync(out, base, (size_t)ncnt * 8, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(reduce_partials, dim3((ncnt + b - 1) / b, (rows + QD_REDUCE_ROWS - 1) / QD_REDUCE_ROWS), dim3(b), 0,
                        st, partial, rows, cnt_stride, ncnt, out);
     return hipGetLastError();

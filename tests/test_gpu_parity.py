@@ -120,6 +120,17 @@ def test_sparse_short_reads_on_the_fast_kernels(torch_cuda, engine, name, n_shor
     if M:
         assert H.mol_rows_to_str(mol.cpu().numpy()) == mol_o
     assert (engine.counts() == counts_o).all()
+    # the device counts into 32-bit rows that the library folds into 64-bit totals before a row could wrap
+    # (every 2^32 - 1 pairs; here every launch): folded totals + the redone pairs' signed moves + fresh rows
+    engine.set_option("fold_pairs", 40000)
+    for rep in (2, 3):
+        engine.demux_device_ragged(w.n, [t.data_ptr() for t in d_seq], [t.data_ptr() for t in d_qual], codes.data_ptr(),
+                                   mol.data_ptr() if M else None, [t.data_ptr() for t in d_len], n_short,
+                                   d_short.data_ptr(), stream=0)
+        assert (engine.counts() == rep * counts_o).all(), rep
+    engine.reset_counts()
+    assert int(engine.counts().sum()) == 0
+    engine.set_option("fold_pairs", 0xFFFFFFFF)
 
 
 @pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"])
