@@ -321,10 +321,24 @@ def main():
                          stream=stream.cuda_stream)
 
     # Clock ramp: the device reaches its steady clock only after a few tens of back-to-back launches
-    # (20 steps after 3 warm-ups read 5 % slower than the steady state), so at least 50 untimed
-    # launches precede the timed region: the W warm-up steps, topped up when W < 50.
-    for _ in range(max(args.warmup, 50)):
-        step()
+    # (20 steps after 3 warm-ups read 5 % slower than the steady state; the first work on a freshly
+    # booted box has read 7 % slow for longer than that), so the untimed launches before the timed
+    # region are the W warm-up steps topped up to at least 50, continued in groups of 25 until a
+    # group's average launch time is within 1 % of the best group so far (at most 400 launches / 2 s).
+    untimed, best, t_warm = 0, None, time.perf_counter()
+    while True:
+        a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(25):
+            step()
+        z.record(stream)
+        z.synchronize()
+        untimed += 25
+        g = a.elapsed_time(z) / 25
+        settled = best is not None and g <= best * 1.01
+        best = g if best is None else min(best, g)
+        if untimed >= max(args.warmup, 50) and (settled or untimed >= 400 or time.perf_counter() - t_warm > 2.0):
+            break
     torch.cuda.synchronize()
     # The count reduce of the N > 1 path is the PRODUCT's: libquade_hip.so's own RCCL communicator
     # (qd_comm_create_rank / qd_reduce_counts); torch.distributed only carries its 128-byte unique id,
@@ -440,7 +454,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "untimed_launches": max(args.warmup, 50),  # W topped up to 50 for the clock ramp (outside the timed region)
+        "untimed_launches": untimed,  # W topped up until the launch time settles (>= 50; outside the timed region)
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",

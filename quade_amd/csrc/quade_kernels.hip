@@ -981,7 +981,11 @@ hipError_t launch_fast_t(const DemuxParams& p_launch, QdKernelCache& cache, int 
         // (a batch that fills the device about once must not leave one workgroup with an extra super-tile)
         constexpr int64_t R = OPS::RUNS > 0 ? OPS::RUNS : 1;
         const int64_t nunits = ntiles / R > 0 ? ntiles / R : 1;
-        int64_t per = R >= 8 ? 1 : 8 / R;  // about 8 tiles per workgroup
+        // about 8 tiles per workgroup; 16 with more than 128 samples: every workgroup ends with one atomic per
+        // non-zero counter, and with a few hundred samples twice as many workgroups put ~0.3 % more bytes on
+        // the fabric for no time gained (profiles/r02_cfg4_grid_with_runs.txt: 3840 .. 7680 workgroups within 0.7 %)
+        int64_t per = (p.n_samples > 128 ? 16 : 8) / R;
+        if (per < 1) per = 1;
         if ((nunits + per - 1) / per > hi) per = (nunits + hi - 1) / hi;
         while (per > 1 && (nunits + per - 1) / per < lo) --per;
         grid = (nunits + per - 1) / per;

@@ -27,7 +27,7 @@ def test_single_gpu_line():
         assert k in j, k
     assert (j["n_gpus"], j["steps"], j["warmup"], j["higher_is_better"], j["scaling"], j["vs_baseline"]) == \
         (1, 3, 1, True, "weak", None)
-    assert j["untimed_launches"] == 50 and j["world"] == 1 and j["launched_by"] == "single process"
+    assert 50 <= j["untimed_launches"] <= 400 and j["untimed_launches"] % 25 == 0 and j["world"] == 1 and j["launched_by"] == "single process"
     assert len(j["ranks"]) == 1 and j["ranks"][0]["device"] == 0
     assert j["dtype"] == "u8" and j["data"] == "synthetic" and j["unit"] == "read-pairs/s"
     assert "workload" in j["config"] and "model" not in j["config"]
