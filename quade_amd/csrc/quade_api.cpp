@@ -23,7 +23,8 @@ namespace {
 thread_local std::string g_create_error;
 
 struct Slot {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // kernel + downloads of this slot
+    hipEvent_t uploaded = nullptr;  // recorded on the context's upload stream behind this slot's H2D copies
     uint8_t* h_base = nullptr;  // pinned
     uint8_t* d_base = nullptr;
     qd_slot_buffers h{};        // host views
@@ -90,6 +91,11 @@ struct qd_ctx {
 
     std::vector<Slot> slots;
     int64_t slot_pairs = 0;
+    // One upload stream for all slots: their H2D copies run one after the other at the full link rate and a
+    // slot's kernel starts as soon as ITS rows have arrived.  With the uploads on the slots' own streams the
+    // copies of all submitted slots shared the link, finished together, and the link then idled while the
+    // kernels, the downloads and the host's next submits went by (48.7 of the link's 57 GB/s, tools/h2d_probe.py).
+    hipStream_t up_stream = nullptr;
 };
 
 namespace {
@@ -675,8 +681,10 @@ int qd_slots_create(qd_ctx* c, int32_t n_slots, int64_t max_pairs) {
     const size_t bytes = carve(probe, nullptr, c->lay, max_pairs);
     c->slots.resize((size_t)n_slots);
     c->slot_pairs = max_pairs;
+    HIPCHK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
     for (auto& s : c->slots) {
         HIPCHK(c, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
         HIPCHK(c, hipHostMalloc((void**)&s.h_base, bytes, hipHostMallocDefault));
         HIPCHK(c, hipMalloc((void**)&s.d_base, bytes));
         carve(s.h, s.h_base, c->lay, max_pairs);
@@ -696,12 +704,18 @@ int qd_slots_destroy(qd_ctx* c) {
             forget_stream(c, s.stream);
             (void)hipStreamDestroy(s.stream);
         }
+        if (s.uploaded) (void)hipEventDestroy(s.uploaded);
         if (s.h_base) (void)hipHostFree(s.h_base);
         if (s.d_base) (void)hipFree(s.d_base);
         if (s.h_short) (void)hipHostFree(s.h_short);
         if (s.d_short) (void)hipFree(s.d_short);
     }
     c->slots.clear();
+    if (c->up_stream) {
+        (void)hipStreamSynchronize(c->up_stream);
+        (void)hipStreamDestroy(c->up_stream);
+        c->up_stream = nullptr;
+    }
     return QD_OK;
 }
 
@@ -751,12 +765,12 @@ static int submit_impl(qd_ctx* c, int32_t slot, int64_t n, int32_t has_len, cons
     const bool listed = has_len && m > 0 && m <= n / 2 && pick_kernel(c, false) == K_FAST;
     qd_rows rows{};
     for (int k = 0; k < L.n_streams; ++k) {
-        HIPCHK(c, hipMemcpyAsync(s.d.seq[k], s.h.seq[k], (size_t)n * L.seq_stride[k], hipMemcpyHostToDevice, s.stream));
-        HIPCHK(c, hipMemcpyAsync(s.d.qual[k], s.h.qual[k], (size_t)n * L.qual_stride[k], hipMemcpyHostToDevice, s.stream));
+        HIPCHK(c, hipMemcpyAsync(s.d.seq[k], s.h.seq[k], (size_t)n * L.seq_stride[k], hipMemcpyHostToDevice, c->up_stream));
+        HIPCHK(c, hipMemcpyAsync(s.d.qual[k], s.h.qual[k], (size_t)n * L.qual_stride[k], hipMemcpyHostToDevice, c->up_stream));
         rows.seq[k] = s.d.seq[k];
         rows.qual[k] = s.d.qual[k];
         if (has_len && !listed) {
-            HIPCHK(c, hipMemcpyAsync(s.d.len[k], s.h.len[k], (size_t)n, hipMemcpyHostToDevice, s.stream));
+            HIPCHK(c, hipMemcpyAsync(s.d.len[k], s.h.len[k], (size_t)n, hipMemcpyHostToDevice, c->up_stream));
             rows.len[k] = s.d.len[k];
         }
     }
@@ -769,10 +783,12 @@ static int submit_impl(qd_ctx* c, int32_t slot, int64_t n, int32_t has_len, cons
             for (int64_t i = 0; i < m; ++i) hl[k * cap2 + (size_t)i] = s.h.len[k][s.h_short[i]];
             dlen[k] = dl + k * cap2;
         }
-        HIPCHK(c, hipMemcpyAsync(s.d_short, s.h_short, (size_t)m * 4, hipMemcpyHostToDevice, s.stream));
+        HIPCHK(c, hipMemcpyAsync(s.d_short, s.h_short, (size_t)m * 4, hipMemcpyHostToDevice, c->up_stream));
         for (int k = 0; k < L.n_streams; ++k)
-            HIPCHK(c, hipMemcpyAsync(dl + k * cap2, hl + k * cap2, (size_t)m, hipMemcpyHostToDevice, s.stream));
+            HIPCHK(c, hipMemcpyAsync(dl + k * cap2, hl + k * cap2, (size_t)m, hipMemcpyHostToDevice, c->up_stream));
     }
+    HIPCHK(c, hipEventRecord(s.uploaded, c->up_stream));
+    HIPCHK(c, hipStreamWaitEvent(s.stream, s.uploaded, 0));
     const int r = launch(c, n, &rows, s.d.codes, s.d.mol, s.stream, listed ? m : -1, s.d_short, listed ? dlen : nullptr);
     if (r != QD_OK) return r;
     HIPCHK(c, hipMemcpyAsync(s.h.codes, s.d.codes, (size_t)n * 2, hipMemcpyDeviceToHost, s.stream));
