@@ -186,9 +186,12 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
             from quade_amd.quade import Quade
             from quade_amd.sample import Sample
             with stdout_to_stderr():  # the driver and the native sink print progress lines; stdout carries one JSON line
+                c0 = os.times()
                 t0 = time.perf_counter()
                 Quade(conf_file=conf)()
                 dt = time.perf_counter() - t0
+                c1 = os.times()
+            cpu_s = (c1.user - c0.user) + (c1.system - c0.system)  # all threads of this process: readers, pool, main
             counts = Sample.COUNTS()[:4]
         finally:
             os.chdir(cwd)
@@ -199,6 +202,9 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
                 "samples": len(bcs), "gzip_backend": io_backend(), "io_threads": io_threads(), "host_cores": host_cores(),
                 "input_gz_bytes": in_bytes, "output_gz_bytes": out_bytes, "counts_total_pass_fail_undetermined": counts,
                 "dataset_seconds": t_gen,
+                # what bounds this rate: CPU seconds of all threads (inflate, scan, format, deflate) against wall x cores
+                "cpu_seconds": cpu_s, "cpu_seconds_per_M_pairs": cpu_s / (n / 1e6),
+                "core_utilisation": cpu_s / (dt * max(host_cores(), 1)),
                 "input_format": "BGZF (bgzip layout: 64 KiB gzip members, inflated in parallel)",
                 "what": "2x150 bp + dual 8 bp index fastq.gz -> %d-sample pass/fail/Undetermined fastq.gz + "
                         "report through quade_amd.quade (CLI driver), one process, one GPU" % len(bcs)}

@@ -46,21 +46,27 @@ try:
         r = subprocess.run([sys.executable, "-m", "quade_amd.launch", "-n", str(ranks), "-c", conf], env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         dt = time.perf_counter() - t0
+        cpu_s = None
         assert r.returncode == 0, r.stdout[-2000:]
         with open("Quade_report.csv") as fh:
             counts = [int(ln.split("\t")[1]) for ln in fh.read().split("\n")[2:6]]
     else:
         from quade_amd.quade import Quade
         from quade_amd.sample import Sample
+        c0 = os.times()
         t0 = time.perf_counter()
         Quade(conf_file=conf)()
         dt = time.perf_counter() - t0
+        c1 = os.times()
+        cpu_s = (c1.user - c0.user) + (c1.system - c0.system)  # every thread of this process (readers, pool, main)
         counts = Sample.COUNTS()[:4]
     from quade_amd.fastq_writer import host_cores, io_backend, io_threads
     print(json.dumps({"mode": "end-to-end fastq.gz -> fastq.gz", "chunks": n_chunks, "pairs": n * n_chunks, "seconds": dt,
                       "pairs_per_s": n * n_chunks / dt, "gzip_level": level, "counts": counts, "chunk_workers": workers,
                       "ranks": ranks, "samples": n_samples, "batch_pairs": batch, "input": {0: "single gzip member", "bgzf": "BGZF"}.get(fmt, "8 MB gzip members"), "gzip_backend": io_backend(),
-                      "io_threads": io_threads(), "host_cores": host_cores(), "host_logical_cpus": os.cpu_count(), "dataset_seconds": round(t_gen, 1)}))
+                      "io_threads": io_threads(), "host_cores": host_cores(), "host_logical_cpus": os.cpu_count(), "dataset_seconds": round(t_gen, 1),
+                      "cpu_seconds": cpu_s, "cpu_seconds_per_M_pairs": cpu_s / (n * n_chunks / 1e6) if cpu_s else None,
+                      "core_utilisation": cpu_s / (dt * host_cores()) if cpu_s else None}))
 finally:
     os.chdir("/")
     shutil.rmtree(work, ignore_errors=True)
