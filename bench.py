@@ -375,9 +375,26 @@ def main():
                     box = ["qd_comm_unique_id failed: %r" % (e,)]
                 dist.broadcast_object_list(box, src=0)
                 if isinstance(box[0], bytes):
-                    comm = Comm.rank(eng, world, rank, box[0])
+                    err = None
+                    try:
+                        comm = Comm.rank(eng, world, rank, box[0])
+                        comm.reduce_counts()  # its first collective builds the rings: a failure shows here
+                    except Exception as e:
+                        err = "rank %d: %r" % (rank, e)
+                    # all ranks or none: one that could not join must not leave the others inside a collective
+                    errs = [None] * world
+                    dist.all_gather_object(errs, err)
+                    if any(errs):
+                        if comm is not None:
+                            try:
+                                comm.close()
+                            except Exception:
+                                pass
+                            comm = None
+                        comm_note = "qd_comm_create_rank / qd_reduce_counts failed: " + "; ".join(e for e in errs if e)
                 else:
                     comm_note = box[0]
+                if comm_note:
                     log("[rank %d] %s -- counts go through torch.distributed's RCCL group instead" % (rank, comm_note))
             reduce_counts()  # warm the communicator up too: its first collective builds the rings
             warm = torch.zeros(1, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
