@@ -177,7 +177,7 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
         paths, bcs = synth.write_fastq_dataset(work, n_pairs)
         t_gen = time.perf_counter() - t0
         conf = os.path.join(work, "conf.txt")
-        synth.write_conf(conf, paths, bcs, n_chunks, gpu="[gpu]\nbatch_pairs : 1000000\ngzip_level : %d\n" % gzip_level)
+        synth.write_conf(conf, paths, bcs, n_chunks, gpu="[gpu]\ngzip_level : %d\n" % gzip_level)
         out = os.path.join(work, "out")
         os.mkdir(out)
         cwd = os.getcwd()

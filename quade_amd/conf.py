@@ -20,7 +20,7 @@ GPU_SECTION_HELP = """\
 Optional [gpu] section (not in Quade 0.3.2; a conf file without it runs with the defaults):
   [gpu]
   devices : 0            GPUs to use: "all" or a blank separated list of device ids
-  batch_pairs : 1000000  read pairs per device batch (host memory in flight grows with it: ~6 GB at 2x150 bp)
+  batch_pairs : 500000   read pairs per device batch (host memory in flight grows with it: ~3 GB at 2x150 bp)
   slots : 3              pinned staging slots per device (H2D / kernel / D2H overlap)
   gzip_level : 6         deflate level of the output fastq.gz files (0-9)
   chunk_workers : 1      chunks processed concurrently by host threads (outputs identical)
@@ -96,7 +96,7 @@ class QuadeConf(object):
             return default
 
         self.devices = opt("devices", "0", str).split()
-        self.batch_pairs = opt("batch_pairs", 1000000)
+        self.batch_pairs = opt("batch_pairs", 500000)
         self.slots = opt("slots", 3)
         self.gzip_level = opt("gzip_level", 6)
         self.chunk_workers = opt("chunk_workers", 1)

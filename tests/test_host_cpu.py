@@ -235,7 +235,7 @@ def test_conf_matches_oracle_and_template_schema(tmp_path, bundled_dir):
         assert (c.seq_R1, c.seq_R2, c.index_R1, c.index_R2) == (ref.seq_R1, ref.seq_R2, ref.index_R1, ref.index_R2)
         assert (c.write_pass, c.write_fail, c.write_undetermined) == (True, True, True)
         assert c.samples == ref.samples == [("S1", "ACAGACAG"), ("S2", "CTTGCTTG")]
-        assert (c.devices, c.batch_pairs, c.slots) == (["0"], 1000000, 3)
+        assert (c.devices, c.batch_pairs, c.slots) == (["0"], 500000, 3)
     p = mine.plan()
     assert (p.dual, p.min_qual, p.idx1_start, p.idx1_end, p.mol2_start, p.mol2_end) == (1, 25, 0, 4, 3, 6)
 

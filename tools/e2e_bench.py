@@ -3,7 +3,7 @@
 the CLI driver.  Host bound (gunzip, scan, format, gzip); printed as one JSON line.
 usage: python tools/e2e_bench.py [pairs] [gzip level] [chunks] [--single-member | --members] [--ranks N]
 input files: BGZF (bgzip layout) by default, --members = 8 MB gzip members, --single-member = one gzip member
-env: E2E_WORKERS (chunk_workers), E2E_IO_THREADS, E2E_SAMPLES (96), E2E_BATCH (1000000), QUADE_PROFILE=1 (stage timers)"""
+env: E2E_WORKERS (chunk_workers), E2E_IO_THREADS, E2E_SAMPLES (96), E2E_BATCH (500000), QUADE_PROFILE=1 (stage timers)"""
 import json
 import os
 import shutil
@@ -26,7 +26,7 @@ ranks = int(sys.argv[sys.argv.index("--ranks") + 1]) if "--ranks" in sys.argv el
 workers = int(os.environ.get("E2E_WORKERS", "1"))
 io_thr = int(os.environ.get("E2E_IO_THREADS", "0"))
 n_samples = int(os.environ.get("E2E_SAMPLES", "96"))
-batch = int(os.environ.get("E2E_BATCH", "1000000"))
+batch = int(os.environ.get("E2E_BATCH", "500000"))
 work = tempfile.mkdtemp(prefix="quade_e2e_")
 try:
     t0 = time.perf_counter()
