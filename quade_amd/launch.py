@@ -26,7 +26,7 @@ def main(argv=None):
     token = uuid.uuid4().hex[:16]
     procs = []
     for r in range(args.nproc):
-        env = dict(os.environ, QUADE_RANK=str(r), QUADE_WORLD=str(args.nproc), QUADE_LOCAL_RANK=str(r),
+        env = dict(os.environ, QUADE_RANK=str(r), QUADE_WORLD=str(args.nproc), QUADE_LOCAL_RANK=str(r), QUADE_LOCAL_WORLD=str(args.nproc),
                    QUADE_RUN_TOKEN=token)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, "-m", args.module, "-c", args.conf_file], env=env))

@@ -114,7 +114,14 @@ class Quade(object):
             devices = [os.environ.get("QUADE_DEVICE", str(local))]
         elif devices == ["all"]:
             devices = list(range(hb.device_count()))
-        io_threads(cf.io_threads)  # size of the library's gzip pool (before its first use)
+        # size of the library's gzip pool (before its first use); ranks of one node share its cores: each
+        # takes its share (LOCAL_WORLD_SIZE when the launcher says it, the whole world otherwise)
+        n_io = cf.io_threads
+        if n_io == 0 and self.world > 1:
+            from .fastq_writer import host_cores
+            on_node = int(os.environ.get("QUADE_LOCAL_WORLD", os.environ.get("LOCAL_WORLD_SIZE", str(self.world))))
+            n_io = max(2, host_cores() // max(1, min(on_node, self.world)))
+        io_threads(n_io)
         plan = cf.plan()
         # chunk workers (host threads) each drive their own contexts: a context is single-threaded
         n_chunks = len(cf.seq_R1)
