@@ -114,24 +114,106 @@ def clean_parts(outdir):
     shutil.rmtree(parts_root(outdir), ignore_errors=True)
 
 
-def merge_parts(outdir, n_chunks):
-    """Concatenates the per-chunk part files into the final outputs, in chunk order.  A gzip file may
-    consist of several members (the reference's own writer appends members,
-    src/FastqWriter.py:83-90), so the decompressed bytes equal those of a sequential run.  A final
-    file exists only if some chunk produced it (lazy creation, src/FastqWriter.py:55-57)."""
-    names = []
+def barrier_through_files(outdir, token, rank, world, name, timeout=3600.0):
+    """Every rank leaves a marker `name.<rank>` in the rendezvous directory and waits for all the others'.
+    (The count all-reduce is a barrier in RCCL runs; this one orders the steps around the parallel merge,
+    and everything in the rehearsal transport.)"""
+    d = rendezvous_dir(outdir, token)
+    os.makedirs(d, exist_ok=True)
+    mine = os.path.join(d, "%s.%d" % (name, rank))
+    with open(mine + ".tmp", "wb") as fh:
+        fh.write(b"1")
+    os.replace(mine + ".tmp", mine)
+    t0 = time.time()
+    for r in range(world):
+        p = os.path.join(d, "%s.%d" % (name, r))
+        while not os.path.exists(p):
+            if not os.path.isdir(d):
+                return  # rank 0 removes the directory after the run's last barrier: it had seen every marker
+            if time.time() - t0 > timeout:
+                raise RuntimeError("rank %d: rank %d never reached barrier %r" % (rank, r, name))
+            time.sleep(0.01)
+
+
+def _append_file(dst_fd, src_path):
+    """src -> the end of dst, in the kernel where the filesystem allows it (copy_file_range may share
+    extents instead of copying); falls back to read/write."""
+    with open(src_path, "rb") as src:
+        left = os.fstat(src.fileno()).st_size
+        use_cfr = hasattr(os, "copy_file_range")
+        while left > 0:
+            if use_cfr:
+                try:
+                    n = os.copy_file_range(src.fileno(), dst_fd, min(left, 1 << 30))
+                except OSError:  # EXDEV / ENOSYS / EINVAL (O_APPEND destinations on old kernels): plain copy
+                    use_cfr = False
+                    continue
+                if n == 0:
+                    use_cfr = False
+                    continue
+            else:
+                buf = src.read(min(left, 16 << 20))
+                if not buf:
+                    break
+                n = len(buf)
+                view = memoryview(buf)
+                while view:
+                    w = os.write(dst_fd, view)
+                    view = view[w:]
+            left -= n
+
+
+def part_names(outdir, n_chunks):
+    """Names of the final files some chunk produced (lazy creation, src/FastqWriter.py:55-57), sorted:
+    every rank computes the same list once all parts are complete."""
+    names = set()
     for c in range(n_chunks):
         d = part_dir(outdir, c)
         if os.path.isdir(d):
-            for f in sorted(os.listdir(d)):
-                if f.endswith(".fastq.gz") and f not in names:
-                    names.append(f)
-    for f in names:
-        with open(os.path.join(outdir, f), "wb") as out:
-            for c in range(n_chunks):
-                p = os.path.join(part_dir(outdir, c), f)
-                if os.path.exists(p):
-                    with open(p, "rb") as fh:
-                        shutil.copyfileobj(fh, out, 16 << 20)
+            names.update(f for f in os.listdir(d) if f.endswith(".fastq.gz"))
+    return sorted(names)
+
+
+def merge_parts(outdir, n_chunks, rank=0, world=1, threads=4, names=None):
+    """Concatenates the per-chunk part files into the final outputs, in chunk order.  A gzip file may
+    consist of several members (the reference's own writer appends members,
+    src/FastqWriter.py:83-90), so the decompressed bytes equal those of a sequential run.  A final
+    file exists only if some chunk produced it.  The final files are independent of each other: rank r
+    of `world` takes every world-th name, a few files at a time on threads (the copies are system calls).
+    The first part of a file is moved into place, the others appended.  `names`: every file name the run
+    can produce, the same list on every rank -- with several ranks it must not come from listing the part
+    directories, which other ranks are emptying at the same time (world == 1: listed when not given).
+    Returns the names this rank produced; the caller removes the parts (remove_parts) once every rank is
+    through."""
+    from concurrent.futures import ThreadPoolExecutor
+    if names is None:
+        assert world == 1, "several ranks need the same candidate list: pass names"
+        names = part_names(outdir, n_chunks)
+    mine = [f for i, f in enumerate(sorted(names)) if i % world == rank]
+
+    def one(f):
+        final = os.path.join(outdir, f)
+        parts = [p for p in (os.path.join(part_dir(outdir, c), f) for c in range(n_chunks)) if os.path.exists(p)]
+        if not parts:
+            return None  # no chunk routed a pair there: the file does not exist (lazy creation)
+        os.replace(parts[0], final)  # same filesystem: the parts live under the output directory
+        if len(parts) > 1:
+            fd = os.open(final, os.O_WRONLY)
+            try:
+                os.lseek(fd, 0, os.SEEK_END)
+                for p in parts[1:]:
+                    _append_file(fd, p)
+            finally:
+                os.close(fd)
+        return f
+
+    if threads > 1 and len(mine) > 1:
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            done = list(ex.map(one, mine))
+    else:
+        done = [one(f) for f in mine]
+    return [f for f in done if f]
+
+
+def remove_parts(outdir):
     shutil.rmtree(parts_root(outdir), ignore_errors=True)
-    return names

@@ -157,10 +157,20 @@ class Quade(object):
         for eng in self.engines:
             eng.close()
         self.engines = []
-        if self.parts and self.rank == 0:
-            # the all-reduce has returned here: every rank had closed its part files before it joined
+        if self.parts:
+            # every rank had closed its part files before it joined the count reduce; the RCCL all-reduce
+            # has returned on every rank here, the rehearsal transport needs a barrier of its own.  The
+            # final files are independent: every rank splices its share of them.
+            if self.world > 1 and self.comm is None:
+                dist.barrier_through_files(self.outdir, self.token, self.rank, self.world, "closed")
+            stems = [s.name + q for s in Sample.SAMPLE_LIST for q in ("_pass", "_fail")] + ["Undetermined"]
             with _timed("merge chunk parts"):
-                dist.merge_parts(self.outdir, n_chunks)
+                dist.merge_parts(self.outdir, n_chunks, self.rank, self.world,
+                                 names=[st + r + ".fastq.gz" for st in stems for r in ("_R1", "_R2")])
+            if self.world > 1:
+                dist.barrier_through_files(self.outdir, self.token, self.rank, self.world, "merged")
+            if self.rank == 0:
+                dist.remove_parts(self.outdir)
         if self.world > 1:
             if self.rank != 0:
                 return 0

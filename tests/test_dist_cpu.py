@@ -5,6 +5,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from quade_amd import synth
 from quade_amd.dist import shard_range
@@ -77,7 +78,7 @@ def test_two_rank_gloo_count_reduce(tmp_path):
 
 def test_merge_parts_keeps_chunk_order_and_lazy_creation(tmp_path):
     """Per-chunk part files -> final files: members concatenated in chunk order, a file exists only
-    if some chunk produced it, parts removed."""
+    if some chunk produced it, every rank splices its share of the files, parts removed afterwards."""
     import gzip
     from quade_amd.dist import chunk_owner, merge_parts, part_dir
     assert [chunk_owner(c, 3) for c in range(7)] == [0, 1, 2, 0, 1, 2, 0]
@@ -91,8 +92,20 @@ def test_merge_parts_keeps_chunk_order_and_lazy_creation(tmp_path):
         for f, data in files.items():
             with gzip.open(os.path.join(part_dir(out, c), f), "wb") as fh:
                 fh.write(data)
-    names = merge_parts(out, 4)
-    assert sorted(names) == ["A_pass_R1.fastq.gz", "B_fail_R1.fastq.gz", "Undetermined_R1.fastq.gz"]
+    # the final files are independent of each other: two ranks splice disjoint shares of them (in any order,
+    # here one after the other), then the parts go
+    from quade_amd.dist import part_names, remove_parts
+    assert part_names(out, 4) == ["A_pass_R1.fastq.gz", "B_fail_R1.fastq.gz", "Undetermined_R1.fastq.gz"]
+    # every rank gets the same candidate list (what the sample sheet can produce), never a listing of
+    # directories the other ranks are emptying
+    cand = ["%s_%s_R1.fastq.gz" % (s, q) for s in "AB" for q in ("pass", "fail")] + ["Undetermined_R1.fastq.gz"]
+    n1 = merge_parts(out, 4, rank=1, world=2, names=cand)
+    n0 = merge_parts(out, 4, rank=0, world=2, names=cand)
+    assert n0 == ["B_fail_R1.fastq.gz", "Undetermined_R1.fastq.gz"] and n1 == ["A_pass_R1.fastq.gz"]
+    with pytest.raises(AssertionError):
+        merge_parts(out, 4, rank=0, world=2)
+    remove_parts(out)
+    names = n0 + n1
     assert sorted(os.listdir(out)) == sorted(names)
     rd = lambda f: gzip.open(os.path.join(out, f)).read()  # noqa: E731
     assert rd("A_pass_R1.fastq.gz") == b"a0a2a3"
