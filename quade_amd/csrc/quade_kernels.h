@@ -29,6 +29,9 @@
 #ifndef QD_FAST_SMALL_BATCH
 #define QD_FAST_SMALL_BATCH (16ll << 20) /* pairs: at most this many -> 256-thread workgroups               */
 #endif
+#ifndef QD_GENERIC_BYTEWISE
+#define QD_GENERIC_BYTEWISE 0 /* A/B: the generic path's byte-at-a-time slice loops (r01)                   */
+#endif
 #ifndef QD_STATIC80_ALWAYS
 #define QD_STATIC80_ALWAYS 0 /* A/B: the static 8+0 shape for small tables too                              */
 #endif

@@ -793,6 +793,46 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// nbytes (0..32, per lane) bytes at p (any alignment) -> little-endian words w[0..3], zero padded.  wmax = the
+// wave-uniform upper bound of nbytes (the slice width of the plan; nbytes is smaller only for a short read).
+// Aligned dword loads, and NO per-lane branches around them: the number of loads follows from wmax alone
+// (a scalar condition), a lane that needs fewer words re-reads its last needed word instead of skipping --
+// with a guard per load every load sat in its own exec-masked block and their latencies added up (~10 us
+// per pair and lane).  No word is read that holds no byte of the lane's slice, so the end of an array is
+// passed by at most the 1-3 bytes that share a word (and a page) with its last byte.
+__device__ __forceinline__ void load_bytes32(const uint8_t* p, int nbytes, int wmax, u64 (&w)[4]) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    const int sh = (int)(a & 3), need = sh + nbytes;
+    const int ju = wmax > 0 ? (wmax + 6) >> 2 : 0;    // dwords that can hold 3 + wmax bytes (uniform)
+    const int jl = need > 0 ? (need - 1) >> 2 : 0;    // the lane's last needed dword
+    uint32_t d[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) d[j] = (j < ju) ? q[j < jl ? j : jl] : 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u64 lo = (u64)d[2 * i] | ((u64)d[2 * i + 1] << 32), nx = d[2 * i + 2];
+        const u64 v = sh ? (lo >> (8 * sh)) | (nx << (64 - 8 * sh)) : lo;
+        const int left = nbytes - 8 * i;  // wanted bytes of this word
+        w[i] = left >= 8 ? v : (left <= 0 ? 0 : v & ((1ull << (8 * left)) - 1));
+    }
+}
+
+// w |= v << (8 * off) over the 256 bits (off = 0..32 bytes; what leaves the top is dropped)
+__device__ __forceinline__ void or_shifted32(u64 (&w)[4], const u64 (&v)[4], int off) {
+    const int ws = off >> 3, bs = (off & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u64 cur = 0, prev = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cur = (j == i - ws) ? v[j] : cur;
+            prev = (j == i - ws - 1) ? v[j] : prev;
+        }
+        w[i] |= bs ? (cur << bs) | (prev >> (64 - bs)) : cur;
+    }
+}
+
 // Writes codes[r] (and mol[r]); returns the routing code.  Counters are the caller's business.
 // len0 / len1: the reads' lengths (0x7FFFFFFF = covers its window).
 __device__ __forceinline__ uint32_t generic_pair(const DemuxParams& p, int64_t r, int len0, int len1) {
@@ -812,6 +852,7 @@ __device__ __forceinline__ uint32_t generic_pair(const DemuxParams& p, int64_t r
     // canonical key: fused bytes, little-endian packed, zero padded
     u64 w[QD_KEY_WORDS] = {0, 0, 0, 0};
     uint32_t pass = 1;
+#if QD_GENERIC_BYTEWISE  // the r01 form: one global byte load per key byte and per quality byte
 #pragma unroll
     for (int i = 0; i < QD_MAX_KEY_BYTES; ++i) {
         if (i < klen) {
@@ -828,6 +869,27 @@ __device__ __forceinline__ uint32_t generic_pair(const DemuxParams& p, int64_t r
             pass &= (q >= p.thr) ? 1u : 0u;            // a5
         }
     }
+#else
+    // slices as words: aligned dword loads + byte shifts, SWAR fold (a3) and gate (a5) as in the fast kernels
+    {
+        int at = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k >= p.n_streams) break;
+            u64 v[4], qv[4];
+            load_bytes32(srow[k] + p.idx_off[k], a[k], p.idx_w[k], v);
+            load_bytes32(qrow[k], a[k], p.idx_w[k], qv);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = qd_fold8(v[i]);
+                const int left = a[k] - 8 * i;  // quality bytes of this word that count; the others read as 0xFF
+                pass &= qd_all_ge8(left >= 8 ? qv[i] : (left <= 0 ? ~0ull : qv[i] | (~0ull << (8 * left))), p.thr);
+            }
+            or_shifted32(w, v, at);
+            at += a[k];
+        }
+    }
+#endif
     // a4: probe the global table of every barcode
     uint32_t code = QD_CODE_UNDET;
     if (klen <= QD_MAX_KEY_BYTES) {
@@ -852,10 +914,32 @@ __device__ __forceinline__ uint32_t generic_pair(const DemuxParams& p, int64_t r
     // a2: molecular bytes, I1 part then I2 part, zero padded to M
     if (p.M > 0) {
         uint8_t* d = p.mol + r * p.M;
-        int o = 0;
-        for (int k = 0; k < p.n_streams; ++k)
-            for (int i = 0; i < ma[k]; ++i) d[o++] = srow[k][p.mol_off[k] + i];
-        for (; o < p.M; ++o) d[o] = 0;
+        if (QD_GENERIC_BYTEWISE || p.M > 32) {  // molecular slices may be as wide as the window (64 B each): bytes
+            int o = 0;
+            for (int k = 0; k < p.n_streams; ++k)
+                for (int i = 0; i < ma[k]; ++i) d[o++] = srow[k][p.mol_off[k] + i];
+            for (; o < p.M; ++o) d[o] = 0;
+            return code;
+        }
+        u64 m[4] = {0, 0, 0, 0};
+        int at = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k >= p.n_streams) break;
+            u64 v[4];
+            load_bytes32(srow[k] + p.mol_off[k], ma[k], p.mol_w[k], v);
+            or_shifted32(m, v, at);
+            at += ma[k];
+        }
+        if ((p.M & 3) == 0) {  // r * M is a multiple of 4 then: dword stores
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (4 * j < p.M) reinterpret_cast<uint32_t*>(d)[j] = (uint32_t)(m[j >> 1] >> (32 * (j & 1)));
+        } else {
+#pragma unroll
+            for (int o = 0; o < 32; ++o)
+                if (o < p.M) d[o] = (uint8_t)(m[o >> 3] >> (8 * (o & 7)));
+        }
     }
     return code;
 }
