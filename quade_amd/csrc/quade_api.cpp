@@ -62,9 +62,11 @@ struct qd_ctx {
     uint32_t* d_slots_gen = nullptr;
     u64* d_bk16 = nullptr;
     u64* d_bk32 = nullptr;
+    u64* d_bkv = nullptr;   // wide plans: per barcode its two slices as the kernel extracts them (confirmation compare)
     uint8_t* d_blen = nullptr;
     uint32_t mask_fast = 0, mask_gen = 0, seed_fast = 0, seed_gen = 0;
     bool fast_ok = false;
+    bool wide = false;      // the fast table holds nibble-packed keys (16 < K <= 32)
     uint32_t lds_bk_off = 0, lds_hist_off = 0, lds_strip_off = 0;
     size_t lds_bytes = 0;       // table image + histogram
     size_t lds_strip_bytes = 0; // per wave: 128*M bytes of molecular staging (M % 4 == 0), else 0
@@ -165,7 +167,8 @@ void canon(const uint8_t* b, int len, u64 w[QD_KEY_WORDS]) {
 // open-addressing table over the given barcode ordinals; picks the seed with the shortest
 // worst-case probe sequence.  Returns slots (size mask+1).
 std::vector<uint32_t> build_slots(const std::vector<int>& ids, const std::vector<u64>& keys32,
-                                  const std::vector<uint8_t>& blen, uint32_t& mask, uint32_t& seed) {
+                                  const std::vector<uint8_t>& blen, uint32_t& mask, uint32_t& seed,
+                                  const std::vector<u64>* packed16 = nullptr, uint32_t K = 0) {
     uint32_t m = 16;
     while (m < 4u * (uint32_t)ids.size()) m <<= 1;
     mask = m - 1;
@@ -175,7 +178,8 @@ std::vector<uint32_t> build_slots(const std::vector<int>& ids, const std::vector
         std::vector<uint32_t> t(m, QD_EMPTY_SLOT);
         uint32_t worst = 0;
         for (int id : ids) {
-            const uint32_t h = qd_hash_key(&keys32[(size_t)id * QD_KEY_WORDS], blen[id], sd);
+            const uint32_t h = packed16 ? qd_hash_wide((*packed16)[2 * (size_t)id], (*packed16)[2 * (size_t)id + 1], K, sd)
+                                        : qd_hash_key(&keys32[(size_t)id * QD_KEY_WORDS], blen[id], sd);
             uint32_t s = h & mask, probes = 1;
             while (t[s] != QD_EMPTY_SLOT) {
                 s = (s + 1) & mask;
@@ -199,6 +203,8 @@ void free_table(qd_ctx* c) {
     if (c->d_slots_gen) (void)hipFree(c->d_slots_gen);
     if (c->d_bk16) (void)hipFree(c->d_bk16);
     if (c->d_bk32) (void)hipFree(c->d_bk32);
+    if (c->d_bkv) (void)hipFree(c->d_bkv);
+    c->d_bkv = nullptr;
     if (c->d_blen) (void)hipFree(c->d_blen);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_acc) (void)hipFree(c->d_acc);
@@ -225,6 +231,18 @@ int rebuild(qd_ctx* c) {
     std::vector<uint8_t> blen(std::max(S, 1), 0);
     std::vector<int> ids_fast, ids_gen;
     std::map<std::string, int> seen;
+    // Wide plan: 16 < K <= 32 with every slice and window inside 16 bytes (so both index reads carry a part of
+    // the key) and at most 8 molecular bytes per read; its fast table is built over nibble-packed keys, which
+    // is injective only on the alphabet the reference admits (src/Sample.py:40,141): any K-long barcode with
+    // another byte sends the plan to the generic kernel.
+    const qd_layout& Lw = c->lay;
+    const int w1 = c->plan.idx1_end - c->plan.idx1_start, w2 = c->plan.dual ? c->plan.idx2_end - c->plan.idx2_start : 0;
+    bool wide = K > 16 && K <= 32 && Lw.n_streams == 2 && w1 <= 16 && w2 <= 16 && Lw.mol_width <= 16;
+    for (int k = 0; wide && k < Lw.n_streams; ++k) {
+        const int mw = (k == 0 ? c->plan.mol1_end - c->plan.mol1_start : c->plan.mol2_end - c->plan.mol2_start);
+        wide = Lw.seq_stride[k] <= 16 && Lw.qual_stride[k] <= 16 && mw <= 8;
+    }
+    std::vector<u64> kv((size_t)std::max(S, 1) * 4, 0);
     for (int i = 0; i < S; ++i) {
         const uint8_t* b = c->bc.data() + c->bc_off[i];
         const int len = c->bc_off[i + 1] - c->bc_off[i];
@@ -243,9 +261,25 @@ int rebuild(qd_ctx* c) {
             k16[2 * (size_t)i] = k32[(size_t)i * QD_KEY_WORDS];
             k16[2 * (size_t)i + 1] = k32[(size_t)i * QD_KEY_WORDS + 1];
             ids_fast.push_back(i);
+        } else if (len == K && wide) {
+            for (int j = 0; j < len; ++j)
+                if (!strchr("ACGTN", b[j]) || b[j] == 0) wide = false;
+            u64 s1[QD_KEY_WORDS], s2[QD_KEY_WORDS];
+            canon(b, w1, s1);           // the barcode's part in index read 1, then in index read 2
+            canon(b + w1, len - w1, s2);
+            u64* v = &kv[(size_t)i * 4];
+            v[0] = s1[0];
+            v[1] = s1[1];
+            v[2] = s2[0];
+            v[3] = s2[1];
+            qd_wide_key(v[0], v[1], v[2], v[3], w1, &k16[2 * (size_t)i], &k16[2 * (size_t)i + 1]);
+            ids_fast.push_back(i);
         }
     }
-    std::vector<uint32_t> sf = build_slots(ids_fast, k32, blen, c->mask_fast, c->seed_fast);
+    if (K > 16 && !wide) ids_fast.clear();
+    c->wide = wide;
+    std::vector<uint32_t> sf = wide ? build_slots(ids_fast, k32, blen, c->mask_fast, c->seed_fast, &k16, (uint32_t)K)
+                                    : build_slots(ids_fast, k32, blen, c->mask_fast, c->seed_fast);
     std::vector<uint32_t> sg = build_slots(ids_gen, k32, blen, c->mask_gen, c->seed_gen);
 
     HIPCHK(c, hipMalloc(&c->d_slots_fast, sf.size() * 4));
@@ -253,6 +287,8 @@ int rebuild(qd_ctx* c) {
     HIPCHK(c, hipMalloc(&c->d_bk16, k16.size() * 8));
     HIPCHK(c, hipMalloc(&c->d_bk32, k32.size() * 8));
     HIPCHK(c, hipMalloc(&c->d_blen, blen.size()));
+    HIPCHK(c, hipMalloc(&c->d_bkv, kv.size() * 8));
+    HIPCHK(c, hipMemcpy(c->d_bkv, kv.data(), kv.size() * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_slots_fast, sf.data(), sf.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_slots_gen, sg.data(), sg.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_bk16, k16.data(), k16.size() * 8, hipMemcpyHostToDevice));
@@ -275,7 +311,7 @@ int rebuild(qd_ctx* c) {
         const int mw = (k == 0 ? c->plan.mol1_end - c->plan.mol1_start : c->plan.mol2_end - c->plan.mol2_start);
         ok = ok && mw <= 8 && L.qual_width[k] <= 8;
     }
-    c->fast_ok = ok;
+    c->fast_ok = ok || (c->wide && c->lds_bytes <= 150 * 1024);
 
     c->cnt_stride = (uint32_t)((2 * S + 1 + 3) & ~3);
     // one counter row per workgroup (modulo), capped at 64 MiB of rows for very large tables
@@ -306,6 +342,8 @@ void fill_params(const qd_ctx* c, DemuxParams& p, bool fast) {
     p.gseed = c->seed_gen;
     p.bk16 = c->d_bk16;
     p.bk32 = c->d_bk32;
+    p.bkv = c->d_bkv;
+    p.wide = (fast && c->wide) ? 1 : 0;
     p.blen = c->d_blen;
     p.n_samples = (uint32_t)c->S;
     p.cnt_stride = c->cnt_stride;
@@ -330,6 +368,7 @@ void fill_params(const qd_ctx* c, DemuxParams& p, bool fast) {
         p.idx_off[k] = p.idx_w[k] ? is[k] - L.seq_off[k] : 0;
         p.mol_off[k] = p.mol_w[k] ? ms[k] - L.seq_off[k] : 0;
         p.idx_mask[k] = p.idx_w[k] >= 8 ? ~0ull : ((1ull << (8 * p.idx_w[k])) - 1);
+        p.idx_mask_hi[k] = p.idx_w[k] >= 16 ? ~0ull : (p.idx_w[k] > 8 ? ((1ull << (8 * (p.idx_w[k] - 8))) - 1) : 0);
         p.mol_mask[k] = p.mol_w[k] >= 8 ? ~0ull : ((1ull << (8 * p.mol_w[k])) - 1);
     }
 }

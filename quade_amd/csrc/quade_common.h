@@ -53,3 +53,38 @@ QD_HD uint32_t qd_hash_key(const uint64_t* w, uint32_t len, uint32_t seed) {
 }
 // slot entry = (fingerprint16 << 16) | sample ordinal; the fingerprint is the hash's top half.
 QD_HD uint32_t qd_slot_entry(uint32_t h, uint32_t ordinal) { return (h & 0xFFFF0000u) | ordinal; }
+
+// ---- wide keys (16 < K <= 32 bytes) on the 16-byte machinery ---------------------------------------------
+// Barcodes are words over {A,C,G,T,N} (src/Sample.py:40,141) and those five letters differ in their low
+// nibble (1, 3, 7, 4, 0xE): a K-byte barcode packs into K nibbles = at most 16 bytes, injectively.  A read's
+// folded slice is packed the same way and looked up in the table of packed barcodes; a hit names the only
+// barcode the read can equal, and a byte compare against that one barcode decides (a read byte outside the
+// alphabet shares its nibble with some letter -- 'Q' with 'A' -- so the packed hit alone proves nothing).
+// low nibbles of 8 packed bytes -> 32 bits (byte i -> bits 4i .. 4i+3)
+QD_HD uint32_t qd_pack_nib8(uint64_t x) {
+    x &= 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = x | (x >> 16);
+    return (uint32_t)x;
+}
+// packed key of the two index-read slices (each <= 16 folded bytes as lo/hi words, zero beyond its width;
+// w1 = bytes of the first slice): the first slice's nibbles, then the second's
+QD_HD void qd_wide_key(uint64_t a_lo, uint64_t a_hi, uint64_t b_lo, uint64_t b_hi, int w1, uint64_t* lo, uint64_t* hi) {
+    const uint64_t n1 = (uint64_t)qd_pack_nib8(a_lo) | ((uint64_t)qd_pack_nib8(a_hi) << 32);
+    const uint64_t n2 = (uint64_t)qd_pack_nib8(b_lo) | ((uint64_t)qd_pack_nib8(b_hi) << 32);
+    if (w1 <= 0) {
+        *lo = n2;
+        *hi = 0;
+    } else if (w1 >= 16) {
+        *lo = n1;
+        *hi = n2;
+    } else {
+        *lo = n1 | (n2 << (4 * w1));
+        *hi = n2 >> (64 - 4 * w1);
+    }
+}
+// hash of a packed key as probe_lds() computes it for K > 8: both words, the byte length K in the seed
+QD_HD uint32_t qd_hash_wide(uint64_t lo, uint64_t hi, uint32_t K, uint32_t seed) {
+    return qd_hash_fini(qd_hash_step(qd_hash_step(qd_hash_init(K, seed), lo), hi));
+}

@@ -95,6 +95,11 @@ struct DemuxParams {
     int32_t mol_off[2], mol_w[2];
     int32_t idx_col[2], mol_col[2];  // absolute 0-based column of the slices (length clamping)
     uint64_t idx_mask[2], mol_mask[2];  // (1 << 8*w) - 1
+    // wide plans (16 < K <= 32, slices of up to 16 bytes per index read): the fast table holds nibble-packed
+    // keys (quade_common.h), a hit is confirmed against the barcode's bytes
+    int32_t wide;
+    uint64_t idx_mask_hi[2];  // mask of slice bytes 8..15
+    const uint64_t* bkv;      // [S][4]  per barcode: slice of index read 1 (lo, hi), slice of index read 2 (lo, hi)
     // table of EVERY barcode (any length), global memory: generic kernel and the exception pairs redone
     // after a fast launch (the LDS table of the fast kernel holds the barcodes of length K only)
     const uint32_t* gslots;

@@ -24,6 +24,13 @@
 //   * static row shapes: the common layouts (barcode at the window start, molecular index behind it)
 //     are instantiated with their slice positions as compile-time constants -- the generic code kept
 //     ~100 scalars live and spilled them through VGPR lanes.
+//   * wave runs (dual-index forms): a wave owns 512 consecutive pairs of a super-tile and walks them in four
+//     steps; its four dwords of codes per lane leave as one 16-byte store through the wave's LDS strip.
+//   * exact-width rows: a lane's second 16-byte block is end-aligned with its second row (no over-read into
+//     the next wave's line).
+//   * wide plans (fused barcode of 17..32 bytes, each index read's part within 16): RowsW -- slices folded,
+//     nibble-packed (ACGTN differ in their low nibble) into the same 16-byte keys, a hit confirmed by a byte
+//     compare against the barcode; StaticWide<10> = the dual 10 bp index kits.
 //   * demux_generic: any stride, optional per-read lengths (truncated index reads), barcodes up to
 //     32 bytes, table in global memory (L2 resident).  Correctness path.
 //   * demux_fixup: the listed short reads of a batch redone with the generic semantics after a fast
@@ -270,6 +277,37 @@ __device__ __forceinline__ uint32_t match_pair(const DemuxParams& p, const LdsTa
 #ifndef QD_ABLATE_HIST
     atomicAdd(&t.hist[code], 1u);
 #endif
+    return code;
+}
+
+// Wide plans (16 < K <= 32; slices of up to 16 bytes per index read; quade_common.h "wide keys"): the slices are
+// folded, nibble-packed and fused into a 16-byte key for the same LDS table probe; a hit is confirmed against
+// the barcode's own bytes (global memory, L2: 32 B per sample) before it counts.
+template <bool DUAL>
+__device__ __forceinline__ uint32_t match_pair_wide(const DemuxParams& p, const LdsTable& t, const u64 (&k1)[2],
+                                                    const u64 (&k2)[2], u64 m1, u64 m2, const u64 (&q1)[2],
+                                                    const u64 (&q2)[2], u64& mlo, u64& mhi) {
+    if (p.M > 0) {  // a2: fused molecular index, raw case
+        mlo = m1;
+        mhi = 0;
+        if (DUAL) fuse(m1, m2, p.mol_w[0], mlo, mhi);
+    }
+    // a3 + a1: fold, pack, fuse
+    const u64 f1lo = qd_fold8(k1[0]), f1hi = qd_fold8(k1[1]);
+    const u64 f2lo = DUAL ? qd_fold8(k2[0]) : 0, f2hi = DUAL ? qd_fold8(k2[1]) : 0;
+    u64 klo, khi;
+    qd_wide_key(f1lo, f1hi, f2lo, f2hi, p.idx_w[0], &klo, &khi);
+    // a4: packed lookup, then the byte compare that makes it exact
+    const uint32_t id = probe_lds(t, klo, khi, (uint32_t)p.K, p.seed, p.slot_mask);
+    if (id == QD_CODE_UNDET) return QD_CODE_UNDET;
+    const ulong2* bv = reinterpret_cast<const ulong2*>(p.bkv) + 2 * (size_t)id;
+    const ulong2 b1 = bv[0], b2 = bv[1];
+    if (b1.x != f1lo || b1.y != f1hi || b2.x != f2lo || b2.y != f2hi) return QD_CODE_UNDET;
+    // a5: min-phred gate over the barcode positions
+    uint32_t pass = qd_all_ge8(q1[0], p.thr) & qd_all_ge8(q1[1], p.thr);
+    if (DUAL) pass &= qd_all_ge8(q2[0], p.thr) & qd_all_ge8(q2[1], p.thr);
+    const uint32_t code = id * 2u + (pass ^ 1u);
+    atomicAdd(&t.hist[code], 1u);
     return code;
 }
 
@@ -654,6 +692,128 @@ struct RowsX {
             } else {
                 store_unit(p, p0, two, c[0], c[1], m0lo, m0hi, m1lo, m1hi);
             }
+        }
+        return undet;
+    }
+};
+
+// ---- RowsW: wide plans.  Even strides <= 16 for the seq AND the qual rows; every stream is read with two
+// 16-byte loads per lane (rows of 2 pairs = 2 * stride <= 32 bytes): the first at the lane's first byte, the
+// second end-aligned with the lane's second row (at byte max(0, 2 * stride - 16): for strides <= 8 it repeats
+// the first).  One instantiation per workgroup size covers every stride combination of the (rare) wide plans.
+// StaticWide<IW>: dual IW-base barcodes (8 < IW <= 16) at the start of both index reads, no molecular index --
+// the layout of the dual 10 bp index kits -- baked in, as StaticShape does for the 8-byte forms (the dynamic
+// code of this policy keeps ~250 scalars alive: 577 SGPR spills, a third of its instructions move lanes).
+template <int IW>
+struct StaticWide {
+    static constexpr bool STATIC = true;
+    static constexpr int STRIDE = (IW + 1) & ~1;
+    static __device__ __forceinline__ void apply(DemuxParams& p) {
+        p.n_streams = 2;
+        p.K = 2 * IW;
+        p.M = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            p.seq_stride[k] = p.qual_stride[k] = STRIDE;
+            p.idx_off[k] = 0;
+            p.idx_w[k] = IW;
+            p.mol_off[k] = p.mol_w[k] = 0;
+            p.idx_mask[k] = ~0ull;
+            p.idx_mask_hi[k] = IW >= 16 ? ~0ull : ((1ull << (8 * (IW - 8))) - 1);
+            p.mol_mask[k] = 0;
+        }
+    }
+    static bool matches(const DemuxParams& p) {
+        if (p.n_streams != 2 || p.K != 2 * IW || p.M != 0) return false;
+        for (int k = 0; k < 2; ++k)
+            if (p.seq_stride[k] != STRIDE || p.qual_stride[k] != STRIDE || p.idx_off[k] != 0 || p.idx_w[k] != IW || p.mol_w[k] != 0)
+                return false;
+        return true;
+    }
+};
+
+template <int BLOCK_, bool DUAL, class SH = DynShape>
+struct RowsW {
+    typedef SH Shape;
+    static constexpr int BLOCK = BLOCK_;
+    static constexpr bool PREFETCH = false;   // 128 B per lane per tile: a second tile in registers costs more in
+                                              // occupancy (132 VGPRs) than it hides (0.74 vs 0.60 ms, static 10+10)
+    static constexpr bool GUARD_LAST = true;  // strides < 8: the first block passes the lane's rows
+    static constexpr int RUNS = DUAL ? QD_FAST_RUNS : 0;
+    struct Tile {
+        u64 s1[4], q1[4], s2[4], q2[4];
+    };
+
+    static __device__ __forceinline__ int second_at(int stride) { return 2 * stride > 16 ? 2 * stride - 16 : 0; }
+
+    template <bool FULL>
+    static __device__ __forceinline__ void load_rows(u64 (&w)[4], const uint8_t* rows, int64_t p0, int stride, int64_t n) {
+        const uint8_t* src = rows + p0 * stride;  // p0 even, stride even: 4-byte aligned
+        if (FULL) {
+            const U128 a = ld16u(src), b = ld16u(src + second_at(stride));
+            w[0] = a.lo;
+            w[1] = a.hi;
+            w[2] = b.lo;
+            w[3] = b.hi;
+        } else {
+            ld_exact(w, src, (p0 + 1 < n ? 2 : 1) * stride);
+        }
+    }
+
+    template <bool FULL>
+    static __device__ __forceinline__ void load(Tile& T, const DemuxParams& p, int64_t base, uint32_t tid) {
+        const int64_t n = p.n, p0 = base + (int64_t)tid * 2;
+        if (FULL || p0 < n) {
+            load_rows<FULL>(T.s1, p.seq[0], p0, p.seq_stride[0], n);
+            load_rows<FULL>(T.q1, p.qual[0], p0, p.qual_stride[0], n);
+            if (DUAL) {
+                load_rows<FULL>(T.s2, p.seq[1], p0, p.seq_stride[1], n);
+                load_rows<FULL>(T.q2, p.qual[1], p0, p.qual_stride[1], n);
+            }
+        }
+    }
+
+    // byte position of row h of a stream inside its four words
+    template <bool FULL>
+    static __device__ __forceinline__ int row_at(int h, int stride) {
+        return h ? (FULL ? 16 + stride - second_at(stride) : stride) : 0;
+    }
+
+    template <bool FULL, int TAG>
+    static __device__ __forceinline__ uint32_t compute(const Tile& T, const DemuxParams& p, const LdsTable& t,
+                                                       int64_t base, uint32_t tid, const CodeOut& co) {
+        asm volatile("; demux tile copy %0" ::"i"(TAG));
+        const int64_t n = p.n, p0 = base + (int64_t)tid * 2;
+        if (!FULL && p0 >= n) return 0;
+        const bool two = FULL || (p0 + 1 < n);
+        u64 m0lo = 0, m0hi = 0, m1lo = 0, m1hi = 0;
+        uint32_t c[2] = {0, 0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !two) break;
+            const int r1 = row_at<FULL>(h, p.seq_stride[0]), rq1 = row_at<FULL>(h, p.qual_stride[0]);
+            const u64 k1[2] = {take8(T.s1, r1 + p.idx_off[0]) & p.idx_mask[0], take8(T.s1, r1 + p.idx_off[0] + 8) & p.idx_mask_hi[0]};
+            const u64 q1[2] = {take8(T.q1, rq1) | ~p.idx_mask[0], take8(T.q1, rq1 + 8) | ~p.idx_mask_hi[0]};  // beyond the slice: 0xFF
+            const u64 m1 = take8(T.s1, r1 + p.mol_off[0]) & p.mol_mask[0];
+            u64 k2[2] = {0, 0}, q2[2] = {~0ull, ~0ull}, m2 = 0;
+            if (DUAL) {
+                const int r2 = row_at<FULL>(h, p.seq_stride[1]), rq2 = row_at<FULL>(h, p.qual_stride[1]);
+                k2[0] = take8(T.s2, r2 + p.idx_off[1]) & p.idx_mask[1];
+                k2[1] = take8(T.s2, r2 + p.idx_off[1] + 8) & p.idx_mask_hi[1];
+                q2[0] = take8(T.q2, rq2) | ~p.idx_mask[1];
+                q2[1] = take8(T.q2, rq2 + 8) | ~p.idx_mask_hi[1];
+                m2 = take8(T.s2, r2 + p.mol_off[1]) & p.mol_mask[1];
+            }
+            c[h] = match_pair_wide<DUAL>(p, t, k1, k2, m1, m2, q1, q2, h ? m1lo : m0lo, h ? m1hi : m0hi);
+        }
+        const uint32_t undet = (c[0] == QD_CODE_UNDET) + (two && c[1] == QD_CODE_UNDET);
+        if (FULL && p.mol_strip_off) {
+            store_codes_full<RUNS>(p, co, p0, c[0] | (c[1] << 16));
+            store_mol_wave(p, t.strips + (tid >> 6) * (128 * p.M), p0, m0lo, m0hi, m1lo, m1hi);
+        } else if (FULL && p.M == 0) {
+            store_codes_full<RUNS>(p, co, p0, c[0] | (c[1] << 16));
+        } else {
+            store_unit(p, p0, two, c[0], c[1], m0lo, m0hi, m1lo, m1hi);
         }
         return undet;
     }
@@ -1089,6 +1249,14 @@ hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, in
                          size_t table_lds, hipStream_t st) {
     constexpr int U = QD_FAST_UNITS;
     const bool dual = p.n_streams > 1;
+    if (p.wide) {  // K > 16 with slices <= 16 bytes means two index reads
+        if (!dual) return hipErrorInvalidValue;
+#ifndef QD_NO_STATIC_SHAPES
+        if (StaticWide<10>::matches(p))  // dual 10 bp indexes
+            return launch_fast_t<RowsW<BLOCK, true, StaticWide<10>>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
+#endif
+        return launch_fast_t<RowsW<BLOCK, true>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
+    }
     const bool all8 = p.seq_stride[0] == 8 && p.qual_stride[0] == 8 &&
                       (!dual || (p.seq_stride[1] == 8 && p.qual_stride[1] == 8));
     if (all8) {
@@ -1128,11 +1296,12 @@ hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, in
 // Workgroup size: 512 threads; 1024 when the LDS image of the table is large (few workgroups fit a
 // CU then, and bigger ones keep the wave count up); 256 for batches of at most 16 M pairs with a small
 // table (a 4 M-pair batch is 3906 tiles of 512 threads: too few to fill 256 CUs evenly; measured -6 % at
-// 4 M pairs, -1.4 % at 10 M, nothing at 100 M: profiles/r02_small_batch_block.txt).  block_override: 0 = this rule.
+// 4 M pairs, -1.4 % at 10 M, nothing at 100 M: profiles/r02_small_batch_block.txt) and for the wide form (its
+// tile is 128 B per lane; -4 %).  block_override: 0 = this rule.
 hipError_t qd_launch_fast(const DemuxParams& p, QdKernelCache& cache, int cus, int wg_per_cu, int block_override,
                           size_t lds_bytes, size_t strip_bytes_per_wave, hipStream_t st) {
     int block = block_override ? block_override
-                               : (lds_bytes > QD_FAST_BIG_LDS ? 1024 : (p.n <= QD_FAST_SMALL_BATCH ? 256 : QD_FAST_BLOCK));
+                               : (lds_bytes > QD_FAST_BIG_LDS ? 1024 : ((p.n <= QD_FAST_SMALL_BATCH || p.wide) ? 256 : QD_FAST_BLOCK));
     const size_t lds = lds_bytes + strip_bytes_per_wave * (size_t)(block / 64);  // table | histogram | strips
     if (block == 1024) return launch_fast_b<1024>(p, cache, cus, wg_per_cu, lds, lds_bytes, st);
     if (block == 256) return launch_fast_b<256>(p, cache, cus, wg_per_cu, lds, lds_bytes, st);

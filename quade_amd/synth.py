@@ -32,20 +32,26 @@ CONFIGS = {
     "cfg3": dict(dual=True, S=96, read_len=8, mol=False, min_qual=25, pairs=100_000_000),
     "cfg4": dict(dual=True, S=384, read_len=14, mol=True, min_qual=25, pairs=500_000_000),
     "cfg5": dict(dual=True, S=1536, read_len=8, mol=False, min_qual=25, pairs=1_000_000_000),
+    # not a BASELINE config: dual 10 bp indexes (fused barcode of 20 bytes: the wide fast kernel), tools and tests only
+    "wide10": dict(dual=True, S=96, read_len=10, mol=False, min_qual=25, pairs=100_000_000, iw=10),
 }
 # algorithmic bytes per pair (SURVEY.md 8d / BASELINE.md section 3)
-ALGO_BYTES = {"cfg2": 18, "cfg3": 34, "cfg4": 58, "cfg5": 34}
+ALGO_BYTES = {"cfg2": 18, "cfg3": 34, "cfg4": 58, "cfg5": 34, "wide10": 42}
 
 
 def config_plan(name):
     c = CONFIGS[name]
+    iw = c.get("iw", 8)
     mol = (8, 14) if c["mol"] else (0, 0)
-    return make_plan(c["dual"], c["min_qual"], (0, 8), (0, 8) if c["dual"] else (0, 0),
+    return make_plan(c["dual"], c["min_qual"], (0, iw), (0, iw) if c["dual"] else (0, 0),
                      mol, mol if c["dual"] else (0, 0))
 
 
 def _key64(rows):
-    """[n, 8k] uint8 -> [n, k] int64 (little-endian words)"""
+    """[n, K] uint8 -> [n, ceil(K / 8)] int64 (little-endian words, zero padded)"""
+    pad = (-rows.shape[1]) % 8
+    if pad:
+        rows = torch.cat([rows, torch.zeros((rows.shape[0], pad), dtype=torch.uint8, device=rows.device)], dim=1)
     return rows.contiguous().view(torch.int64)
 
 
@@ -98,7 +104,8 @@ def generate(name, n, seed=None, device="cpu", chunk=8_000_000, layout=None):
     dev = torch.device(device)
     gen = gcpu if dev.type == "cpu" else torch.Generator(device=dev).manual_seed(seed)
     ns = 2 if c["dual"] else 1
-    K = 8 * ns
+    iw = c.get("iw", 8)
+    K = iw * ns
     S = c["S"]
     L = c["read_len"]
     plan = config_plan(name)
@@ -155,11 +162,11 @@ def generate(name, n, seed=None, device="cpu", chunk=8_000_000, layout=None):
         expected[a:a + m] = exp.to(torch.int32)
         for k in range(ns):
             seq[k][a:a + m].zero_()
-            seq[k][a:a + m, 0:8] = key[:, 8 * k:8 * k + 8]
+            seq[k][a:a + m, 0:iw] = key[:, iw * k:iw * k + iw]
             if c["mol"]:
                 seq[k][a:a + m, 8:L] = acgt[ri(0, 4, (m, L - 8))]
             qual[k][a:a + m].fill_(0xFF)
-            qual[k][a:a + m, 0:8] = q[:, 8 * k:8 * k + 8]
+            qual[k][a:a + m, 0:iw] = q[:, iw * k:iw * k + iw]
     return Workload(name, n, seq, qual, expected, bcs_cpu, plan, lay)
 
 

@@ -278,3 +278,69 @@ def test_two_threads_two_contexts_different_tables():
         t.join()
     assert not errors, errors
     assert results == {"cfg3": True, "cfg5": True, "cfg4": True}
+
+
+WIDE_PLANS = {
+    # name: (index1 span, index2 span, molecular1 span, molecular2 span)
+    "dual_10_10": ((0, 10), (0, 10), (0, 0), (0, 0)),
+    "dual_12_12": ((0, 12), (0, 12), (0, 0), (0, 0)),
+    "dual_16_16": ((0, 16), (0, 16), (0, 0), (0, 0)),
+    "dual_10_8_offset": ((3, 13), (2, 10), (0, 0), (0, 0)),
+    "dual_10_10_umi_6_4": ((0, 10), (1, 11), (10, 16), (11, 15)),
+    "dual_9_8": ((0, 9), (0, 8), (0, 0), (0, 0)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(WIDE_PLANS))
+@pytest.mark.parametrize("n", [1, 777, 20011])
+def test_wide_plans_on_the_fast_kernel(engine, name, n):
+    """Fused barcodes of 17..32 bytes whose two slices fit 16 bytes each (the dual 10 bp indexes of current
+    kits above all) run on the fast kernel: nibble-packed table lookup + byte confirmation.  Reads carry
+    every byte value, among them bytes that share their low nibble with a letter of the alphabet ('Q' / 'A',
+    'S' / 'C', 'W' / 'G', 'D' / 'T', '^' / 'N'): such a read must stay undetermined."""
+    from quade_amd.hip_backend import make_plan
+    i1, i2, m1, m2 = WIDE_PLANS[name]
+    rng = np.random.default_rng(len(name) * 1000 + n)
+    w1, w2 = i1[1] - i1[0], i2[1] - i2[0]
+    bcs = _barcodes(rng, 37, w1 + w2)
+    bcs[3] = "N" * (w1 + w2)
+    plan = make_plan(True, 22, i1, i2, m1, m2)
+    L1, L2 = max(i1[1], m1[1]) + 2, max(i2[1], m2[1]) + 1
+    s1, q1 = _random_reads(rng, n, L1, [b[:w1] for b in bcs], i1[0], frac_hit=0.0)
+    s2, q2 = _random_reads(rng, n, L2, [b[w1:] for b in bcs], i2[0], frac_hit=0.0)
+    twin = bytes.maketrans(b"ACGTN", b"QSWD^")  # same low nibbles, other letters
+    for i in range(n):
+        kind = i % 4
+        if kind == 3:
+            continue
+        b = bcs[int(rng.integers(0, len(bcs)))].encode()
+        a, c = b[:w1], b[w1:]
+        if kind == 1:  # one byte of the key replaced by its nibble twin, or by an arbitrary byte
+            pos = int(rng.integers(0, w1 + w2))
+            bad = bytes([b[pos]]).translate(twin) if rng.integers(0, 2) else bytes([int(rng.choice([0, 1, 0x7F, 0x80, 0xC1, 0xFF, 0x61]))])
+            bb = b[:pos] + bad + b[pos + 1:]
+            a, c = bb[:w1], bb[w1:]
+        elif kind == 2 and rng.integers(0, 2):
+            a, c = a.lower(), c  # folds back: still a match
+        s1[i] = s1[i][:i1[0]] + a + s1[i][i1[0] + w1:]
+        s2[i] = s2[i][:i2[0]] + c + s2[i][i2[0] + w2:]
+    codes, counts = _run_vs_c_oracle(engine, plan, bcs, [(s1, q1), (s2, q2)])
+    assert engine.kernel_kind(False) == "fast"
+    if n > 500:
+        assert counts[1] + counts[2] > n // 4 and counts[3] > n // 4
+
+
+def test_wide_plan_with_a_barcode_outside_the_alphabet_goes_generic(engine):
+    """The packed table is injective on ACGTN only: a K-long barcode with another byte (the library takes any
+    bytes; the reference's registry would have refused it) sends the plan to the generic kernel."""
+    from quade_amd.hip_backend import make_plan
+    rng = np.random.default_rng(3)
+    bcs = _barcodes(rng, 5, 20) + ["ACGTACGTAQACGTACGTAC"]
+    plan = make_plan(True, 20, (0, 10), (0, 10))
+    s1, q1 = _random_reads(rng, 3000, 10, [b[:10] for b in bcs], 0)
+    s2, q2 = _random_reads(rng, 3000, 10, [b[10:] for b in bcs], 0)
+    for i in range(0, 3000, 2):
+        b = bcs[int(rng.integers(0, len(bcs)))]
+        s1[i], s2[i] = b[:10].encode(), b[10:].encode()
+    _, counts = _run_vs_c_oracle(engine, plan, bcs, [(s1, q1), (s2, q2)])
+    assert engine.kernel_kind(False) == "generic" and counts[-2] + counts[-1] > 100

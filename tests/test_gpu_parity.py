@@ -53,6 +53,15 @@ def test_fast_kernel_vs_oracle(torch_cuda, engine, name, n):
     _check_workload(torch_cuda, engine, synth.generate(name, n, seed=1000 + n))
 
 
+@pytest.mark.parametrize("n", [0, 1, 2, 511, 1023, 4097, 30001, 70003])
+def test_wide_fast_kernel_vs_oracle(torch_cuda, engine, n):
+    """Dual 10 bp indexes (fused barcode of 20 bytes): the wide form of the fast kernel, and the generic one."""
+    from quade_amd import synth
+    _check_workload(torch_cuda, engine, synth.generate("wide10", n, seed=3000 + n))
+    if n in (1023, 30001):
+        _check_workload(torch_cuda, engine, synth.generate("wide10", n, seed=3000 + n), force_generic=True)
+
+
 @pytest.mark.parametrize("name", ["cfg3", "cfg4"])
 @pytest.mark.parametrize("n_short", [0, 1, 57, 20000])
 def test_sparse_short_reads_on_the_fast_kernels(torch_cuda, engine, name, n_short):

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 from quade_amd import synth
 from quade_amd.hip_backend import Engine, LIB_PATH
 LIBS = [LIB_PATH] + [p for p in os.environ.get("GENERIC_LIBS", "").split(",") if p]
-for cfg in ["cfg2", "cfg3", "cfg4", "cfg5"]:
+for cfg in os.environ.get("GENERIC_CFGS", "cfg2,cfg3,cfg4,cfg5").split(","):
     n = 20_000_000
     w = synth.generate(cfg, n, device="cuda")
     M = w.layout.mol_width

@@ -14,7 +14,7 @@ from quade_amd.hip_backend import Engine  # noqa: E402
 cfg = sys.argv[1]
 launches = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 kernel = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-default_n = {"cfg2": 10_000_000, "cfg3": 100_000_000, "cfg4": 62_500_000, "cfg5": 125_000_000}
+default_n = {"cfg2": 10_000_000, "cfg3": 100_000_000, "cfg4": 62_500_000, "cfg5": 125_000_000, "wide10": 60_000_000}
 n = int(sys.argv[4]) if len(sys.argv) > 4 else default_n[cfg]
 w = synth.generate(cfg, n, device="cuda")
 M = w.layout.mol_width

@@ -14,7 +14,7 @@ from quade_amd import synth  # noqa: E402
 from quade_amd.hip_backend import Engine, LIB_PATH  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
-default_n = {"cfg2": 10_000_000, "cfg3": 100_000_000, "cfg4": 62_500_000, "cfg5": 125_000_000}
+default_n = {"cfg2": 10_000_000, "cfg3": 100_000_000, "cfg4": 62_500_000, "cfg5": 125_000_000, "wide10": 60_000_000}
 n = int(sys.argv[2]) if len(sys.argv) > 2 else default_n[cfg]
 blocks = [int(x) for x in os.environ.get("TUNE_BLOCKS", "0,256,512,1024").split(",")]
 wgs = [int(x) for x in os.environ.get("TUNE_WG", "0,4,16,64").split(",")]
