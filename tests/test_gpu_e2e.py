@@ -164,6 +164,11 @@ SCENARIOS = {
                                   gpu="[gpu]\nchunk_workers : 3\nbatch_pairs : 31\nslots : 2\n"),
     # "all": every device the library sees (one on this box)
     "devices_all": dict(dual=False, idx_len=8, pos=((1, 8), None, None, None), minq=20, gpu="[gpu]\ndevices : all\n"),
+    # dual 10 bp indexes (fused barcode of 20 bytes): the wide form of the fast kernel, incl. truncated reads
+    # (listed exceptions redone by the fixup kernel) and a molecular index behind the second barcode
+    "dual_10bp_wide_fast": dict(dual=True, idx_len=12, pos=((1, 10), (1, 10), None, None), minq=25),
+    "dual_10bp_umi_truncated": dict(dual=True, idx_len=16, pos=((1, 10), (2, 11), None, (12, 16)), minq=20, trunc=True,
+                                    gpu="[gpu]\nbatch_pairs : 64\n"),
     "wide_window_generic": dict(dual=False, idx_len=24, pos=((1, 20), None, (21, 24), None), minq=10),
     # truncated reads on a plan the fast kernel does not take: the generic kernel needs every read's length
     "wide_window_truncated": dict(dual=False, idx_len=24, pos=((1, 20), None, (21, 24), None), minq=10, trunc=True,
