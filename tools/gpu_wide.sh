@@ -2,7 +2,7 @@
 # wide fast kernel (16 < K <= 32): parity, then its rate against the generic kernel on dual 10 bp indexes
 set -o pipefail
 export TMPDIR=/tmp
-D=gpurun_out/r02wide; rm -rf $D; mkdir -p $D
+D=gpurun_out/wide; rm -rf $D; mkdir -p $D
 echo "[tests] all gpu tests"
 timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tee $D/tests.txt | tail -4 || exit 1
 echo "[tune] wide10 (fast, wide form)"
