@@ -169,8 +169,11 @@ void canon(const uint8_t* b, int len, u64 w[QD_KEY_WORDS]) {
 std::vector<uint32_t> build_slots(const std::vector<int>& ids, const std::vector<u64>& keys32,
                                   const std::vector<uint8_t>& blen, uint32_t& mask, uint32_t& seed,
                                   const std::vector<u64>* packed16 = nullptr, uint32_t K = 0) {
-    uint32_t m = 16;
-    while (m < 4u * (uint32_t)ids.size()) m <<= 1;
+    // >= 4 slots per barcode (half that many cost +8 % on S = 1536 and +13 % on S = 96, twice as many nothing:
+    // profiles/r02_slot_table_load.txt), and never fewer than 256: a dozen barcodes in 64 slots have every lane of
+    // a wave probing the same few LDS words (S = 12: -7 % with 256 slots)
+    uint32_t m = 256;
+    while (m < (uint32_t)QD_SLOT_FACTOR * (uint32_t)ids.size()) m <<= 1;
     mask = m - 1;
     std::vector<uint32_t> best;
     uint32_t best_worst = ~0u;

@@ -32,6 +32,12 @@
 #ifndef QD_GENERIC_BYTEWISE
 #define QD_GENERIC_BYTEWISE 0 /* A/B: the generic path's byte-at-a-time slice loops (r01)                   */
 #endif
+#ifndef QD_STRIPS_LDS_BUDGET
+#define QD_STRIPS_LDS_BUDGET 0 /* A/B: LDS a CU may spend on two workgroups incl. their code strips (0: small tables only) */
+#endif
+#ifndef QD_SLOT_FACTOR
+#define QD_SLOT_FACTOR 4 /* open-addressing slots per barcode, before rounding up to a power of two (load <= 1/4) */
+#endif
 #ifndef QD_STATIC80_ALWAYS
 #define QD_STATIC80_ALWAYS 0 /* A/B: the static 8+0 shape for small tables too                              */
 #endif

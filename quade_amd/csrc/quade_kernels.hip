@@ -1187,7 +1187,8 @@ hipError_t launch_fast_t(const DemuxParams& p_launch, QdKernelCache& cache, int 
     // code strips (wave runs): R x 256 B per wave behind the table image and the molecular strips, while the
     // table image is small (a large one leaves no room without giving up a co-resident workgroup)
     DemuxParams p = p_launch;
-    if (OPS::RUNS >= 4 && QD_FAST_CODE_STRIPS && table_lds <= 24 * 1024) {
+    if (OPS::RUNS >= 4 && QD_FAST_CODE_STRIPS &&
+        (table_lds <= 24 * 1024 || 2 * (lds + (size_t)OPS::RUNS * 256 * (BLOCK / 64)) <= QD_STRIPS_LDS_BUDGET)) {
         p.code_strip_off = (uint32_t)lds;
         lds += (size_t)OPS::RUNS * 256 * (BLOCK / 64);
     }
