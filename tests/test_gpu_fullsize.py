@@ -6,7 +6,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-FULL = {"cfg2": 10_000_000, "cfg3": 100_000_000, "cfg4": 62_500_000, "cfg5": 125_000_000}
+FULL = {"cfg2": 10_000_000, "cfg3": 100_000_000, "cfg4": 62_500_000, "cfg5": 125_000_000, "wide10": 60_000_000}
 
 
 def _run(eng, torch, seq, qual, n, M):
@@ -21,7 +21,7 @@ def _run(eng, torch, seq, qual, n, M):
     return codes.view(torch.int16).to(torch.int32) & 0xFFFF, mol, eng.counts().astype(np.int64)
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5", "wide10"])
 def test_full_size_properties(name):
     import torch
     from quade_amd import synth
@@ -81,6 +81,12 @@ def test_more_than_2_31_pairs_in_one_launch():
                          stream=st.cuda_stream)
         eng.synchronize()
         counts = eng.counts().astype(np.int64)
+        # a second launch takes the pairs since the last fold past 2^32 - 1: the 32-bit counter rows are folded
+        # into the 64-bit totals first (quade_api.cpp fold_rows), and the sums stay exact
+        eng.demux_device(n, [t.data_ptr() for t in w.seq], [t.data_ptr() for t in w.qual], codes.data_ptr(), None,
+                         stream=st.cuda_stream)
+        eng.synchronize()
+        assert (eng.counts().astype(np.int64) == 2 * counts).all()
     step = 1 << 28
     for a in range(0, n, step):  # compare in slices to bound temporaries
         got = codes[a:a + step].to(torch.int32) & 0xFFFF
