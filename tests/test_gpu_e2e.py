@@ -408,3 +408,12 @@ print("ok")
 ''' % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_c99_client_runs_the_hot_path(tmp_path):
+    """examples/abi_client.c: fastq text -> pinned slot -> codes, molecular bytes, counters and name tags through
+    the C ABI alone, from plain C."""
+    import subprocess
+    from tests.test_host_cpu import _build_abi_client
+    r = subprocess.run([_build_abi_client(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok: 4 pairs on "), (r.returncode, r.stdout, r.stderr)

@@ -351,3 +351,31 @@ def test_synthetic_generator_truth_equals_oracle():
         codes, _, _, counts = H.oracle_on_workload(w)
         assert (codes == w.expected.numpy().astype(np.uint16)).all()
         assert counts[0] == 3000 and counts[3] > 0 and (counts[2] > 0) == (synth.CONFIGS[name]["min_qual"] > 0)
+
+
+def _build_abi_client(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "abi_client")
+    lib_dir = os.path.join(ROOT, "quade_amd", "lib")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "abi_client.c"), "-L", lib_dir, "-lquade_hip", "-Wl,-rpath," + lib_dir,
+           "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_c99_client_builds_against_the_header_and_fails_loudly_without_a_gpu(tmp_path):
+    """include/quade_hip.h is the boundary: a strict-C99 program (no HIP header, no Python) compiles against
+    it and links with the library.  Without an MI355X qd_create says QD_ERR_NO_DEVICE -- there is no CPU path
+    behind the ABI -- and the example exits 77; on the GPU box the same binary is run by
+    tests/test_gpu_e2e.py::test_c99_client_runs_the_hot_path."""
+    import subprocess
+    hb.load_library()  # builds the library on a fresh checkout
+    exe = _build_abi_client(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    import torch
+    if torch.cuda.is_available():
+        assert r.returncode == 0, (r.stdout, r.stderr)
+    else:
+        assert r.returncode == 77 and "no CPU fallback" in r.stdout, (r.returncode, r.stdout, r.stderr)
