@@ -201,6 +201,51 @@ def test_reference_finder_vectors_through_hip(torch_cuda, engine, finder_vectors
         assert engine.counts().tolist() == vs["counts"]
 
 
+def test_reference_finder_vectors_on_the_fast_kernels(torch_cuda, engine, finder_vectors):
+    """The same recorded Sample.FINDER outcomes, this time through the FAST kernels: the plan's window is the
+    barcode length of the set (K = 8, 16 and 20: the last one is the wide form), split over two index reads;
+    keys shorter than that are listed as exceptions (fast kernel + fixup), keys longer than the barcodes are
+    left out (the plan's slice would cut them, the reference compared them whole)."""
+    from quade_amd.hip_backend import make_plan, pack_index_reads
+    torch = torch_cuda
+    seen = set()
+    for vs in finder_vectors["finder"]:
+        lens_bc = {len(bc) for _, bc in vs["samples"]}
+        if len(lens_bc) != 1:
+            continue
+        K = lens_bc.pop()
+        w1 = K // 2
+        keep = [i for i, (key, _) in enumerate(vs["vectors"]) if len(key) <= K]
+        sub = dict(vs, vectors=[vs["vectors"][i] for i in keep])
+        _, s1, q1, s2, q2 = _vector_reads(sub, w1)
+        n = len(keep)
+        plan = make_plan(True, vs["min_qual"], (0, w1), (0, K - w1))
+        lay = engine.set_plan(plan)
+        engine.set_barcodes([bc for _, bc in vs["samples"]])
+        seq, qual, lens = [], [], []
+        for k, (s, q) in enumerate([(s1, q1), (s2, q2)]):
+            sr, qr, lr, full = pack_index_reads(lay, k, [v.encode("latin-1") for v in s], [v.encode("latin-1") for v in q])
+            seq.append(torch.from_numpy(sr).cuda()); qual.append(torch.from_numpy(qr).cuda())
+            lens.append(torch.from_numpy(lr).cuda())
+        short = np.array([i for i in range(n) if len(s1[i]) < w1 or len(s2[i]) < K - w1], dtype=np.uint32)
+        if len(short) > n // 2:
+            continue
+        assert engine.kernel_kind(False) == "fast"
+        d_short = torch.from_numpy(short.astype(np.int64)).to(torch.int32).cuda() if len(short) else torch.zeros(1, dtype=torch.int32, device="cuda")
+        codes = torch.full((n,), 0x7777, dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        engine.demux_device_ragged(n, [t.data_ptr() for t in seq], [t.data_ptr() for t in qual], codes.data_ptr(), None,
+                                   [t.data_ptr() for t in lens], len(short), d_short.data_ptr(), stream=0)
+        torch.cuda.synchronize()
+        want = [vs["codes"][i] for i in keep]
+        assert codes.cpu().numpy().view(np.uint16).tolist() == want, (vs["S"], K)
+        c = engine.counts()
+        assert int(c[0]) == n and int(c[3]) == sum(1 for v in want if v == 0xFFFF)
+        assert [int(v) for v in c[4:]] == [sum(1 for v in want if v == j) for j in range(2 * len(vs["samples"]))]
+        seen.add(K)
+    assert {8, 16, 20} <= seen
+
+
 def test_million_pairs_vs_c_oracle_fast_and_generic(torch_cuda, engine):
     """Mid size, beyond what the Python oracle does in seconds: 2 M pairs per config against the C
     restatement (pinned to the Python oracle by tests/test_oracle_c.py)."""
