@@ -338,6 +338,26 @@ int qd_text_batch_free(void* handle);
 int qd_reader_close(qd_reader* reader);
 const char* qd_reader_last_error(const qd_reader* reader); /* reader == NULL: why qd_reader_open failed on this thread */
 
+/* ---- BGZF inflate on the device ------------------------------------------------------------------------
+ * The gunzip inside pyFastq.FastqReader (src/Quade.py:203-214), for BGZF (bgzip) files: their blocks are
+ * independent gzip members of <= 64 KiB that carry their compressed and inflated sizes, so a run of them is
+ * inflated one block per GPU lane.  An inflater owns a stream and grow-only staging buffers on one device and
+ * is driven by one thread at a time (the native reader gives each of its files one).
+ * qd_inflater_run: comp[0..comp_len) = whole BGZF blocks back to back, out_len = the sum of their ISIZE
+ * fields; blocking.  Every block's CRC32 and length are checked on the host.  QD_ERR_FORMAT: not whole BGZF
+ * blocks, sizes inconsistent, or a block did not inflate / check (*bad_block = its index, else -1) -- the
+ * caller may inflate that run itself (the reader does).  No reference counterpart beyond the gunzip. */
+typedef struct qd_inflater qd_inflater;
+int qd_inflater_create(int device_id, qd_inflater** out);
+int qd_inflater_run(qd_inflater* inflater, const uint8_t* comp, int64_t comp_len, uint8_t* out, int64_t out_len,
+                    int32_t* bad_block);
+int qd_inflater_destroy(qd_inflater* inflater);
+const char* qd_inflater_last_error(const qd_inflater* inflater);
+/* A reader whose BGZF runs go through an inflater on `device_id` (< 0: host threads, as qd_reader_open). */
+int qd_reader_open_on(const char* path, int64_t batch_records, int32_t queue_depth, int32_t device_id, qd_reader** out);
+/* BGZF runs of this reader inflated by the device / by host threads so far (read it after the last batch). */
+int qd_reader_inflate_stats(const qd_reader* reader, int64_t* device_runs, int64_t* host_runs);
+
 #ifdef __cplusplus
 }
 #endif

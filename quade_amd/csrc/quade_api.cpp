@@ -15,6 +15,7 @@
 #include "../../include/quade_hip.h"
 #include "quade_common.h"
 #include "quade_kernels.h"
+#include "quade_inflate.h"
 
 typedef uint64_t u64;
 
@@ -1012,6 +1013,162 @@ int qd_comm_destroy(qd_comm* cm) {
         if (R.ok && cm->comms[i]) (void)R.CommDestroy(cm->comms[i]);
     }
     delete cm;
+    return QD_OK;
+}
+
+}  // extern "C"
+
+// ---- BGZF inflate on the device (include/quade_hip.h; kernel: quade_inflate.hip) ------------------------------
+uint32_t qd_io_crc32(const uint8_t* p, size_t n);  // quade_io.cpp: libdeflate's when loaded, else zlib's
+
+struct qd_inflater {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // grow-only staging: pinned host + device, for the compressed run, its text, the block table and the states
+    uint8_t *h_comp = nullptr, *d_comp = nullptr, *h_out = nullptr, *d_out = nullptr;
+    size_t cap_comp = 0, cap_out = 0;
+    qd_inflate_block *h_blk = nullptr, *d_blk = nullptr;
+    int32_t *h_st = nullptr, *d_st = nullptr;
+    size_t cap_blk = 0, cap_st = 0;
+    std::vector<uint32_t> crc;
+};
+
+namespace {
+int inf_fail(qd_inflater* f, int code, const std::string& msg) {
+    if (f) f->err = msg;
+    return code;
+}
+#define INFCHK(f, call)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) return inf_fail((f), QD_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+hipError_t grow_pair(T*& h, T*& d, size_t& cap, size_t need) {
+    if (need <= cap) return hipSuccess;
+    if (h) (void)hipHostFree(h);
+    if (d) (void)hipFree(d);
+    h = nullptr;
+    d = nullptr;
+    cap = 0;
+    const size_t n = need + need / 4 + 4096;
+    hipError_t e = hipHostMalloc((void**)&h, n * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    e = hipMalloc((void**)&d, n * sizeof(T));
+    if (e != hipSuccess) return e;
+    cap = n;
+    return hipSuccess;
+}
+thread_local std::string g_inflater_error;
+}  // namespace
+
+extern "C" {
+
+int qd_inflater_create(int device_id, qd_inflater** out) {
+    if (!out) return QD_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) {
+        g_inflater_error = "no such HIP device";
+        return QD_ERR_NO_DEVICE;
+    }
+    qd_inflater* f = new qd_inflater();
+    f->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) {
+        g_inflater_error = "hipStreamCreate failed";
+        delete f;
+        return QD_ERR_HIP;
+    }
+    *out = f;
+    return QD_OK;
+}
+
+const char* qd_inflater_last_error(const qd_inflater* f) { return f ? f->err.c_str() : g_inflater_error.c_str(); }
+
+int qd_inflater_destroy(qd_inflater* f) {
+    if (!f) return QD_OK;
+    (void)hipSetDevice(f->device);
+    if (f->stream) {
+        (void)hipStreamSynchronize(f->stream);
+        (void)hipStreamDestroy(f->stream);
+    }
+    if (f->h_comp) (void)hipHostFree(f->h_comp);
+    if (f->d_comp) (void)hipFree(f->d_comp);
+    if (f->h_out) (void)hipHostFree(f->h_out);
+    if (f->d_out) (void)hipFree(f->d_out);
+    if (f->h_blk) (void)hipHostFree(f->h_blk);
+    if (f->d_blk) (void)hipFree(f->d_blk);
+    if (f->h_st) (void)hipHostFree(f->h_st);
+    if (f->d_st) (void)hipFree(f->d_st);
+    delete f;
+    return QD_OK;
+}
+
+int qd_inflater_run(qd_inflater* f, const uint8_t* comp, int64_t comp_len, uint8_t* out, int64_t out_len, int32_t* bad_block) {
+    if (bad_block) *bad_block = -1;
+    if (!f || !comp || comp_len < 0 || out_len < 0 || (out_len > 0 && !out)) return inf_fail(f, QD_ERR_INVALID, "bad arguments");
+    if (comp_len > (int64_t)0xFFFF0000ll || out_len > (int64_t)0xFFFF0000ll) return inf_fail(f, QD_ERR_INVALID, "run larger than 4 GiB");
+    // 1. walk the block headers: gzip member with the 'BC' extra subfield = total block size - 1
+    std::vector<qd_inflate_block> blk;
+    f->crc.clear();
+    size_t pos = 0, opos = 0;
+    while (pos < (size_t)comp_len) {
+        const uint8_t* p = comp + pos;
+        const size_t avail = (size_t)comp_len - pos;
+        size_t bsize = 0, xlen = 0;
+        if (avail >= 18 && p[0] == 0x1f && p[1] == 0x8b && p[2] == 8 && (p[3] & 4)) {
+            xlen = p[10] | ((size_t)p[11] << 8);
+            if (avail >= 12 + xlen)
+                for (size_t o = 12; o + 4 <= 12 + xlen;) {
+                    const size_t slen = p[o + 2] | ((size_t)p[o + 3] << 8);
+                    if (p[o] == 'B' && p[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen) {
+                        bsize = (size_t)(p[o + 4] | (p[o + 5] << 8)) + 1;
+                        break;
+                    }
+                    o += 4 + slen;
+                }
+        }
+        if (!bsize || bsize > avail || bsize < 12 + xlen + 8 || (p[3] & ~4))  // other gzip flags (name, comment, hcrc): not bgzip's
+            return inf_fail(f, QD_ERR_FORMAT, "not a run of whole BGZF blocks");
+        const uint8_t* tr = p + bsize - 8;
+        const uint32_t crc = tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+        const uint32_t isize = tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24);
+        if (isize > (64u << 10) || opos + isize > (size_t)out_len) return inf_fail(f, QD_ERR_FORMAT, "BGZF block sizes do not add up");
+        blk.push_back(qd_inflate_block{(uint32_t)(pos + 12 + xlen), (uint32_t)(bsize - 12 - xlen - 8), (uint32_t)opos, isize});
+        f->crc.push_back(crc);
+        pos += bsize;
+        opos += isize;
+    }
+    if (opos != (size_t)out_len) return inf_fail(f, QD_ERR_FORMAT, "BGZF block sizes do not add up");
+    if (blk.empty()) return QD_OK;
+    // 2. stage, inflate one block per lane, fetch
+    INFCHK(f, hipSetDevice(f->device));
+    INFCHK(f, grow_pair(f->h_comp, f->d_comp, f->cap_comp, (size_t)comp_len));
+    INFCHK(f, grow_pair(f->h_out, f->d_out, f->cap_out, (size_t)out_len + 16));
+    INFCHK(f, grow_pair(f->h_blk, f->d_blk, f->cap_blk, blk.size()));
+    INFCHK(f, grow_pair(f->h_st, f->d_st, f->cap_st, blk.size()));
+    memcpy(f->h_comp, comp, (size_t)comp_len);
+    memcpy(f->h_blk, blk.data(), blk.size() * sizeof(qd_inflate_block));
+    INFCHK(f, hipMemcpyAsync(f->d_comp, f->h_comp, (size_t)comp_len, hipMemcpyHostToDevice, f->stream));
+    INFCHK(f, hipMemcpyAsync(f->d_blk, f->h_blk, blk.size() * sizeof(qd_inflate_block), hipMemcpyHostToDevice, f->stream));
+    INFCHK(f, qd_launch_inflate(f->d_comp, f->d_blk, (uint32_t)blk.size(), f->d_out, f->d_st, f->stream));
+    INFCHK(f, hipMemcpyAsync(f->h_st, f->d_st, blk.size() * 4, hipMemcpyDeviceToHost, f->stream));
+    if (out_len) INFCHK(f, hipMemcpyAsync(f->h_out, f->d_out, (size_t)out_len, hipMemcpyDeviceToHost, f->stream));
+    INFCHK(f, hipStreamSynchronize(f->stream));
+    // 3. every block: decoder status, then the CRC32 of its text
+    for (size_t i = 0; i < blk.size(); ++i) {
+        if (f->h_st[i] != 0 || qd_io_crc32(f->h_out + blk[i].out_off, blk[i].out_len) != f->crc[i]) {
+            if (bad_block) *bad_block = (int32_t)i;
+            char m[128];
+            if (f->h_st[i])
+                snprintf(m, sizeof m, "BGZF block %zu: did not inflate (decoder status %d)", i, (int)f->h_st[i]);
+            else
+                snprintf(m, sizeof m, "BGZF block %zu: CRC32 mismatch", i);
+            return inf_fail(f, QD_ERR_FORMAT, m);
+        }
+    }
+    memcpy(out, f->h_out, (size_t)out_len);
     return QD_OK;
 }
 

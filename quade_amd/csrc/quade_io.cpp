@@ -81,6 +81,25 @@ LibDeflate& deflate_lib() {
     return L;
 }
 
+}  // namespace
+
+// CRC-32 of a buffer (gzip's): libdeflate's slice-by-N when loaded, zlib's otherwise.  Used by the device inflater
+// (quade_api.cpp) to check every BGZF block it inflated.
+uint32_t qd_io_crc32(const uint8_t* p, size_t n) {
+    LibDeflate& L = deflate_lib();
+    if (L.ok && L.crc32) return L.crc32(0, p, n);
+    uLong c = crc32(0L, Z_NULL, 0);
+    while (n) {
+        const uInt k = (uInt)std::min<size_t>(n, 1u << 30);
+        c = crc32(c, p, k);
+        p += k;
+        n -= k;
+    }
+    return (uint32_t)c;
+}
+
+namespace {
+
 // byte buffer that is NOT value-initialised (std::vector<uint8_t>::resize writes every byte first)
 struct Bytes {
     std::unique_ptr<uint8_t[]> p;
@@ -597,7 +616,18 @@ constexpr size_t PIECE = 4u << 20;          // text handed to the scanner at a t
 
 }  // namespace
 
+// device inflate of BGZF runs (quade_api.cpp); weak: this file also builds without the HIP half (sanitizer tests)
+extern "C" {
+int qd_inflater_create(int device_id, qd_inflater** out) __attribute__((weak));
+int qd_inflater_run(qd_inflater* inflater, const uint8_t* comp, int64_t comp_len, uint8_t* out, int64_t out_len,
+                    int32_t* bad_block) __attribute__((weak));
+int qd_inflater_destroy(qd_inflater* inflater) __attribute__((weak));
+}
+
 struct qd_reader {
+    int inflate_device = -1;          // >= 0: BGZF runs go through an inflater on that device
+    qd_inflater* inflater = nullptr;  // created by the inflate thread at its first BGZF run
+    int64_t device_runs = 0, host_runs = 0;
     std::string path, err;
     int fd = -1;
     bool gz = false;
@@ -770,6 +800,27 @@ struct BgzfRun {  // consecutive blocks inflated by one pool job
 
 constexpr size_t BGZF_RUN_BYTES = 2u << 20;  // compressed bytes per job
 constexpr size_t BGZF_RUNS_IN_FLIGHT = 6;
+constexpr size_t BGZF_DEVICE_RUN_BYTES = 16u << 20;  // per device launch: one lane per block wants thousands of blocks
+
+// the blocks of a run, one after the other, on this thread
+void host_inflate_run(BgzfRun& run, LibDeflate& L) {
+    thread_local void* dec = nullptr;
+    if (!dec) dec = L.alloc_decompressor();
+    size_t ip = 0, op = 0;
+    bool good = dec != nullptr;
+    while (good && ip < run.in.size()) {
+        size_t ain = 0, aout = 0;
+        good = L.gzip_decompress_ex(dec, run.in.data() + ip, run.in.size() - ip, run.out.data() + op, run.out.size() - op,
+                                    &ain, &aout) == 0 && ain > 0;
+        ip += ain;
+        op += aout;
+    }
+    good = good && op == run.out.size();
+    std::lock_guard<std::mutex> g(run.m);
+    run.ok = good;
+    run.done = true;
+    run.cv.notify_all();
+}
 
 // The whole file as BGZF: the inflater thread only walks the block headers and hands runs of blocks to the
 // pool; it collects the runs in file order.  Returns false when the file stops being BGZF where a block is
@@ -798,11 +849,15 @@ bool inflate_bgzf(qd_reader* r, Input& in, int& cur, bool& ok) {
             cur ^= 1;
         }
     };
+    // device mode: a run is inflated by the GPU (one lane per block) while this thread waits for it -- the
+    // batcher works on the previous run meanwhile; a run the device refuses is inflated here instead
+    bool on_device = r->inflate_device >= 0 && qd_inflater_create && qd_inflater_run && qd_inflater_destroy;
+    if (on_device && !r->inflater && qd_inflater_create(r->inflate_device, &r->inflater) != QD_OK) on_device = false;
     while (ok && more) {
         // one run: whole blocks up to BGZF_RUN_BYTES
         std::shared_ptr<BgzfRun> run = std::make_shared<BgzfRun>();
         size_t out_bytes = 0;
-        while (run->in.size() < BGZF_RUN_BYTES) {
+        while (run->in.size() < (on_device ? BGZF_DEVICE_RUN_BYTES : BGZF_RUN_BYTES)) {
             if (!in.refill(1u << 17)) {
                 fail_reader(r, strerror(errno));
                 ok = false;
@@ -826,24 +881,26 @@ bool inflate_bgzf(qd_reader* r, Input& in, int& cur, bool& ok) {
         if (!run->in.empty()) {
             run->out.resize(out_bytes);
             flight.push_back(run);
-            pool().submit([run, &L] {
-                thread_local void* dec = nullptr;
-                if (!dec) dec = L.alloc_decompressor();
-                size_t ip = 0, op = 0;
-                bool good = dec != nullptr;
-                while (good && ip < run->in.size()) {
-                    size_t ain = 0, aout = 0;
-                    good = L.gzip_decompress_ex(dec, run->in.data() + ip, run->in.size() - ip, run->out.data() + op,
-                                                run->out.size() - op, &ain, &aout) == 0 && ain > 0;
-                    ip += ain;
-                    op += aout;
+            bool taken = false;
+            if (on_device) {
+                int32_t bad = -1;
+                const int rc = qd_inflater_run(r->inflater, run->in.data(), (int64_t)run->in.size(), run->out.data(),
+                                               (int64_t)run->out.size(), &bad);
+                if (rc == QD_OK) {
+                    std::lock_guard<std::mutex> g(run->m);
+                    run->ok = run->done = taken = true;
+                    ++r->device_runs;
+                } else if (rc != QD_ERR_FORMAT) {
+                    on_device = false;  // a HIP error: the host takes over for the rest of the file
                 }
-                good = good && op == run->out.size();
-                std::lock_guard<std::mutex> g(run->m);
-                run->ok = good;
-                run->done = true;
-                run->cv.notify_all();
-            }, true);
+            }
+            if (!taken && on_device) {
+                host_inflate_run(*run, L);  // the device refused this run (a damaged block shows here as run->ok == false)
+                ++r->host_runs;
+            } else if (!taken) {
+                ++r->host_runs;
+                pool().submit([run, &L] { host_inflate_run(*run, L); }, true);
+            }
         }
         while (ok && !flight.empty() && (flight.size() >= BGZF_RUNS_IN_FLIGHT || !more)) collect_one();
     }
@@ -1034,6 +1091,10 @@ extern "C" {
 const char* qd_reader_last_error(const qd_reader* r) { return r ? r->err.c_str() : g_reader_open_error.c_str(); }
 
 int qd_reader_open(const char* path, int64_t batch_records, int32_t queue_depth, qd_reader** out) {
+    return qd_reader_open_on(path, batch_records, queue_depth, -1, out);
+}
+
+int qd_reader_open_on(const char* path, int64_t batch_records, int32_t queue_depth, int32_t device_id, qd_reader** out) {
     if (!path || batch_records < 1 || queue_depth < 1 || queue_depth > 64 || !out) return QD_ERR_INVALID;
     *out = nullptr;
     const int fd = open(path, O_RDONLY | O_CLOEXEC);
@@ -1048,6 +1109,7 @@ int qd_reader_open(const char* path, int64_t batch_records, int32_t queue_depth,
     r->gz = n >= 3 && (path[n - 3] == '.') && (path[n - 2] == 'g' || path[n - 2] == 'G') && (path[n - 1] == 'z' || path[n - 1] == 'Z');
     r->B = batch_records;
     r->depth = (size_t)queue_depth;
+    r->inflate_device = device_id;
     r->th_inflate = std::thread(inflate_thread, r);
     r->th = std::thread(batch_thread, r);
     *out = r;
@@ -1090,8 +1152,16 @@ int qd_reader_close(qd_reader* r) {
     if (r->th_inflate.joinable()) r->th_inflate.join();
     if (r->th.joinable()) r->th.join();
     for (Batch* b : r->ready) delete b;
+    if (r->inflater && qd_inflater_destroy) qd_inflater_destroy(r->inflater);
     close(r->fd);
     delete r;
+    return QD_OK;
+}
+
+int qd_reader_inflate_stats(const qd_reader* r, int64_t* device_runs, int64_t* host_runs) {
+    if (!r) return QD_ERR_INVALID;
+    if (device_runs) *device_runs = r->device_runs;
+    if (host_runs) *host_runs = r->host_runs;
     return QD_OK;
 }
 

@@ -54,11 +54,13 @@ class TextBatch(object):
 
 
 class FastqStream(object):
-    def __init__(self, path, batch_records, queue_depth=2):
+    def __init__(self, path, batch_records, queue_depth=2, inflate_device=-1):
+        """inflate_device >= 0: the runs of a BGZF file are inflated on that GPU (one lane per block), everything
+        else -- and any run the device refuses -- by the reader's host threads."""
         self.path, self.batch_records = path, int(batch_records)
         self.lib = hb.load_library()
         h = C.c_void_p()
-        r = self.lib.qd_reader_open(str(path).encode(), self.batch_records, int(queue_depth), C.byref(h))
+        r = self.lib.qd_reader_open_on(str(path).encode(), self.batch_records, int(queue_depth), int(inflate_device), C.byref(h))
         if r != hb.QD_OK:
             raise IOError(self.lib.qd_reader_last_error(None).decode() or "%s: cannot open" % path)
         self._h = h
@@ -88,6 +90,12 @@ class FastqStream(object):
             return n, full, n_short
         finally:
             b.release()
+
+    def inflate_stats(self):
+        """(BGZF runs inflated on the device, on host threads) so far."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self.lib.qd_reader_inflate_stats(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def close(self):
         if getattr(self, "_h", None):

@@ -105,6 +105,12 @@ SYMBOLS = [
     ("qd_comm_last_error", C.c_char_p, []),
     ("qd_write_gzip_file", C.c_int, [C.c_char_p, _P, C.c_int64, C.c_int32, C.c_int64]),
     ("qd_reader_open", C.c_int, [C.c_char_p, C.c_int64, C.c_int32, C.POINTER(_P)]),
+    ("qd_reader_open_on", C.c_int, [C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    ("qd_reader_inflate_stats", C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("qd_inflater_create", C.c_int, [C.c_int, C.POINTER(_P)]),
+    ("qd_inflater_run", C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.POINTER(C.c_int32)]),
+    ("qd_inflater_destroy", C.c_int, [_P]),
+    ("qd_inflater_last_error", C.c_char_p, [_P]),
     ("qd_reader_next", C.c_int, [_P, C.POINTER(qd_text_batch)]),
     ("qd_text_batch_free", C.c_int, [_P]),
     ("qd_reader_close", C.c_int, [_P]),
@@ -503,3 +509,38 @@ class Comm(object):
         if getattr(self, "_h", None):
             self.lib.qd_comm_destroy(self._h)
             self._h = None
+
+
+class Inflater(object):
+    """BGZF blocks -> text on the device (qd_inflater_*): one lane per block, CRC32 of every block checked."""
+
+    def __init__(self, device_id=0):
+        self.lib = load_library()
+        h = _P()
+        r = self.lib.qd_inflater_create(int(device_id), C.byref(h))
+        if r != QD_OK:
+            raise QuadeHipError(r, self.lib.qd_inflater_last_error(None).decode())
+        self._h = h
+
+    def run(self, comp, out_len):
+        """comp: bytes of whole BGZF blocks; out_len: the sum of their ISIZE fields.  Returns the text (bytes)."""
+        src = np.frombuffer(comp, dtype=np.uint8)
+        out = np.empty(max(int(out_len), 1), dtype=np.uint8)
+        bad = C.c_int32(-1)
+        r = self.lib.qd_inflater_run(self._h, _ptr(src), len(src), _ptr(out), int(out_len), C.byref(bad))
+        if r != QD_OK:
+            e = QuadeHipError(r, self.lib.qd_inflater_last_error(self._h).decode())
+            e.bad_block = bad.value
+            raise e
+        return out[:out_len].tobytes()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.qd_inflater_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

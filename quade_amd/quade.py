@@ -251,12 +251,14 @@ class Quade(object):
                 writers.close()
             print("\tEnd of chunk {}".format(c + 1))
 
+        # BGZF inputs: inflated by the first device of this process (quade_inflate.hip), the rest by host threads
+        inflate_on = self.engine_groups[0][0].device_id if self.cf.device_inflate else -1
         if self.workers == 1:
             lookahead, opened, nxt = 2, deque(), 0
             try:
                 for i, c in enumerate(mine):
                     while nxt < len(mine) and nxt <= i + lookahead:
-                        opened.append([FastqStream(f, self.cf.batch_pairs) for f in chunks[mine[nxt]]])
+                        opened.append([FastqStream(f, self.cf.batch_pairs, inflate_device=inflate_on) for f in chunks[mine[nxt]]])
                         nxt += 1
                     one_chunk(c, opened.popleft(), self.engine_groups[0])
             finally:
@@ -279,7 +281,7 @@ class Quade(object):
                 except queue.Empty:
                     return
                 try:
-                    one_chunk(c, [FastqStream(f, self.cf.batch_pairs) for f in chunks[c]], engines)
+                    one_chunk(c, [FastqStream(f, self.cf.batch_pairs, inflate_device=inflate_on) for f in chunks[c]], engines)
                 except BaseException as e:  # surfaced in the main thread
                     errors.append(e)
 

@@ -1,0 +1,132 @@
+"""BGZF inflate on the device (qd_inflater_*, quade_amd/csrc/quade_inflate.hip) against zlib: every DEFLATE block
+type, the encoders that produce real files (zlib at several levels and strategies, libdeflate), damaged input,
+and the native reader with its BGZF runs on the GPU against the host reader."""
+import gzip
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bgzf_block(text, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+    """one BGZF block (bgzip / htslib layout) of <= 65280 text bytes"""
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    payload = c.compress(text) + c.flush()
+    bsize = 12 + 6 + len(payload) + 8
+    assert bsize <= 65536
+    head = b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+    return head + payload + struct.pack("<II", zlib.crc32(text) & 0xFFFFFFFF, len(text))
+
+
+def _fastq_text(rng, n_bytes):
+    out = []
+    size = 0
+    i = 0
+    while size < n_bytes:
+        L = int(rng.integers(8, 151))
+        rec = b"@SIM:1:FC:%d:%d 1:N:0:\n%s\n+\n%s\n" % (i, i * 7, bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), L)),
+                                                     bytes(rng.integers(35, 74, L).astype(np.uint8)))
+        out.append(rec)
+        size += len(rec)
+        i += 1
+    return b"".join(out)[:n_bytes]
+
+
+def _texts(rng):
+    yield "fastq", _fastq_text(rng, 300_000)
+    yield "one byte repeated", b"A" * 200_000                       # matches at distance 1, length 258
+    yield "random bytes", bytes(rng.integers(0, 256, 150_000).astype(np.uint8))  # incompressible: stored blocks
+    yield "short period", (b"ACGTTGCA" * 40_000)[:250_001]
+    yield "empty", b""
+    yield "one byte", b"x"
+    yield "two symbols", bytes(rng.choice(np.frombuffer(b"AB", np.uint8), 70_000))
+
+
+@pytest.mark.parametrize("level,strategy", [(0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY),
+                                            (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)])
+def test_device_inflate_equals_zlib(level, strategy):
+    from quade_amd.hip_backend import Inflater
+    rng = np.random.default_rng(level * 10 + strategy)
+    with Inflater(0) as inf:
+        for name, text in _texts(rng):
+            for block in (65280, 4000, 1):
+                if block == 1 and len(text) > 3000:
+                    continue
+                parts = [text[a:a + block] for a in range(0, len(text), block)] or [b""]
+                comp = b"".join(_bgzf_block(p, level, strategy) for p in parts)
+                assert inf.run(comp, len(text)) == text, (name, block)
+        assert inf.run(b"", 0) == b""
+
+
+def test_device_inflate_of_library_written_bgzf_and_damage(tmp_path):
+    """Files as synth / qd_write_gzip_file write them (libdeflate raw deflate per block, EOF block at the end);
+    a flipped payload byte, a wrong CRC and a wrong ISIZE are refused with the block's index."""
+    from quade_amd import hip_backend as hb
+    rng = np.random.default_rng(4)
+    text = _fastq_text(rng, 3_000_000)
+    lib = hb.load_library()
+    path = str(tmp_path / "x.fastq.gz")
+    src = np.frombuffer(text, dtype=np.uint8)
+    assert lib.qd_write_gzip_file(path.encode(), hb._ptr(src), len(src), 1, -1) == hb.QD_OK
+    comp = open(path, "rb").read()
+    assert gzip.decompress(comp) == text
+    with hb.Inflater(0) as inf:
+        assert inf.run(comp, len(text)) == text
+        # block boundaries, to damage block 3
+        offs, pos = [], 0
+        while pos < len(comp):
+            offs.append(pos)
+            pos += struct.unpack_from("<H", comp, pos + 16)[0] + 1
+        for what, at, delta in (("payload", offs[3] + 40, 1), ("crc", offs[4] - 8, 1), ("isize", offs[4] - 4, 1)):
+            bad = bytearray(comp)
+            bad[at] ^= 0x55
+            with pytest.raises(hb.QuadeHipError) as ei:
+                inf.run(bytes(bad), len(text))
+            assert ei.value.code == hb.QD_ERR_FORMAT, what
+            if what != "isize":
+                assert ei.value.bad_block == 3, (what, ei.value.bad_block)
+        with pytest.raises(hb.QuadeHipError):
+            inf.run(comp[:-10], len(text))          # not whole blocks
+        with pytest.raises(hb.QuadeHipError):
+            inf.run(gzip.compress(text), len(text))  # a gzip member, but not BGZF
+        assert inf.run(comp, len(text)) == text     # the inflater is usable after errors
+
+
+def test_reader_with_device_inflate_equals_host_reader(tmp_path):
+    from quade_amd import hip_backend as hb
+    from quade_amd.fastq_reader import FastqStream
+    rng = np.random.default_rng(8)
+    text = _fastq_text(rng, 40_000_000)
+    text = text[:text.rfind(b"\n@SIM") + 1]
+    lib = hb.load_library()
+    src = np.frombuffer(text, dtype=np.uint8)
+    bg, mixed = str(tmp_path / "b.fastq.gz"), str(tmp_path / "m.fastq.gz")
+    assert lib.qd_write_gzip_file(bg.encode(), hb._ptr(src), len(src), 1, -1) == hb.QD_OK
+    with open(mixed, "wb") as fh:  # BGZF blocks, then an ordinary gzip member: the reader switches back to the host
+        half = text[:len(text) // 2]
+        half = half[:half.rfind(b"\n@SIM") + 1]
+        s2 = np.frombuffer(half, dtype=np.uint8)
+        assert lib.qd_write_gzip_file((mixed + ".tmp").encode(), hb._ptr(s2), len(s2), 1, -1) == hb.QD_OK
+        fh.write(open(mixed + ".tmp", "rb").read()[:-28])  # without the EOF block
+        fh.write(gzip.compress(text[len(half):], 1))
+    for path in (bg, mixed):
+        got = {}
+        for dev in (-1, 0):
+            st = FastqStream(path, 100_000, inflate_device=dev)
+            chunks, n = [], 0
+            while True:
+                b = st.take()
+                if b.n == 0:
+                    break
+                chunks.append(bytes(b.text))
+                n += b.n
+                b.release()
+            stats = st.inflate_stats()
+            st.close()
+            got[dev] = (b"".join(chunks), n, stats)
+        assert got[0][0] == got[-1][0] == text and got[0][1] == got[-1][1]
+        assert got[-1][2][0] == 0 and got[0][2][0] > 0, got[0][2]   # the device really took runs
