@@ -351,6 +351,12 @@ typedef struct qd_inflater qd_inflater;
 int qd_inflater_create(int device_id, qd_inflater** out);
 int qd_inflater_run(qd_inflater* inflater, const uint8_t* comp, int64_t comp_len, uint8_t* out, int64_t out_len,
                     int32_t* bad_block);
+/* The same with `out` in page-locked memory from qd_pinned_alloc: the text is copied from the device straight
+ * into it (no staging copy on the host). */
+int qd_inflater_run_pinned(qd_inflater* inflater, const uint8_t* comp, int64_t comp_len, uint8_t* out, int64_t out_len,
+                           int32_t* bad_block);
+void* qd_pinned_alloc(int64_t bytes); /* NULL on failure */
+void qd_pinned_free(void* p);
 int qd_inflater_destroy(qd_inflater* inflater);
 const char* qd_inflater_last_error(const qd_inflater* inflater);
 /* A reader whose BGZF runs go through an inflater on `device_id` (< 0: host threads, as qd_reader_open). */

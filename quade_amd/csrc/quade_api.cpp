@@ -1024,6 +1024,7 @@ uint32_t qd_io_crc32(const uint8_t* p, size_t n);  // quade_io.cpp: libdeflate's
 struct qd_inflater {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;  // blocking-sync event: the calling thread sleeps while the device works
     std::string err;
     // grow-only staging: pinned host + device, for the compressed run, its text, the block table and the states
     uint8_t *h_comp = nullptr, *d_comp = nullptr, *h_out = nullptr, *d_out = nullptr;
@@ -1075,7 +1076,8 @@ int qd_inflater_create(int device_id, qd_inflater** out) {
     }
     qd_inflater* f = new qd_inflater();
     f->device = device_id;
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&f->done, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
         g_inflater_error = "hipStreamCreate failed";
         delete f;
         return QD_ERR_HIP;
@@ -1093,6 +1095,7 @@ int qd_inflater_destroy(qd_inflater* f) {
         (void)hipStreamSynchronize(f->stream);
         (void)hipStreamDestroy(f->stream);
     }
+    if (f->done) (void)hipEventDestroy(f->done);
     if (f->h_comp) (void)hipHostFree(f->h_comp);
     if (f->d_comp) (void)hipFree(f->d_comp);
     if (f->h_out) (void)hipHostFree(f->h_out);
@@ -1105,7 +1108,27 @@ int qd_inflater_destroy(qd_inflater* f) {
     return QD_OK;
 }
 
+// page-locked host memory for callers that want the text to land in their buffer without a staging copy
+void* qd_pinned_alloc(int64_t bytes) {
+    void* p = nullptr;
+    if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void qd_pinned_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+static int inflater_run(qd_inflater* f, const uint8_t* comp, int64_t comp_len, uint8_t* out, int64_t out_len, int32_t* bad_block,
+                        bool out_pinned);
 int qd_inflater_run(qd_inflater* f, const uint8_t* comp, int64_t comp_len, uint8_t* out, int64_t out_len, int32_t* bad_block) {
+    return inflater_run(f, comp, comp_len, out, out_len, bad_block, false);
+}
+int qd_inflater_run_pinned(qd_inflater* f, const uint8_t* comp, int64_t comp_len, uint8_t* out, int64_t out_len, int32_t* bad_block) {
+    return inflater_run(f, comp, comp_len, out, out_len, bad_block, true);
+}
+
+static int inflater_run(qd_inflater* f, const uint8_t* comp, int64_t comp_len, uint8_t* out, int64_t out_len, int32_t* bad_block,
+                        bool out_pinned) {
     if (bad_block) *bad_block = -1;
     if (!f || !comp || comp_len < 0 || out_len < 0 || (out_len > 0 && !out)) return inf_fail(f, QD_ERR_INVALID, "bad arguments");
     if (comp_len > (int64_t)0xFFFF0000ll || out_len > (int64_t)0xFFFF0000ll) return inf_fail(f, QD_ERR_INVALID, "run larger than 4 GiB");
@@ -1146,6 +1169,7 @@ int qd_inflater_run(qd_inflater* f, const uint8_t* comp, int64_t comp_len, uint8
     INFCHK(f, hipSetDevice(f->device));
     INFCHK(f, grow_pair(f->h_comp, f->d_comp, f->cap_comp, (size_t)comp_len));
     INFCHK(f, grow_pair(f->h_out, f->d_out, f->cap_out, (size_t)out_len + 16));
+    uint8_t* const text = out_pinned ? out : f->h_out;  // where the D2H copy lands
     INFCHK(f, grow_pair(f->h_blk, f->d_blk, f->cap_blk, blk.size()));
     INFCHK(f, grow_pair(f->h_st, f->d_st, f->cap_st, blk.size()));
     memcpy(f->h_comp, comp, (size_t)comp_len);
@@ -1154,11 +1178,12 @@ int qd_inflater_run(qd_inflater* f, const uint8_t* comp, int64_t comp_len, uint8
     INFCHK(f, hipMemcpyAsync(f->d_blk, f->h_blk, blk.size() * sizeof(qd_inflate_block), hipMemcpyHostToDevice, f->stream));
     INFCHK(f, qd_launch_inflate(f->d_comp, f->d_blk, (uint32_t)blk.size(), f->d_out, f->d_st, f->stream));
     INFCHK(f, hipMemcpyAsync(f->h_st, f->d_st, blk.size() * 4, hipMemcpyDeviceToHost, f->stream));
-    if (out_len) INFCHK(f, hipMemcpyAsync(f->h_out, f->d_out, (size_t)out_len, hipMemcpyDeviceToHost, f->stream));
-    INFCHK(f, hipStreamSynchronize(f->stream));
+    if (out_len) INFCHK(f, hipMemcpyAsync(text, f->d_out, (size_t)out_len, hipMemcpyDeviceToHost, f->stream));
+    INFCHK(f, hipEventRecord(f->done, f->stream));
+    INFCHK(f, hipEventSynchronize(f->done));
     // 3. every block: decoder status, then the CRC32 of its text
     for (size_t i = 0; i < blk.size(); ++i) {
-        if (f->h_st[i] != 0 || qd_io_crc32(f->h_out + blk[i].out_off, blk[i].out_len) != f->crc[i]) {
+        if (f->h_st[i] != 0 || qd_io_crc32(text + blk[i].out_off, blk[i].out_len) != f->crc[i]) {
             if (bad_block) *bad_block = (int32_t)i;
             char m[128];
             if (f->h_st[i])
@@ -1168,7 +1193,7 @@ int qd_inflater_run(qd_inflater* f, const uint8_t* comp, int64_t comp_len, uint8
             return inf_fail(f, QD_ERR_FORMAT, m);
         }
     }
-    memcpy(out, f->h_out, (size_t)out_len);
+    if (!out_pinned) memcpy(out, f->h_out, (size_t)out_len);
     return QD_OK;
 }
 

@@ -7,13 +7,16 @@
 // bounds the rate and inflate is 30 % of their work, while the GPU idles.
 //
 // One WAVE inflates one block.  DEFLATE is a serial bit stream: the symbol decode is one dependent chain, run
-// redundantly (wave-uniform) by all 64 lanes out of tables in LDS -- a 10-bit lookup for literal/length codes, an
-// 8-bit one for distances, the canonical bit-by-bit decode (RFC 1951; count[] / symbol[] per code) behind them for
-// longer codes.  What the lanes share is the work that is not serial: a match of up to 258 bytes is copied by
-// all lanes at once inside the block's 64 KiB output window, which lives in LDS (so a match never goes to memory
-// and back), and the finished window leaves as 16-byte coalesced stores.  Two blocks per CU (2 x 69 KB of LDS),
-// 512 on the chip.  (The first version had one LANE per block with its tables in scratch memory: 0.2 MB/s per
-// lane -- every table step and every copied byte a dependent trip to memory -- 0.1-1 GB/s in all.)
+// redundantly (wave-uniform, kept in scalar registers) by all 64 lanes out of tables in LDS -- a 10-bit lookup for
+// literal/length codes, an 8-bit one for distances, the canonical bit-by-bit decode (RFC 1951; count[] / symbol[]
+// per code) behind them for longer codes; the payload is read one dword ahead.  What the lanes share is the work
+// that is not serial: a match of up to 258 bytes is copied by all lanes at once.  The text is written in place
+// (global memory; a match reads back what this same wave stored earlier, through the same L1, in program order),
+// so a workgroup needs 3.6 KB of LDS and thousands of blocks are in flight: a launch takes ~16 ms whether it
+// holds 500 blocks or 8 000 (13 GB/s of text then).  History of the design, measured on 512 MB of fastq text
+// (profiles/r02_device_inflate.txt): one LANE per block with tables in scratch memory 0.1-1 GB/s (every table
+// step and copied byte a dependent trip to memory); one wave per block with the 64 KiB window in LDS 2.4 GB/s
+// (two waves per CU: nothing hides the chain's latency); this form 13 GB/s.
 //
 // Written for a machine where a fault can take the whole node down: every input read, window access, table
 // index and loop is bounded; any inconsistency ends the block with a status code and the host inflates that run
@@ -27,8 +30,7 @@ namespace {
 
 constexpr int LBITS = 10, DBITS = 8;         // first-level lookup widths
 constexpr uint32_t WINDOW = 65536;           // BGZF: ISIZE <= 64 KiB
-struct Lds {                                  // dynamic LDS of one workgroup (= one wave)
-    uint8_t out[WINDOW];
+struct Lds {                                  // dynamic LDS of one workgroup (= one wave): the tables only
     uint16_t llut[1 << LBITS];                // literal/length: symbol | code length << 9 (0 = longer code or none)
     uint16_t dlut[1 << DBITS];                // distance: symbol | code length << 5
     uint16_t lsym[288], dsym[32];             // symbols ordered by code (canonical decode of the longer codes)
@@ -149,7 +151,7 @@ __constant__ uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6,
 __constant__ uint8_t CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // literal/length + distance codes -> the window; 0 at the end-of-block symbol.  Wave-uniform control flow.
-__device__ int codes(Bits& b, Lds& L, uint32_t& opos, uint32_t olen, uint32_t lane, int nlsym, int ndsym) {
+__device__ int codes(Bits& b, Lds& L, uint8_t* o, uint32_t& opos, uint32_t olen, uint32_t lane, int nlsym, int ndsym) {
 #pragma unroll 1
     for (;;) {
         refill(b);
@@ -166,7 +168,7 @@ __device__ int codes(Bits& b, Lds& L, uint32_t& opos, uint32_t olen, uint32_t la
         if (sym < 0) return QD_INFLATE_BAD_CODE;
         if (sym < 256) {
             if (opos >= olen) return QD_INFLATE_OVERRUN;
-            if (lane == 0) L.out[opos] = (uint8_t)sym;
+            if (lane == 0) o[opos] = (uint8_t)sym;
             ++opos;
             continue;
         }
@@ -189,16 +191,14 @@ __device__ int codes(Bits& b, Lds& L, uint32_t& opos, uint32_t olen, uint32_t la
         if (b.cnt < 0) return QD_INFLATE_TRUNCATED;
         if (dist > opos) return QD_INFLATE_BAD_DISTANCE;  // a BGZF block never reaches behind its own start
         if (len > olen - opos) return QD_INFLATE_OVERRUN;
-        // the copy: all lanes, one byte each per round; a match longer than its distance repeats the last `dist` bytes
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        // the copy: all lanes, one byte each per round; a match longer than its distance repeats the last `dist` bytes.
+        // Source bytes were stored earlier by this same wave (lane 0's literals, earlier copies): its loads come
+        // after those stores in the one instruction stream all lanes share, through the same L1.
         const uint32_t from = opos - dist;
         for (uint32_t i = lane; i < len; i += 64) {
             const uint32_t s = dist >= len ? i : i % dist;
-            L.out[opos + i] = L.out[from + s];
+            o[opos + i] = o[from + s];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
         opos += len;
     }
 }
@@ -218,6 +218,7 @@ __global__ __launch_bounds__(64) void inflate_bgzf_blocks(const uint8_t* comp, c
     int err = 0, last = 0;
     uint32_t opos = 0;
     if (olen > WINDOW) err = QD_INFLATE_OVERRUN;
+    uint8_t* const o = out + blk.out_off;  // the block's text is written in place: matches read it back from there
     Bits b{comp + blk.in_off, 0, blk.in_len, 0, 0, 0, 0};
     fetch_ahead(b);
 #pragma unroll 1
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64) void inflate_bgzf_blocks(const uint8_t* comp, c
             else if (len > b.end - b.pos) err = QD_INFLATE_TRUNCATED;
             else if (len > olen - opos) err = QD_INFLATE_OVERRUN;
             else {
-                for (uint32_t k = lane; k < len; k += 64) L.out[opos + k] = b.p[b.pos + k];
+                for (uint32_t k = lane; k < len; k += 64) o[opos + k] = b.p[b.pos + k];
                 opos += len;
                 b.pos += len;
                 fetch_ahead(b);
@@ -345,32 +346,13 @@ __global__ __launch_bounds__(64) void inflate_bgzf_blocks(const uint8_t* comp, c
                 err = QD_INFLATE_BAD_TABLE;
                 break;
             }
-            err = codes(b, L, opos, olen, lane, lit_codes, dist_codes);
+            err = codes(b, L, o, opos, olen, lane, lit_codes, dist_codes);
         } else {
             err = QD_INFLATE_BAD_TYPE;
         }
     }
     if (!err && !last) err = QD_INFLATE_BAD_TYPE;
     if (!err && opos != olen) err = QD_INFLATE_LENGTH;
-    __syncthreads();
-    if (!err) {  // the window -> memory: 16 bytes per lane where the destination allows, bytes at the ragged ends
-        uint8_t* dst = out + blk.out_off;
-        const uint32_t head = (16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u;
-        const uint32_t h = head < olen ? head : olen;
-        for (uint32_t k = lane; k < h; k += 64) dst[k] = L.out[k];
-        const uint32_t body = (olen - h) & ~15u;
-        typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
-        for (uint32_t k = lane * 16; k < body; k += 64 * 16) {
-            v4u32 v;
-            const uint8_t* s = &L.out[h + k];  // LDS side may be misaligned by `head`: assemble from bytes of dwords
-            v.x = s[0] | (s[1] << 8) | (s[2] << 16) | ((uint32_t)s[3] << 24);
-            v.y = s[4] | (s[5] << 8) | (s[6] << 16) | ((uint32_t)s[7] << 24);
-            v.z = s[8] | (s[9] << 8) | (s[10] << 16) | ((uint32_t)s[11] << 24);
-            v.w = s[12] | (s[13] << 8) | (s[14] << 16) | ((uint32_t)s[15] << 24);
-            *reinterpret_cast<v4u32*>(dst + h + k) = v;
-        }
-        for (uint32_t k = h + body + lane; k < olen; k += 64) dst[k] = L.out[k];
-    }
     if (lane == 0) status[i] = err;
 }
 

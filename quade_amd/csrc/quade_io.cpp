@@ -622,12 +622,27 @@ int qd_inflater_create(int device_id, qd_inflater** out) __attribute__((weak));
 int qd_inflater_run(qd_inflater* inflater, const uint8_t* comp, int64_t comp_len, uint8_t* out, int64_t out_len,
                     int32_t* bad_block) __attribute__((weak));
 int qd_inflater_destroy(qd_inflater* inflater) __attribute__((weak));
+int qd_inflater_run_pinned(qd_inflater* inflater, const uint8_t* comp, int64_t comp_len, uint8_t* out, int64_t out_len,
+                           int32_t* bad_block) __attribute__((weak));
+void* qd_pinned_alloc(int64_t bytes) __attribute__((weak));
+void qd_pinned_free(void* p) __attribute__((weak));
 }
 
+namespace {
+struct BgzfRun;
+}
 struct qd_reader {
-    int inflate_device = -1;          // >= 0: BGZF runs go through an inflater on that device
-    qd_inflater* inflater = nullptr;  // created by the inflate thread at its first BGZF run
-    int64_t device_runs = 0, host_runs = 0;
+    int inflate_device = -1;          // >= 0: BGZF runs go through inflaters on that device
+    // device lanes: a few threads of this reader's own, each with its inflater, that mostly sleep on the device
+    // (the library's pool is for work that needs a core); runs queue here and are collected in file order
+    std::vector<std::thread> dev_threads;
+    std::mutex dm;
+    std::condition_variable dcv;
+    std::deque<std::shared_ptr<BgzfRun>> devq;
+    bool dev_stop = false, dev_failed = false;
+    std::vector<uint8_t*> pin_pool;   // page-locked text buffers of PIN_BYTES each, recycled between device runs
+    int64_t pin_made = 0;
+    std::atomic<int64_t> device_runs{0}, host_runs{0};
     std::string path, err;
     int fd = -1;
     bool gz = false;
@@ -790,9 +805,19 @@ size_t bgzf_block_size(const uint8_t* p, size_t avail) {
     return 0;
 }
 
+constexpr size_t PIN_BYTES = 48u << 20;  // text of one device run (16 MB of blocks inflate to ~30 MB of fastq text)
+
 struct BgzfRun {  // consecutive blocks inflated by one pool job
     std::vector<uint8_t> in;  // the compressed blocks (copied out of the window, which moves on)
     Bytes out;
+    // device runs: the text lands in a page-locked buffer of the reader's pool instead (no staging copy, no fresh
+    // pages to fault in per run); it goes back to the pool with the run
+    qd_reader* owner = nullptr;
+    uint8_t* pin = nullptr;
+    size_t out_len = 0;
+    uint8_t* text() { return pin ? pin : out.data(); }
+    size_t text_len() const { return pin ? out_len : out.size(); }
+    ~BgzfRun();
     std::mutex m;
     std::condition_variable cv;
     bool done = false, ok = true;
@@ -800,7 +825,8 @@ struct BgzfRun {  // consecutive blocks inflated by one pool job
 
 constexpr size_t BGZF_RUN_BYTES = 2u << 20;  // compressed bytes per job
 constexpr size_t BGZF_RUNS_IN_FLIGHT = 6;
-constexpr size_t BGZF_DEVICE_RUN_BYTES = 16u << 20;  // per device launch: one lane per block wants thousands of blocks
+constexpr size_t BGZF_DEVICE_RUN_BYTES = 16u << 20;  // per device launch: ~500 blocks (a launch takes ~16 ms whether it holds 500 blocks or 8 000)
+constexpr size_t BGZF_DEVICE_LANES = 3;              // launches in flight per reader
 
 // the blocks of a run, one after the other, on this thread
 void host_inflate_run(BgzfRun& run, LibDeflate& L) {
@@ -820,6 +846,60 @@ void host_inflate_run(BgzfRun& run, LibDeflate& L) {
     run.ok = good;
     run.done = true;
     run.cv.notify_all();
+}
+
+BgzfRun::~BgzfRun() {
+    if (pin && owner) {
+        std::lock_guard<std::mutex> g(owner->dm);
+        owner->pin_pool.push_back(pin);
+    }
+}
+
+// a device lane: takes queued runs, inflates them on the GPU (the thread sleeps meanwhile), falls back to the
+// host for a run the device refuses; after a HIP error the lane leaves the rest to the host
+void device_lane(qd_reader* r) {
+    LibDeflate& L = deflate_lib();
+    qd_inflater* inf = nullptr;
+    bool usable = qd_inflater_create(r->inflate_device, &inf) == QD_OK;
+    for (;;) {
+        std::shared_ptr<BgzfRun> run;
+        {
+            std::unique_lock<std::mutex> g(r->dm);
+            r->dcv.wait(g, [r] { return r->dev_stop || !r->devq.empty(); });
+            if (r->devq.empty()) break;
+            run = r->devq.front();
+            r->devq.pop_front();
+        }
+        bool taken = false;
+        if (usable) {
+            int32_t bad = -1;
+            const int rc = run->pin ? qd_inflater_run_pinned(inf, run->in.data(), (int64_t)run->in.size(), run->pin, (int64_t)run->out_len, &bad)
+                                    : qd_inflater_run(inf, run->in.data(), (int64_t)run->in.size(), run->out.data(), (int64_t)run->out.size(), &bad);
+            if (rc == QD_OK) {
+                std::lock_guard<std::mutex> g(run->m);
+                run->ok = run->done = taken = true;
+                run->cv.notify_all();
+                ++r->device_runs;
+            } else if (rc != QD_ERR_FORMAT) {
+                usable = false;
+                std::lock_guard<std::mutex> g(r->dm);
+                r->dev_failed = true;
+            }
+        }
+        if (!taken) {
+            if (run->pin) {  // the host inflates into ordinary memory
+                run->out.resize(run->out_len);
+                {
+                    std::lock_guard<std::mutex> g(r->dm);
+                    r->pin_pool.push_back(run->pin);
+                }
+                run->pin = nullptr;
+            }
+            host_inflate_run(*run, L);  // (a damaged block shows here as run->ok == false)
+            ++r->host_runs;
+        }
+    }
+    if (inf) qd_inflater_destroy(inf);
 }
 
 // The whole file as BGZF: the inflater thread only walks the block headers and hands runs of blocks to the
@@ -843,16 +923,17 @@ bool inflate_bgzf(qd_reader* r, Input& in, int& cur, bool& ok) {
             ok = false;
             return;
         }
-        if (run->out.size()) {
+        if (run->text_len()) {
             r->held[cur] = run;  // keeps the text alive until this slot is handed over again
-            ok = hand_over(r, cur, run->out.size(), run->out.data());
+            ok = hand_over(r, cur, run->text_len(), run->text());
             cur ^= 1;
         }
     };
     // device mode: a run is inflated by the GPU (one lane per block) while this thread waits for it -- the
     // batcher works on the previous run meanwhile; a run the device refuses is inflated here instead
     bool on_device = r->inflate_device >= 0 && qd_inflater_create && qd_inflater_run && qd_inflater_destroy;
-    if (on_device && !r->inflater && qd_inflater_create(r->inflate_device, &r->inflater) != QD_OK) on_device = false;
+    if (on_device && r->dev_threads.empty())
+        for (size_t i = 0; i < BGZF_DEVICE_LANES; ++i) r->dev_threads.emplace_back(device_lane, r);
     while (ok && more) {
         // one run: whole blocks up to BGZF_RUN_BYTES
         std::shared_ptr<BgzfRun> run = std::make_shared<BgzfRun>();
@@ -879,30 +960,33 @@ bool inflate_bgzf(qd_reader* r, Input& in, int& cur, bool& ok) {
         }
         if (!ok) break;
         if (!run->in.empty()) {
-            run->out.resize(out_bytes);
-            flight.push_back(run);
-            bool taken = false;
-            if (on_device) {
-                int32_t bad = -1;
-                const int rc = qd_inflater_run(r->inflater, run->in.data(), (int64_t)run->in.size(), run->out.data(),
-                                               (int64_t)run->out.size(), &bad);
-                if (rc == QD_OK) {
-                    std::lock_guard<std::mutex> g(run->m);
-                    run->ok = run->done = taken = true;
-                    ++r->device_runs;
-                } else if (rc != QD_ERR_FORMAT) {
-                    on_device = false;  // a HIP error: the host takes over for the rest of the file
+            if (on_device && qd_pinned_alloc && qd_inflater_run_pinned && out_bytes <= PIN_BYTES) {
+                std::lock_guard<std::mutex> g(r->dm);
+                if (!r->pin_pool.empty()) {
+                    run->pin = r->pin_pool.back();
+                    r->pin_pool.pop_back();
+                } else if (r->pin_made < 12) {  // lanes + queue + the two the batcher holds, with slack
+                    run->pin = (uint8_t*)qd_pinned_alloc((int64_t)PIN_BYTES);
+                    if (run->pin) ++r->pin_made;
                 }
+                run->owner = r;
+                run->out_len = out_bytes;
             }
-            if (!taken && on_device) {
-                host_inflate_run(*run, L);  // the device refused this run (a damaged block shows here as run->ok == false)
-                ++r->host_runs;
-            } else if (!taken) {
+            if (!run->pin) run->out.resize(out_bytes);
+            flight.push_back(run);
+            if (on_device) {
+                std::lock_guard<std::mutex> g(r->dm);
+                if (r->dev_failed) on_device = false;
+                else r->devq.push_back(run);
+            }
+            if (on_device) {
+                r->dcv.notify_one();
+            } else {
                 ++r->host_runs;
                 pool().submit([run, &L] { host_inflate_run(*run, L); }, true);
             }
         }
-        while (ok && !flight.empty() && (flight.size() >= BGZF_RUNS_IN_FLIGHT || !more)) collect_one();
+        while (ok && !flight.empty() && (flight.size() >= (on_device ? BGZF_DEVICE_LANES + 1 : BGZF_RUNS_IN_FLIGHT) || !more)) collect_one();
     }
     while (!flight.empty()) {  // stopping early (close / error): the jobs still reference their runs; just wait them out
         std::shared_ptr<BgzfRun> run = flight.front();
@@ -1152,7 +1236,17 @@ int qd_reader_close(qd_reader* r) {
     if (r->th_inflate.joinable()) r->th_inflate.join();
     if (r->th.joinable()) r->th.join();
     for (Batch* b : r->ready) delete b;
-    if (r->inflater && qd_inflater_destroy) qd_inflater_destroy(r->inflater);
+    {
+        std::lock_guard<std::mutex> g(r->dm);
+        r->dev_stop = true;
+    }
+    r->dcv.notify_all();
+    for (auto& t : r->dev_threads) t.join();
+    r->held[0].reset();  // runs give their page-locked buffers back to the pool: before the pool goes
+    r->held[1].reset();
+    for (uint8_t* p : r->pin_pool)
+        if (qd_pinned_free) qd_pinned_free(p);
+    r->pin_pool.clear();
     close(r->fd);
     delete r;
     return QD_OK;

@@ -109,6 +109,9 @@ SYMBOLS = [
     ("qd_reader_inflate_stats", C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("qd_inflater_create", C.c_int, [C.c_int, C.POINTER(_P)]),
     ("qd_inflater_run", C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.POINTER(C.c_int32)]),
+    ("qd_inflater_run_pinned", C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.POINTER(C.c_int32)]),
+    ("qd_pinned_alloc", _P, [C.c_int64]),
+    ("qd_pinned_free", None, [_P]),
     ("qd_inflater_destroy", C.c_int, [_P]),
     ("qd_inflater_last_error", C.c_char_p, [_P]),
     ("qd_reader_next", C.c_int, [_P, C.POINTER(qd_text_batch)]),

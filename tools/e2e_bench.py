@@ -3,7 +3,7 @@
 the CLI driver.  Host bound (gunzip, scan, format, gzip); printed as one JSON line.
 usage: python tools/e2e_bench.py [pairs] [gzip level] [chunks] [--single-member | --members] [--ranks N]
 input files: BGZF (bgzip layout) by default, --members = 8 MB gzip members, --single-member = one gzip member
-env: E2E_WORKERS (chunk_workers), E2E_IO_THREADS, E2E_SAMPLES (96), E2E_BATCH (500000), QUADE_PROFILE=1 (stage timers)"""
+env: E2E_DEVICE_INFLATE (0; 1 = BGZF inflate on the GPU), E2E_WORKERS (chunk_workers), E2E_IO_THREADS, E2E_SAMPLES (96), E2E_BATCH (500000), QUADE_PROFILE=1 (stage timers)"""
 import json
 import os
 import shutil
@@ -33,8 +33,9 @@ try:
     paths, bcs = synth.write_fastq_dataset(work, n, n_samples=n_samples, member_bytes=fmt)
     t_gen = time.perf_counter() - t0
     conf = os.path.join(work, "conf.txt")
-    synth.write_conf(conf, paths, bcs, n_chunks, gpu="[gpu]\nbatch_pairs : %d\ngzip_level : %d\nchunk_workers : %d\nio_threads : %d\n"
-                     % (batch, level, workers, io_thr))
+    dev_inflate = os.environ.get("E2E_DEVICE_INFLATE", "0") not in ("0", "false", "False")
+    synth.write_conf(conf, paths, bcs, n_chunks, gpu="[gpu]\nbatch_pairs : %d\ngzip_level : %d\nchunk_workers : %d\nio_threads : %d\ndevice_inflate : %s\n"
+                     % (batch, level, workers, io_thr, dev_inflate))
     out = os.path.join(work, "out")
     os.mkdir(out)
     os.chdir(out)
@@ -59,13 +60,14 @@ try:
         dt = time.perf_counter() - t0
         c1 = os.times()
         cpu_s = (c1.user - c0.user) + (c1.system - c0.system)  # every thread of this process (readers, pool, main)
+        cpu_user, cpu_sys = c1.user - c0.user, c1.system - c0.system
         counts = Sample.COUNTS()[:4]
     from quade_amd.fastq_writer import host_cores, io_backend, io_threads
     print(json.dumps({"mode": "end-to-end fastq.gz -> fastq.gz", "chunks": n_chunks, "pairs": n * n_chunks, "seconds": dt,
                       "pairs_per_s": n * n_chunks / dt, "gzip_level": level, "counts": counts, "chunk_workers": workers,
-                      "ranks": ranks, "samples": n_samples, "batch_pairs": batch, "input": {0: "single gzip member", "bgzf": "BGZF"}.get(fmt, "8 MB gzip members"), "gzip_backend": io_backend(),
+                      "ranks": ranks, "device_inflate": dev_inflate, "samples": n_samples, "batch_pairs": batch, "input": {0: "single gzip member", "bgzf": "BGZF"}.get(fmt, "8 MB gzip members"), "gzip_backend": io_backend(),
                       "io_threads": io_threads(), "host_cores": host_cores(), "host_logical_cpus": os.cpu_count(), "dataset_seconds": round(t_gen, 1),
-                      "cpu_seconds": cpu_s, "cpu_seconds_per_M_pairs": cpu_s / (n * n_chunks / 1e6) if cpu_s else None,
+                      "cpu_seconds": cpu_s, "cpu_user_sys": [round(cpu_user, 2), round(cpu_sys, 2)] if cpu_s else None, "cpu_seconds_per_M_pairs": cpu_s / (n * n_chunks / 1e6) if cpu_s else None,
                       "core_utilisation": cpu_s / (dt * host_cores()) if cpu_s else None}))
 finally:
     os.chdir("/")

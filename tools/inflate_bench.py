@@ -53,7 +53,8 @@ with hb.Inflater(0) as inf:
             i = j
         dt = time.perf_counter() - t0
         print("device inflater, runs of %d MB: %.3f s  %.2f GB/s of text (staging copies, H2D, kernel, D2H, CRC32 included)" % (run_mb, dt, out_total / dt / 1e9))
-for dev in (-1, 0):
+for dev in (-1, 0, -1, 0):
+    c0 = os.times()
     t0 = time.perf_counter()
     st = FastqStream(path, 500_000, inflate_device=dev)
     nrec = 0
@@ -66,6 +67,9 @@ for dev in (-1, 0):
     stats = st.inflate_stats()
     st.close()
     dt = time.perf_counter() - t0
-    print("native reader, inflate on %s: %.3f s  %.2f GB/s of text, %d records, runs device/host %s" % ("the device" if dev >= 0 else "host threads", dt, len(text) / dt / 1e9, nrec, stats))
+    c1 = os.times()
+    cpu = (c1.user - c0.user) + (c1.system - c0.system)
+    print("native reader, inflate on %s: %.3f s  %.2f GB/s of text, %d records, runs device/host %s, CPU %.2f s = %.2f core-s per GB of text (user %.2f sys %.2f)"
+          % ("the device" if dev >= 0 else "host threads", dt, len(text) / dt / 1e9, nrec, stats, cpu, cpu / (len(text) / 1e9), c1.user - c0.user, c1.system - c0.system))
 os.remove(path)
 os.rmdir(d)
