@@ -130,3 +130,30 @@ def test_reader_with_device_inflate_equals_host_reader(tmp_path):
             got[dev] = (b"".join(chunks), n, stats)
         assert got[0][0] == got[-1][0] == text and got[0][1] == got[-1][1]
         assert got[-1][2][0] == 0 and got[0][2][0] > 0, got[0][2]   # the device really took runs
+
+
+def test_cli_run_with_device_inflate_equals_host_inflate(tmp_path):
+    """The command line driver on BGZF inputs with `[gpu] device_inflate : True`: same files (decompressed), same
+    report as with the host's inflate; the readers did use the device."""
+    from quade_amd import synth
+    from quade_amd.quade import Quade
+    from quade_amd.sample import Sample
+    work = str(tmp_path)
+    paths, bcs = synth.write_fastq_dataset(work, 60_000, n_samples=24)
+    outs = {}
+    for mode in ("False", "True"):
+        conf = os.path.join(work, "conf_%s.txt" % mode)
+        synth.write_conf(conf, paths, bcs, 2, gpu="[gpu]\nbatch_pairs : 25000\ngzip_level : 1\ndevice_inflate : %s\n" % mode)
+        out = os.path.join(work, "out_" + mode)
+        os.mkdir(out)
+        cwd = os.getcwd()
+        os.chdir(out)
+        try:
+            assert Quade(conf_file=conf)() == 0
+        finally:
+            os.chdir(cwd)
+        files = sorted(f for f in os.listdir(out) if f.endswith(".fastq.gz"))
+        outs[mode] = (files, [gzip.open(os.path.join(out, f)).read() for f in files], Sample.COUNTS(),
+                      open(os.path.join(out, "Quade_report.csv")).read().split("\n")[1:])
+    assert outs["True"] == outs["False"]
+    assert outs["True"][2][0] == 120_000 and len(outs["True"][0]) > 20
