@@ -134,7 +134,8 @@ def test_reader_with_device_inflate_equals_host_reader(tmp_path):
 
 def test_cli_run_with_device_inflate_equals_host_inflate(tmp_path):
     """The command line driver on BGZF inputs with `[gpu] device_inflate : True`: same files (decompressed), same
-    report as with the host's inflate; the readers did use the device."""
+    report as with the host's inflate (that the readers' runs really go to the device is asserted by the reader
+    test above)."""
     from quade_amd import synth
     from quade_amd.quade import Quade
     from quade_amd.sample import Sample
