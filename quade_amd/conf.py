@@ -26,7 +26,7 @@ Optional [gpu] section (not in Quade 0.3.2; a conf file without it runs with the
   chunk_workers : 1      chunks processed concurrently by host threads (outputs identical)
   io_threads : 0         threads of the native gunzip / gzip pool (0 = one per core)
   device_inflate : False BGZF (bgzip) input files are inflated on the GPU, one block per wave (default: on host threads --
-                         on a 16-core host both ways run at the same rate; the GPU way uses ~10 % less CPU on long chunks)
+                         on a 16-core host both ways run at the same rate; the GPU way uses 5-10 % less CPU)
 """
 
 

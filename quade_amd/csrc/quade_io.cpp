@@ -855,12 +855,38 @@ BgzfRun::~BgzfRun() {
     }
 }
 
+// Inflaters (a stream + grow-only staging buffers each) and page-locked text buffers outlive the readers that
+// used them: a run with many chunks opens four readers per chunk, and setting these up per reader cost more
+// than the device saved.  Kept per device for the life of the process (a few hundred MB at most).
+std::mutex g_dev_cache_mutex;
+std::map<int, std::vector<qd_inflater*>> g_idle_inflaters;
+std::vector<uint8_t*> g_idle_pins;
+
+qd_inflater* borrow_inflater(int device) {
+    {
+        std::lock_guard<std::mutex> g(g_dev_cache_mutex);
+        auto& v = g_idle_inflaters[device];
+        if (!v.empty()) {
+            qd_inflater* f = v.back();
+            v.pop_back();
+            return f;
+        }
+    }
+    qd_inflater* f = nullptr;
+    return qd_inflater_create(device, &f) == QD_OK ? f : nullptr;
+}
+void return_inflater(int device, qd_inflater* f) {
+    if (!f) return;
+    std::lock_guard<std::mutex> g(g_dev_cache_mutex);
+    g_idle_inflaters[device].push_back(f);
+}
+
 // a device lane: takes queued runs, inflates them on the GPU (the thread sleeps meanwhile), falls back to the
 // host for a run the device refuses; after a HIP error the lane leaves the rest to the host
 void device_lane(qd_reader* r) {
     LibDeflate& L = deflate_lib();
-    qd_inflater* inf = nullptr;
-    bool usable = qd_inflater_create(r->inflate_device, &inf) == QD_OK;
+    qd_inflater* inf = borrow_inflater(r->inflate_device);
+    bool usable = inf != nullptr;
     for (;;) {
         std::shared_ptr<BgzfRun> run;
         {
@@ -899,7 +925,8 @@ void device_lane(qd_reader* r) {
             ++r->host_runs;
         }
     }
-    if (inf) qd_inflater_destroy(inf);
+    if (usable) return_inflater(r->inflate_device, inf);
+    else if (inf) qd_inflater_destroy(inf);
 }
 
 // The whole file as BGZF: the inflater thread only walks the block headers and hands runs of blocks to the
@@ -966,7 +993,14 @@ bool inflate_bgzf(qd_reader* r, Input& in, int& cur, bool& ok) {
                     run->pin = r->pin_pool.back();
                     r->pin_pool.pop_back();
                 } else if (r->pin_made < 12) {  // lanes + queue + the two the batcher holds, with slack
-                    run->pin = (uint8_t*)qd_pinned_alloc((int64_t)PIN_BYTES);
+                    {
+                        std::lock_guard<std::mutex> c(g_dev_cache_mutex);
+                        if (!g_idle_pins.empty()) {
+                            run->pin = g_idle_pins.back();
+                            g_idle_pins.pop_back();
+                        }
+                    }
+                    if (!run->pin) run->pin = (uint8_t*)qd_pinned_alloc((int64_t)PIN_BYTES);
                     if (run->pin) ++r->pin_made;
                 }
                 run->owner = r;
@@ -1244,8 +1278,13 @@ int qd_reader_close(qd_reader* r) {
     for (auto& t : r->dev_threads) t.join();
     r->held[0].reset();  // runs give their page-locked buffers back to the pool: before the pool goes
     r->held[1].reset();
-    for (uint8_t* p : r->pin_pool)
-        if (qd_pinned_free) qd_pinned_free(p);
+    {
+        std::lock_guard<std::mutex> c(g_dev_cache_mutex);
+        for (uint8_t* p : r->pin_pool) {
+            if (g_idle_pins.size() < 32) g_idle_pins.push_back(p);
+            else if (qd_pinned_free) qd_pinned_free(p);
+        }
+    }
     r->pin_pool.clear();
     close(r->fd);
     delete r;
