@@ -176,29 +176,41 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
         t0 = time.perf_counter()
         paths, bcs = synth.write_fastq_dataset(work, n_pairs)
         t_gen = time.perf_counter() - t0
-        conf = os.path.join(work, "conf.txt")
-        synth.write_conf(conf, paths, bcs, n_chunks, gpu="[gpu]\ngzip_level : %d\n" % gzip_level)
-        out = os.path.join(work, "out")
-        os.mkdir(out)
-        cwd = os.getcwd()
-        os.chdir(out)
-        try:
-            from quade_amd.quade import Quade
-            from quade_amd.sample import Sample
-            with stdout_to_stderr():  # the driver and the native sink print progress lines; stdout carries one JSON line
-                c0 = os.times()
-                t0 = time.perf_counter()
-                Quade(conf_file=conf)()
-                dt = time.perf_counter() - t0
-                c1 = os.times()
-            cpu_s = (c1.user - c0.user) + (c1.system - c0.system)  # all threads of this process: readers, pool, main
-            counts = Sample.COUNTS()[:4]
-        finally:
-            os.chdir(cwd)
-        in_bytes = sum(os.path.getsize(p) for p in paths.values()) * n_chunks
-        out_bytes = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out) if f.endswith(".gz"))
+        from quade_amd.quade import Quade
+        from quade_amd.sample import Sample
         n = n_pairs * n_chunks
-        return {"value": n / dt, "unit": "read-pairs/s", "pairs": n, "chunks": n_chunks, "seconds": dt, "gzip_level": gzip_level,
+
+        def run(level, tag):
+            conf = os.path.join(work, "conf_%s.txt" % tag)
+            synth.write_conf(conf, paths, bcs, n_chunks, gpu="[gpu]\ngzip_level : %d\n" % level)
+            out = os.path.join(work, "out_" + tag)
+            os.mkdir(out)
+            cwd = os.getcwd()
+            os.chdir(out)
+            try:
+                with stdout_to_stderr():  # the driver and the native sink print progress lines; stdout carries one JSON line
+                    c0 = os.times()
+                    t0 = time.perf_counter()
+                    Quade(conf_file=conf)()
+                    dt = time.perf_counter() - t0
+                    c1 = os.times()
+                cpu_s = (c1.user - c0.user) + (c1.system - c0.system)  # all threads of this process: readers, pool, main
+                counts = Sample.COUNTS()[:4]
+            finally:
+                os.chdir(cwd)
+            out_bytes = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out) if f.endswith(".gz"))
+            shutil.rmtree(out, ignore_errors=True)
+            return dt, cpu_s, counts, out_bytes
+
+        dt, cpu_s, counts, out_bytes = run(gzip_level, "lvl")
+        # the same job with gzip_level -1: output members are one dynamic-Huffman block of literals (no string matching)
+        dt_h, cpu_h, counts_h, out_bytes_h = run(-1, "huff")
+        in_bytes = sum(os.path.getsize(p) for p in paths.values()) * n_chunks
+        huff = {"value": n / dt_h, "unit": "read-pairs/s", "seconds": dt_h, "gzip_level": -1, "output_gz_bytes": out_bytes_h,
+                "cpu_seconds_per_M_pairs": cpu_h / (n / 1e6), "core_utilisation": cpu_h / (dt_h * max(host_cores(), 1)),
+                "counts_equal": counts_h == counts,
+                "what": "same input, [gpu] gzip_level : -1 (Huffman coding only; on real fastq ~25 % larger files than level 1)"}
+        return {"value": n / dt, "huffman_only": huff, "unit": "read-pairs/s", "pairs": n, "chunks": n_chunks, "seconds": dt, "gzip_level": gzip_level,
                 "samples": len(bcs), "gzip_backend": io_backend(), "io_threads": io_threads(), "host_cores": host_cores(),
                 "input_gz_bytes": in_bytes, "output_gz_bytes": out_bytes, "counts_total_pass_fail_undetermined": counts,
                 "dataset_seconds": t_gen,

@@ -289,7 +289,7 @@ typedef struct qd_text_batch qd_text_batch; /* a batch of the native reader, bel
 int qd_io_threads(int32_t n_threads);
 int qd_io_backend(void); /* 1 = libdeflate, 0 = zlib */
 int qd_host_cores(void); /* cores this process may use: affinity mask capped by the cgroup CPU quota */
-/* names: n_samples sample names in ordinal order (SAMPLE_LIST order, src/Sample.py:153); gzip_level 0..9;
+/* names: n_samples sample names in ordinal order (SAMPLE_LIST order, src/Sample.py:153); gzip_level -1..9 (-1 = Huffman coding only, no string matching: ~3x the speed of level 1, larger files);
  * write_*: the [output] flags (src/Quade.py:125-129 -> Sample.CLASS_INIT). */
 int qd_sink_create(const char* outdir, int32_t n_samples, const char* const* names, int32_t gzip_level,
                    int32_t write_pass, int32_t write_fail, int32_t write_undetermined, qd_sink** out);

@@ -22,7 +22,8 @@ Optional [gpu] section (not in Quade 0.3.2; a conf file without it runs with the
   devices : 0            GPUs to use: "all" or a blank separated list of device ids
   batch_pairs : 500000   read pairs per device batch (host memory in flight grows with it: ~3 GB at 2x150 bp)
   slots : 3              pinned staging slots per device (H2D / kernel / D2H overlap)
-  gzip_level : 6         deflate level of the output fastq.gz files (0-9)
+  gzip_level : 6         deflate level of the output fastq.gz files (0-9; -1 = Huffman coding only: ~3x the
+                         speed of level 1, files ~25 % larger on real data)
   chunk_workers : 1      chunks processed concurrently by host threads (outputs identical)
   io_threads : 0         threads of the native gunzip / gzip pool (0 = one per core)
   device_inflate : False BGZF (bgzip) input files are inflated on the GPU, one block per wave (default: on host threads --
@@ -123,9 +124,9 @@ class QuadeConf(object):
         for pos in [self.idx1_pos, self.idx2_pos, self.mol1_pos, self.mol2_pos]:
             assert pos["start"] >= 0
             assert pos["end"] >= pos["start"]
-        assert self.batch_pairs >= 1 and 1 <= self.slots <= 64 and 0 <= self.gzip_level <= 9 and \
+        assert self.batch_pairs >= 1 and 1 <= self.slots <= 64 and -1 <= self.gzip_level <= 9 and \
             1 <= self.chunk_workers <= 64 and 0 <= self.io_threads <= 1024, \
-            "[gpu] batch_pairs >= 1, 1 <= slots <= 64, 0 <= gzip_level <= 9, 1 <= chunk_workers <= 64, 0 <= io_threads <= 1024"
+            "[gpu] batch_pairs >= 1, 1 <= slots <= 64, -1 <= gzip_level <= 9, 1 <= chunk_workers <= 64, 0 <= io_threads <= 1024"
 
     def plan(self):
         """The qd_plan the HIP library takes (include/quade_hip.h)."""

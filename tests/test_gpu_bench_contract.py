@@ -49,6 +49,9 @@ def test_single_gpu_line():
     e = j["extra"]["e2e"]
     assert e["pairs"] == 30000 and e["value"] > 0 and e["gzip_level"] == 1 and e["gzip_backend"] in ("libdeflate", "zlib")
     assert e["counts_total_pass_fail_undetermined"][0] == 30000 == sum(e["counts_total_pass_fail_undetermined"][1:])
+    assert e["cpu_seconds"] > 0 and 0 < e["core_utilisation"] <= 1.05
+    h = e["huffman_only"]
+    assert h["gzip_level"] == -1 and h["value"] > 0 and h["counts_equal"] is True and h["output_gz_bytes"] > 0
 
 
 def test_two_ranks_self_spawned():

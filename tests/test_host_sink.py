@@ -63,15 +63,17 @@ def _compare(d1, d2):
     return f1
 
 
-@pytest.mark.parametrize("flags", [(True, True, True), (True, False, False), (False, False, True)])
-def test_sink_equals_oracle_writer(tmp_path, flags):
+@pytest.mark.parametrize("flags,level", [((True, True, True), 4), ((True, False, False), 4), ((False, False, True), 4),
+                                         ((True, True, True), -1), ((True, True, True), 0)])
+def test_sink_equals_oracle_writer(tmp_path, flags, level):
+    """level -1 = members of one dynamic-Huffman block of literals (no string matching), 0 = stored"""
     rng = np.random.default_rng(sum(flags))
     S = 5
     names = ["S%d" % i for i in range(S)]
     mine, ref = tmp_path / "mine", tmp_path / "ref"
     mine.mkdir()
     ref.mkdir()
-    sink = FastqSink(str(mine), names, 4, *flags, quiet=True)
+    sink = FastqSink(str(mine), names, level, *flags, quiet=True)
     batches = []
     for b in range(3):
         n = [700, 1, 2500][b]
@@ -301,3 +303,34 @@ def test_reader_to_sink_owned_batches_equal_plain_routing(tmp_path):
         s2.close()
         outs.append({f: _gz(str(o / f)) for f in sorted(os.listdir(o))})
     assert len(outs[0]) == 2 * (2 * len(bcs) + 1) and outs[0] == outs[1]
+
+
+def test_huffman_only_members_decode_with_gzip(tmp_path):
+    """gzip_level -1 (quade_io.cpp huffman_member): a histogram, a length-limited Huffman code, one table lookup per
+    byte.  Every shape of symbol statistics has to come out as a stream any gunzip accepts: one symbol, two, all
+    256, Fibonacci frequencies (an unlimited Huffman tree would be deeper than DEFLATE's 15 bits), incompressible
+    bytes, the empty input; as one member and as many."""
+    lib = hb.load_library()
+    rng = np.random.default_rng(3)
+    fib = [1, 1]
+    while len(fib) < 32:
+        fib.append(fib[-1] + fib[-2])
+    cases = {
+        "fastq": b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 150)),
+                                                   bytes(rng.integers(35, 74, 150).astype(np.uint8))) for i in range(3000)),
+        "one value": b"A" * 100000,
+        "all byte values": bytes(range(256)) * 300,
+        "fibonacci": b"".join(bytes([i]) * min(f, 200000) for i, f in enumerate(fib[:30])),
+        "random": bytes(rng.integers(0, 256, 300000).astype(np.uint8)),
+        "tiny": b"x", "two": b"ab", "empty": b"",
+    }
+    path = str(tmp_path / "h.gz")
+    for name, text in cases.items():
+        src = np.frombuffer(text, dtype=np.uint8) if text else np.zeros(1, np.uint8)
+        for member_bytes in (0, 65536, 1 << 20):
+            assert lib.qd_write_gzip_file(path.encode(), hb._ptr(src), len(text), -1, member_bytes) == hb.QD_OK
+            with open(path, "rb") as fh:
+                data = fh.read()
+            assert gzip.decompress(data) == text, (name, member_bytes)
+        if name == "fastq":  # the code is at least near the entropy of the bytes
+            assert len(data) < 0.62 * len(text)
