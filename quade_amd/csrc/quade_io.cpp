@@ -16,6 +16,7 @@
 //     zlib's otherwise -- both write standard gzip members, only decompressed bytes are pinned.
 // No GPU calls here: this file builds with plain g++ (sanitizer tests).
 #include <dlfcn.h>
+#include <immintrin.h>
 #include <fcntl.h>
 #include <sched.h>
 #include <unistd.h>
@@ -812,6 +813,9 @@ struct qd_reader {
     // producer state
     Batch* cur = nullptr;
     int64_t fill = 0, scan = 0;
+    std::vector<int64_t> nls;  // newline positions of cur->text found so far, beyond `scan`
+    size_t nl_at = 0;          // next unused entry of nls
+    int64_t nl_from = 0;       // cur->text has been searched for newlines up to here
     double avg = 400.0;  // bytes per record, learned
     uint8_t last = '\n';
 };
@@ -839,16 +843,53 @@ bool push_batch(qd_reader* r, Batch* b) {
     return true;
 }
 
+// Newline positions of t[from, to) appended to out: 32 bytes per step with AVX2 (a fastq line is ~80 bytes: one
+// memchr call per line spends more time entering and leaving memchr than searching), memchr elsewhere.
+__attribute__((target("avx2"))) void newlines_avx2(const uint8_t* t, int64_t from, int64_t to, std::vector<int64_t>& out) {
+    const __m256i nl = _mm256_set1_epi8('\n');
+    int64_t i = from;
+    for (; i + 32 <= to; i += 32) {
+        uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(t + i)), nl));
+        while (m) {
+            out.push_back(i + __builtin_ctz(m));
+            m &= m - 1;
+        }
+    }
+    for (; i < to; ++i)
+        if (t[i] == '\n') out.push_back(i);
+}
+void newlines(const uint8_t* t, int64_t from, int64_t to, std::vector<int64_t>& out) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return newlines_avx2(t, from, to, out);
+    for (int64_t i = from; i < to;) {
+        const void* p = memchr(t + i, '\n', (size_t)(to - i));
+        if (!p) break;
+        out.push_back((const uint8_t*)p - t);
+        i = ((const uint8_t*)p - t) + 1;
+    }
+}
+
 bool scan_records(qd_reader* r) {
     for (;;) {
         Batch* b = r->cur;
-        Rec rec;
-        while (b->n < r->B && next_record(b->text, r->fill, r->scan, rec)) {
-            if (rec.seq_end - rec.seq == rec.qual_end - rec.qual) {
-                b->off.push_back(rec.head);
+        // every newline of the text fed so far, then records four lines at a time (same rules as next_record():
+        // a record whose sequence and quality lengths differ is dropped, a trailing '\r' is not part of a line)
+        if (r->nl_from < r->fill) {
+            newlines(b->text, r->nl_from, r->fill, r->nls);
+            r->nl_from = r->fill;
+        }
+        const uint8_t* t = b->text;
+        while (b->n < r->B && r->nl_at + 4 <= r->nls.size()) {
+            const int64_t* e = &r->nls[r->nl_at];
+            const int64_t head = r->scan, seq = e[0] + 1, qual = e[2] + 1;
+            const int64_t seq_end = (e[1] > seq && t[e[1] - 1] == '\r') ? e[1] - 1 : e[1];
+            const int64_t qual_end = (e[3] > qual && t[e[3] - 1] == '\r') ? e[3] - 1 : e[3];
+            if (seq_end - seq == qual_end - qual) {
+                b->off.push_back(head);
                 ++b->n;
             }
-            r->scan = rec.next;
+            r->scan = e[3] + 1;
+            r->nl_at += 4;
         }
         if (b->n < r->B) return true;
         b->off.push_back(r->scan);
@@ -861,6 +902,15 @@ bool scan_records(qd_reader* r) {
             delete nb;
             r->cur = nullptr;
             return false;
+        }
+        // the newlines already found in the text that moves to the next batch move with it
+        {
+            const int64_t base = r->scan;
+            size_t k = 0;
+            for (size_t i = r->nl_at; i < r->nls.size(); ++i) r->nls[k++] = r->nls[i] - base;
+            r->nls.resize(k);
+            r->nl_at = 0;
+            r->nl_from -= base;
         }
         r->cur = nb;
         r->fill = left;
