@@ -651,7 +651,9 @@ static int route_impl(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_
     Pool& P = pool();
     for (const Piece& p : pieces) {
         P.submit([s, p, tag_rows, tag_stride, tag_len, res]() mutable {
-            Bytes text, member;
+            thread_local Bytes text;  // formatted records of this piece: the pool thread's scratch, grown once
+            Bytes member;
+            text.clear();
             text.resize((size_t)p.text_bytes + 8 * (size_t)p.n_sel + 16);
             const int64_t w = qd_format_records(p.text, p.rec_off, p.sel, p.n_sel, tag_rows, tag_stride, tag_len, text.data(),
                                                 (int64_t)text.size());
