@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 2
+#define QD_ABI_VERSION 3
 
 #define QD_OK 0
 #define QD_ERR_INVALID (-1)     /* bad argument (NULL pointer, misaligned buffer, size out of range)   */
@@ -170,6 +170,12 @@ int qd_set_option(qd_ctx* ctx, const char* name, int64_t value);
  * qd_get_counts waits for outstanding work of this context (only), then writes 2*S+4 values. */
 int qd_get_counts(qd_ctx* ctx, uint64_t* out, int32_t n_values);
 int qd_reset_counts(qd_ctx* ctx);
+/* Adds a counter vector (layout of qd_get_counts, e.g. another context's) to this context's totals.  The reference
+ * keeps ONE set of class counters per run (src/Sample.py:32,144); a process that drives several contexts on one
+ * device (chunk workers) folds the others into the context that is the member of its communicator before
+ * qd_reduce_counts, or into any one of them before the report.  Waits for this context's outstanding work.
+ * QD_ERR_INVALID when the vector's aggregates do not add up (TOTAL = PASS + FAIL + UNDETERMINED over the samples). */
+int qd_add_counts(qd_ctx* ctx, const uint64_t* counts, int32_t n_values);
 /* Waits for every outstanding launch / copy this context issued (on its own stream, its slots'
  * streams and the caller's streams it was handed) -- not for other contexts' work on the device. */
 int qd_synchronize(qd_ctx* ctx);

@@ -679,6 +679,30 @@ int qd_get_counts(qd_ctx* c, uint64_t* out, int32_t n_values) {
     return QD_OK;
 }
 
+// Counters another context of this process gathered (qd_get_counts layout) join this context's 64-bit totals: what
+// a process with several contexts on one device does before qd_reduce_counts, whose communicator holds one of them.
+int qd_add_counts(qd_ctx* c, const uint64_t* counts, int32_t n_values) {
+    if (!c || !counts) return QD_ERR_INVALID;
+    if (!c->have_table) return fail(c, QD_ERR_STATE, "qd_set_barcodes first");
+    if (n_values != 2 * c->S + 4) return fail(c, QD_ERR_INVALID, "n_values must be 2*S+4");
+    uint64_t pass = 0, failq = 0;
+    for (int i = 0; i < c->S; ++i) {
+        pass += counts[4 + 2 * i];
+        failq += counts[5 + 2 * i];
+    }
+    if (pass != counts[1] || failq != counts[2] || counts[0] != pass + failq + counts[3])
+        return fail(c, QD_ERR_INVALID, "counter vector is not self-consistent (TOTAL = PASS + FAIL + UNDETERMINED over the samples)");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, wait_all(c));  // demux_fixup adds to d_acc on the device: nothing of this context may be in flight
+    std::vector<u64> h((size_t)c->cnt_stride);
+    HIPCHK(c, hipMemcpy(h.data(), c->d_acc, h.size() * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 2 * c->S; ++i) h[(size_t)i] += counts[4 + i];
+    h[(size_t)(2 * c->S)] += counts[3];
+    HIPCHK(c, hipMemcpy(c->d_acc, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    c->total_pairs += counts[0];
+    return QD_OK;
+}
+
 int qd_reset_counts(qd_ctx* c) {
     if (!c) return QD_ERR_INVALID;
     if (!c->have_table) return QD_OK;

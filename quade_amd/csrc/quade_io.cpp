@@ -157,22 +157,20 @@ void huffman_lengths(const uint64_t* freq, int n, int max_bits, uint8_t* len) {
     }
     for (int k = 2 * m - 3; k >= 0; --k) depth[k] = depth[parent[k]] + 1;
     std::vector<int> bl(max_bits + 1, 0);
-    int overflow = 0;
-    for (int i = 0; i < m; ++i) {
-        int d = depth[i];
-        if (d > max_bits) {
-            d = max_bits;
-            ++overflow;
-        }
-        ++bl[d];
-    }
-    while (overflow > 0) {
+    for (int i = 0; i < m; ++i) ++bl[std::min(depth[i], max_bits)];
+    // Leaves deeper than the limit were clamped to it, so the code is over-subscribed by
+    // excess = sum bl[d] * 2^(max_bits - d) - 2^max_bits code points.  zlib's repair step -- the deepest leaf above
+    // the limit becomes an inner node whose children are itself and one leaf taken from the limit -- frees exactly
+    // one code point, so it runs `excess` times.  (Counting the overflow by clamped LEAVES only, as this did, stops
+    // too early once the unlimited tree is deeper than max_bits + 1: zlib counts clamped inner nodes too.)
+    uint64_t kraft = 0;
+    for (int d = 1; d <= max_bits; ++d) kraft += (uint64_t)bl[d] << (max_bits - d);
+    for (uint64_t excess = kraft - ((uint64_t)1 << max_bits); excess > 0; --excess) {
         int bits = max_bits - 1;
         while (bl[bits] == 0) --bits;
         --bl[bits];
         bl[bits + 1] += 2;
         --bl[max_bits];
-        overflow -= 2;
     }
     int at = 0;  // v is ascending by frequency: the longest codes first
     for (int bits = max_bits; bits >= 1; --bits)
@@ -228,6 +226,12 @@ bool huffman_member(const uint8_t* in, size_t n, Bytes& out) {
     freq[256] = 1;  // end of block
     uint8_t len[257];
     huffman_lengths(freq, 257, 15, len);
+    {  // a literal/length code must be complete (inflate refuses over- and under-subscribed sets): never emit another
+        uint32_t kraft = 0;
+        for (int s = 0; s < 257; ++s)
+            if (len[s]) kraft += 1u << (15 - len[s]);
+        if (kraft != (1u << 15)) return false;
+    }
     uint32_t code[257];  // bit-reversed canonical codes: DEFLATE sends Huffman codes most significant bit first
     {
         int bl[16] = {0}, next[16] = {0};
@@ -756,6 +760,8 @@ struct RawBuf {
 std::mutex g_text_pool_mutex;
 std::vector<std::pair<uint8_t*, int64_t>> g_text_pool;  // (buffer, capacity)
 constexpr size_t TEXT_POOL_MAX = 12;
+constexpr int64_t TEXT_POOL_MAX_BYTES = (int64_t)3 << 30;  // and never more than this much kept idle
+int64_t g_text_pool_bytes = 0;
 
 uint8_t* text_alloc(int64_t need, int64_t& cap) {
     {
@@ -764,6 +770,7 @@ uint8_t* text_alloc(int64_t need, int64_t& cap) {
             if (g_text_pool[i].second >= need && g_text_pool[i].second <= 3 * need) {
                 uint8_t* p = g_text_pool[i].first;
                 cap = g_text_pool[i].second;
+                g_text_pool_bytes -= cap;
                 g_text_pool.erase(g_text_pool.begin() + (long)i);
                 return p;
             }
@@ -775,8 +782,9 @@ void text_free(uint8_t* p, int64_t cap) {
     if (!p) return;
     {
         std::lock_guard<std::mutex> g(g_text_pool_mutex);
-        if (g_text_pool.size() < TEXT_POOL_MAX) {
+        if (g_text_pool.size() < TEXT_POOL_MAX && g_text_pool_bytes + cap <= TEXT_POOL_MAX_BYTES) {
             g_text_pool.emplace_back(p, cap);
+            g_text_pool_bytes += cap;
             return;
         }
     }
@@ -903,6 +911,8 @@ void newlines(const uint8_t* t, int64_t from, int64_t to, std::vector<int64_t>& 
     }
 }
 
+void fail_reader(qd_reader* r, const std::string& msg);
+
 bool scan_records(qd_reader* r) {
     for (;;) {
         Batch* b = r->cur;
@@ -931,6 +941,11 @@ bool scan_records(qd_reader* r) {
         r->avg = (double)r->scan / (double)b->n;
         const int64_t left = r->fill - r->scan;
         Batch* nb = new_batch(r, left);
+        if (!nb->text) {
+            fail_reader(r, "out of memory for a text batch");
+            delete nb;
+            return false;
+        }
         if (left) memcpy(nb->text, b->text + r->scan, (size_t)left);
         if (!push_batch(r, b)) {
             delete nb;
@@ -952,13 +967,21 @@ bool scan_records(qd_reader* r) {
     }
 }
 
+void fail_reader(qd_reader* r, const std::string& msg);
+
 bool feed(qd_reader* r, const uint8_t* d, size_t len) {
     while (len) {
         const size_t piece = std::min(len, PIECE);
         Batch* b = r->cur;
         if (r->fill + (int64_t)piece > b->cap) {
-            b->cap = std::max<int64_t>(b->cap * 2, r->fill + (int64_t)piece);
-            b->text = (uint8_t*)realloc(b->text, (size_t)b->cap);
+            const int64_t cap = std::max<int64_t>(b->cap * 2, r->fill + (int64_t)piece);
+            uint8_t* grown = (uint8_t*)realloc(b->text, (size_t)cap);
+            if (!grown) {
+                fail_reader(r, "out of memory growing a text batch");
+                return false;
+            }
+            b->text = grown;
+            b->cap = cap;
         }
         memcpy(b->text + r->fill, d, piece);
         r->fill += (int64_t)piece;
@@ -1118,6 +1141,10 @@ void device_lane(qd_reader* r) {
     LibDeflate& L = deflate_lib();
     qd_inflater* inf = borrow_inflater(r->inflate_device);
     bool usable = inf != nullptr;
+    // test hook: pretend the device fails once the reader has inflated this many runs on it (the fall-back to the
+    // host pool in the middle of a file is otherwise unreachable without breaking a GPU)
+    const char* fa = getenv("QUADE_TEST_INFLATE_FAIL_AFTER");
+    const int64_t fail_after = fa && *fa ? atoll(fa) : -1;
     for (;;) {
         std::shared_ptr<BgzfRun> run;
         {
@@ -1130,7 +1157,7 @@ void device_lane(qd_reader* r) {
         bool taken = false;
         if (usable) {
             int32_t bad = -1;
-            const int rc = run->pin ? qd_inflater_run_pinned(inf, run->in.data(), (int64_t)run->in.size(), run->pin, (int64_t)run->out_len, &bad)
+            const int rc = (fail_after >= 0 && r->device_runs >= fail_after) ? QD_ERR_HIP : run->pin ? qd_inflater_run_pinned(inf, run->in.data(), (int64_t)run->in.size(), run->pin, (int64_t)run->out_len, &bad)
                                     : qd_inflater_run(inf, run->in.data(), (int64_t)run->in.size(), run->out.data(), (int64_t)run->out.size(), &bad);
             if (rc == QD_OK) {
                 std::lock_guard<std::mutex> g(run->m);
@@ -1212,7 +1239,12 @@ bool inflate_bgzf(qd_reader* r, Input& in, int& cur, bool& ok) {
                 break;
             }
             const uint8_t* b = in.buf.data() + in.pos;
-            out_bytes += (size_t)b[bs - 4] | ((size_t)b[bs - 3] << 8) | ((size_t)b[bs - 2] << 16) | ((size_t)b[bs - 1] << 24);  // ISIZE
+            const size_t isize = (size_t)b[bs - 4] | ((size_t)b[bs - 3] << 8) | ((size_t)b[bs - 2] << 16) | ((size_t)b[bs - 1] << 24);
+            if (isize > 65536) {  // a BGZF block holds at most 64 KiB of text: whatever this is, its trailer does not size a buffer
+                still_bgzf = more = false;
+                break;
+            }
+            out_bytes += isize;
             run->in.insert(run->in.end(), b, b + bs);
             in.pos += bs;
         }
@@ -1241,9 +1273,22 @@ bool inflate_bgzf(qd_reader* r, Input& in, int& cur, bool& ok) {
             flight.push_back(run);
             if (on_device) {
                 std::lock_guard<std::mutex> g(r->dm);
-                if (r->dev_failed) on_device = false;
-                else r->devq.push_back(run);
+                if (r->dev_failed) {
+                    // the lanes have given the device up: this run (and the rest of the file) is the host pool's.  It
+                    // may already hold a page-locked buffer of the reader -- hand that back and give the run ordinary
+                    // memory, as device_lane does, or the host would inflate into an empty `out` (and a pool job
+                    // holding the last reference to the run would touch the reader after qd_reader_close)
+                    on_device = false;
+                    if (run->pin) {
+                        r->pin_pool.push_back(run->pin);
+                        run->pin = nullptr;
+                    }
+                    run->owner = nullptr;
+                } else {
+                    r->devq.push_back(run);
+                }
             }
+            if (!on_device && !run->pin && run->out.size() != out_bytes) run->out.resize(out_bytes);
             if (on_device) {
                 r->dcv.notify_one();
             } else {
@@ -1385,7 +1430,8 @@ void inflate_thread(qd_reader* r) {
 
 void batch_thread(qd_reader* r) {
     r->cur = new_batch(r, 0);
-    bool ok = true;
+    bool ok = r->cur->text != nullptr;
+    if (!ok) fail_reader(r, "out of memory for a text batch");
     for (int j = 0; ok; j ^= 1) {
         size_t len;
         {

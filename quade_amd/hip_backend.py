@@ -80,6 +80,7 @@ SYMBOLS = [
     ("qd_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("qd_get_counts", C.c_int, [_P, _P, C.c_int32]),
     ("qd_reset_counts", C.c_int, [_P]),
+    ("qd_add_counts", C.c_int, [_P, _P, C.c_int32]),
     ("qd_synchronize", C.c_int, [_P]),
     ("qd_slots_create", C.c_int, [_P, C.c_int32, C.c_int64]),
     ("qd_slots_destroy", C.c_int, [_P]),
@@ -399,6 +400,11 @@ class Engine(object):
         out = np.zeros(2 * self.n_samples + 4, dtype=np.uint64)
         self._chk(self.lib.qd_get_counts(self._h, _ptr(out), out.size))
         return out
+
+    def add_counts(self, counts):
+        """Another context's counter vector (numpy uint64[2S+4]) joins this context's totals (qd_add_counts)."""
+        counts = np.ascontiguousarray(counts, dtype=np.uint64)
+        self._chk(self.lib.qd_add_counts(self._h, _ptr(counts), counts.size))
 
     def reset_counts(self):
         self._chk(self.lib.qd_reset_counts(self._h))

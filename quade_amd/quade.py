@@ -210,6 +210,13 @@ class Quade(object):
         """The only exchange of the run: the counter vectors of every context, summed."""
         from . import dist
         if self.comm is not None:
+            # contexts of this process that are not members of the communicator (the other chunk workers'
+            # groups: same device, own counters) join a member's totals first -- the reference has ONE set
+            # of class counters per run (src/Sample.py:32,144)
+            members = set(id(e) for e in self.comm.engines)
+            for eng in self.engines:
+                if id(eng) not in members:
+                    self.comm.engines[0].add_counts(eng.counts())
             counts = self.comm.reduce_counts()  # RCCL all-reduce over xGMI
             self.comm.close()
             return counts

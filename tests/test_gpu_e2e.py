@@ -283,6 +283,40 @@ def test_rccl_count_reduce_through_the_c_abi():
     del torch
 
 
+def test_chunk_worker_contexts_join_the_rank_reduce():
+    """with a launcher (world > 1) and `chunk_workers` > 1 a rank drives several contexts, but its
+    communicator holds only the first; the others' counters must join it before the all-reduce (qd_add_counts),
+    or the report under-counts.  Driven through Quade._reduce_counts with the one-rank communicator a 1-GPU box
+    can hold; the real N-rank form is in test_gpu_multi.py (needs >= 2 devices)."""
+    from quade_amd import hip_backend as hb
+    from quade_amd import synth
+    from quade_amd.quade import Quade
+    from tests import helpers as H
+    ws = [synth.generate("cfg3", n, seed=sd) for n, sd in ((20011, 31), (7001, 32), (13, 33))]
+    bcs = ws[0].barcode_strings()
+    engines, want = [], None
+    for w in ws:
+        w.barcodes = ws[0].barcodes  # one sample sheet; the reads of the other workloads mostly miss it
+        _, _, _, c = H.oracle_on_workload(w)
+        want = c if want is None else want + c
+        eng = hb.Engine(0)
+        eng.set_plan(w.plan)
+        eng.set_barcodes(bcs)
+        H.hip_on_device(eng, [t.cuda() for t in w.seq], [t.cuda() for t in w.qual], w.n)
+        engines.append(eng)
+    q = Quade.__new__(Quade)
+    q.engines, q.world, q.rank, q.outdir, q.token = engines, 1, 0, ".", "t"
+    q.comm = hb.Comm.rank(engines[0], 1, 0, hb.comm_unique_id())
+    got = q._reduce_counts([0])
+    assert (got == want).all() and int(got[0]) == sum(w.n for w in ws)
+    with pytest.raises(hb.QuadeHipError):  # aggregates that do not add up are refused
+        bad = engines[1].counts()
+        bad[0] += 1
+        engines[0].add_counts(bad)
+    for eng in engines:
+        eng.close()
+
+
 def test_pinned_slots_streaming_vs_oracle():
     """H2D || kernel || D2H through the pinned slots, several batches in flight, no torch."""
     from quade_amd import synth

@@ -132,6 +132,36 @@ def test_reader_with_device_inflate_equals_host_reader(tmp_path):
         assert got[-1][2][0] == 0 and got[0][2][0] > 0, got[0][2]   # the device really took runs
 
 
+def test_reader_survives_a_device_that_fails_mid_file(tmp_path, monkeypatch):
+    """once the device lanes give up (`dev_failed`), the run under construction may already hold one of the
+    reader's page-locked buffers; it must go to the host pool with ordinary memory, not with an empty `out`.  The
+    hook makes every device run after the first fail like a HIP error would."""
+    from quade_amd import hip_backend as hb
+    from quade_amd.fastq_reader import FastqStream
+    rng = np.random.default_rng(81)
+    piece = _fastq_text(rng, 30_000_000)
+    piece = piece[:piece.rfind(b"\n@SIM") + 1]
+    text = piece * 8  # ~100 MB of blocks: several 16 MB device runs, more than the lanes hold at once
+    lib = hb.load_library()
+    src = np.frombuffer(text, dtype=np.uint8)
+    bg = str(tmp_path / "b.fastq.gz")
+    assert lib.qd_write_gzip_file(bg.encode(), hb._ptr(src), len(src), 1, -1) == hb.QD_OK
+    monkeypatch.setenv("QUADE_TEST_INFLATE_FAIL_AFTER", "1")
+    st = FastqStream(bg, 200_000, inflate_device=0)
+    chunks, n = [], 0
+    while True:
+        b = st.take()   # raised "damaged BGZF block" on this healthy file before the fix
+        if b.n == 0:
+            break
+        chunks.append(bytes(b.text))
+        n += b.n
+        b.release()
+    dev_runs, host_runs = st.inflate_stats()
+    st.close()
+    assert b"".join(chunks) == text and n == text.count(b"\n") // 4
+    assert dev_runs >= 1 and host_runs >= 2, (dev_runs, host_runs)
+
+
 def test_cli_run_with_device_inflate_equals_host_inflate(tmp_path):
     """The command line driver on BGZF inputs with `[gpu] device_inflate : True`: same files (decompressed), same
     report as with the host's inflate (that the readers' runs really go to the device is asserted by the reader

@@ -324,6 +324,13 @@ def test_huffman_only_members_decode_with_gzip(tmp_path):
         "random": bytes(rng.integers(0, 256, 300000).astype(np.uint8)),
         "tiny": b"x", "two": b"ab", "empty": b"",
     }
+    # steep geometric tails: counts 1, 2, 4 ... 2^(k-1) give an unlimited tree of depth k (the end-of-block symbol
+    # adds one more), i.e. two and more levels beyond the 15-bit limit -- where counting clamped leaves only, instead
+    # of every clamped node as zlib does, left the code over-subscribed; and a strict Fibonacci chain
+    for k in (16, 17, 18, 19, 20, 22, 24):
+        cases["powers of two, %d symbols" % k] = b"".join(bytes([65 + i]) * (1 << i) for i in range(k))
+    cases["strict fibonacci, 34 symbols"] = b"".join(bytes([40 + i]) * f for i, f in enumerate(fib[:34][1:]))
+    cases["tail behind a fastq body"] = cases["fastq"] + b"".join(bytes([130 + i]) * (1 << i) for i in range(19))
     path = str(tmp_path / "h.gz")
     for name, text in cases.items():
         src = np.frombuffer(text, dtype=np.uint8) if text else np.zeros(1, np.uint8)
