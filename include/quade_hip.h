@@ -344,6 +344,29 @@ int qd_text_batch_free(void* handle);
 int qd_reader_close(qd_reader* reader);
 const char* qd_reader_last_error(const qd_reader* reader); /* reader == NULL: why qd_reader_open failed on this thread */
 
+/* ---- ordinary gzip files: parallel inflate on the library's pool ------------------------------------------------
+ * The reference opens ordinary .fastq.gz files (src/Quade.py:203-206, 234-236; its fixtures under test/dataset
+ * are single gzip members): one DEFLATE stream, which a single thread inflates at a few hundred MB/s.  The reader
+ * cuts such a file at fixed offsets, finds a block start behind every cut by trying every bit offset, inflates
+ * the chunks in parallel into 16-bit symbols over a window of markers, proves every boundary by the chain from the
+ * start of the stream, resolves the markers in file order and checks every member's CRC-32 and ISIZE
+ * (quade_amd/csrc/quade_pgz.h).  Result: the bytes zlib would give, or an error.
+ * qd_io_set_option names (process-wide; tests and tuning):
+ *   "parallel_gunzip"        1 (default) / 0 = one thread per file (libdeflate per member, streaming zlib beyond 32 MB)
+ *   "gunzip_chunk_bytes"     compressed bytes per chunk (default 4 MiB, at least 64 KiB)
+ *   "gunzip_min_file_bytes"  smaller files are inflated by one thread (default 8 MiB)
+ *   "gunzip_in_flight"       chunks in flight per file, 0 (default) = one per pool thread */
+int qd_io_set_option(const char* name, int64_t value);
+/* Chunks of this reader's file that were inflated speculatively and proven / inflated by the coordinator itself. */
+int qd_reader_gunzip_stats(const qd_reader* reader, int64_t* parallel_chunks, int64_t* serial_chunks);
+/* A whole gzip file image in memory -> its text, by the same parallel inflater (chunk_bytes 0 = the option's value).
+ * stats (may be NULL): int64[5] = pieces, of them speculative and proven, inflated by the coordinator, members whose
+ * trailer was checked, bit offsets tried by the block searches.  QD_ERR_FORMAT: damaged or truncated stream
+ * (qd_gunzip_last_error); QD_ERR_INVALID: out_cap too small. */
+int qd_gunzip_buffer(const uint8_t* comp, int64_t comp_len, int64_t chunk_bytes, uint8_t* out, int64_t out_cap,
+                     int64_t* out_len, int64_t* stats);
+const char* qd_gunzip_last_error(void);
+
 /* ---- BGZF inflate on the device ------------------------------------------------------------------------
  * The gunzip inside pyFastq.FastqReader (src/Quade.py:203-214), for BGZF (bgzip) files: their blocks are
  * independent gzip members of <= 64 KiB that carry their compressed and inflated sizes, so a run of them is

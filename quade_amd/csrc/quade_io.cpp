@@ -19,6 +19,8 @@
 #include <immintrin.h>
 #include <fcntl.h>
 #include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -40,6 +42,7 @@
 
 #include "../../include/quade_hip.h"
 #include "fastq_scan.h"
+#include "quade_pgz.h"
 
 namespace {
 
@@ -833,6 +836,7 @@ struct qd_reader {
     std::vector<uint8_t*> pin_pool;   // page-locked text buffers of PIN_BYTES each, recycled between device runs
     int64_t pin_made = 0;
     std::atomic<int64_t> device_runs{0}, host_runs{0};
+    std::atomic<int64_t> pgz_parallel{0}, pgz_serial{0};  // ordinary gzip: chunks inflated speculatively / by the coordinator
     std::string path, err;
     int fd = -1;
     bool gz = false;
@@ -1312,6 +1316,53 @@ bool inflate_bgzf(qd_reader* r, Input& in, int& cur, bool& ok) {
     return still_bgzf;
 }
 
+// ---- ordinary gzip files (one member or a few, of any size): parallel inflate, quade_pgz.cpp -------------------
+std::atomic<int64_t> g_pgz_enabled{1};
+std::atomic<int64_t> g_pgz_chunk_bytes{4 << 20};
+std::atomic<int64_t> g_pgz_min_file_bytes{8 << 20};  // smaller files: one thread is done before a second could help
+std::atomic<int64_t> g_pgz_in_flight{0};             // 0 = one chunk per pool thread
+
+qdpgz::Options pgz_options() {
+    qdpgz::Options o;
+    o.chunk_bytes = (size_t)std::max<int64_t>(g_pgz_chunk_bytes.load(), 64 << 10);
+    const int64_t f = g_pgz_in_flight.load();
+    o.in_flight = f > 0 ? (int)f : std::max(4, pool().size());
+    return o;
+}
+
+// The whole file through the parallel inflater; false when the file cannot be mapped (a pipe ...): the caller's
+// sequential loop takes it then.  *ok = false after an error (the reader has been failed).
+bool inflate_parallel(qd_reader* r, int& cur, bool& ok) {
+    struct stat sb;
+    if (fstat(r->fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < g_pgz_min_file_bytes.load()) return false;
+    const size_t size = (size_t)sb.st_size;
+    if (size == 0) return false;
+    void* map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, r->fd, 0);
+    if (map == MAP_FAILED) return false;
+    (void)madvise(map, size, MADV_SEQUENTIAL);
+    {
+        qdpgz::Gunzip gz((const uint8_t*)map, size, pgz_options(), [](std::function<void()> fn) { pool().submit(std::move(fn), true); });
+        while (ok) {
+            std::shared_ptr<qdpgz::Text> t;
+            const int rc = gz.next(&t);
+            if (rc == 0) break;
+            if (rc < 0) {
+                fail_reader(r, gz.error());
+                ok = false;
+                break;
+            }
+            r->held[cur] = t;  // keeps the text alive until this slot is handed over again
+            ok = hand_over(r, cur, t->len, t->data);
+            cur ^= 1;
+        }
+        const qdpgz::Stats st = gz.stats();
+        r->pgz_parallel = st.parallel;
+        r->pgz_serial = st.serial;
+    }  // (the inflater waits for its jobs before the mapping goes)
+    munmap(map, size);
+    return true;
+}
+
 void inflate_thread(qd_reader* r) {
     Input in(r->fd);
     int cur = 0;  // scratch block being filled (block 0 starts free)
@@ -1342,6 +1393,12 @@ void inflate_thread(qd_reader* r) {
                 r->hcv.notify_all();
                 return;
             }
+        }
+        if (in.pos == 0 && g_pgz_enabled.load() && inflate_parallel(r, cur, ok)) {
+            std::lock_guard<std::mutex> g(r->hm);
+            r->inflated = true;
+            r->hcv.notify_all();
+            return;
         }
         void* dec = L.ok ? L.alloc_decompressor() : nullptr;
         bool whole_members = dec != nullptr;  // until a member turns out not to fit the window
@@ -1565,6 +1622,63 @@ int qd_reader_close(qd_reader* r) {
     r->pin_pool.clear();
     close(r->fd);
     delete r;
+    return QD_OK;
+}
+
+int qd_io_set_option(const char* name, int64_t value) {
+    if (!name) return QD_ERR_INVALID;
+    const std::string n(name);
+    if (n == "parallel_gunzip") g_pgz_enabled = value != 0;
+    else if (n == "gunzip_chunk_bytes" && value >= (64 << 10)) g_pgz_chunk_bytes = value;
+    else if (n == "gunzip_min_file_bytes" && value >= 0) g_pgz_min_file_bytes = value;
+    else if (n == "gunzip_in_flight" && value >= 0 && value <= 256) g_pgz_in_flight = value;
+    else return QD_ERR_INVALID;
+    return QD_OK;
+}
+
+int qd_reader_gunzip_stats(const qd_reader* r, int64_t* parallel_chunks, int64_t* serial_chunks) {
+    if (!r) return QD_ERR_INVALID;
+    if (parallel_chunks) *parallel_chunks = r->pgz_parallel;
+    if (serial_chunks) *serial_chunks = r->pgz_serial;
+    return QD_OK;
+}
+
+static thread_local std::string g_gunzip_error;
+const char* qd_gunzip_last_error(void) { return g_gunzip_error.c_str(); }
+
+int qd_gunzip_buffer(const uint8_t* comp, int64_t comp_len, int64_t chunk_bytes, uint8_t* out, int64_t out_cap, int64_t* out_len,
+                     int64_t* stats) {
+    if ((!comp && comp_len) || comp_len < 0 || (!out && out_cap) || out_cap < 0 || !out_len) return QD_ERR_INVALID;
+    qdpgz::Options o = pgz_options();
+    if (chunk_bytes > 0) o.chunk_bytes = (size_t)chunk_bytes;
+    qdpgz::Gunzip gz(comp, (size_t)comp_len, o, [](std::function<void()> fn) { pool().submit(std::move(fn), true); });
+    int64_t at = 0;
+    int rc;
+    for (;;) {
+        std::shared_ptr<qdpgz::Text> t;
+        rc = gz.next(&t);
+        if (rc != 1) break;
+        if (at + (int64_t)t->len > out_cap) {
+            g_gunzip_error = "output buffer too small";
+            *out_len = at;
+            return QD_ERR_INVALID;
+        }
+        memcpy(out + at, t->data, t->len);
+        at += (int64_t)t->len;
+    }
+    *out_len = at;
+    if (stats) {
+        const qdpgz::Stats st = gz.stats();
+        stats[0] = st.chunks;
+        stats[1] = st.parallel;
+        stats[2] = st.serial;
+        stats[3] = st.members;
+        stats[4] = st.search_bits;
+    }
+    if (rc < 0) {
+        g_gunzip_error = gz.error();
+        return QD_ERR_FORMAT;
+    }
     return QD_OK;
 }
 

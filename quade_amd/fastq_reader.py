@@ -97,6 +97,12 @@ class FastqStream(object):
         self.lib.qd_reader_inflate_stats(self._h, C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def gunzip_stats(self):
+        """(chunks of an ordinary gzip file inflated speculatively and proven, chunks inflated by the coordinator)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self.lib.qd_reader_gunzip_stats(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.qd_reader_close(self._h)

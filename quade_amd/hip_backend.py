@@ -115,6 +115,10 @@ SYMBOLS = [
     ("qd_pinned_free", None, [_P]),
     ("qd_inflater_destroy", C.c_int, [_P]),
     ("qd_inflater_last_error", C.c_char_p, [_P]),
+    ("qd_io_set_option", C.c_int, [C.c_char_p, C.c_int64]),
+    ("qd_reader_gunzip_stats", C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("qd_gunzip_buffer", C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.POINTER(C.c_int64), _P]),
+    ("qd_gunzip_last_error", C.c_char_p, []),
     ("qd_reader_next", C.c_int, [_P, C.POINTER(qd_text_batch)]),
     ("qd_text_batch_free", C.c_int, [_P]),
     ("qd_reader_close", C.c_int, [_P]),

@@ -251,6 +251,7 @@ int main(int argc, char** argv) {
     exe = tmp_path / "drv"
     cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=thread", "-fno-omit-frame-pointer", "-I", ROOT, str(drv),
            os.path.join(ROOT, "quade_amd", "csrc", "quade_io.cpp"), os.path.join(ROOT, "quade_amd", "csrc", "fastq_pack.cpp"),
+           os.path.join(ROOT, "quade_amd", "csrc", "quade_pgz.cpp"),
            "-o", str(exe), "-lz", "-ldl", "-lpthread"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
