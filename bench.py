@@ -205,12 +205,36 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
         dt, cpu_s, counts, out_bytes = run(gzip_level, "lvl")
         # the same job with gzip_level -1: output members are one dynamic-Huffman block of literals (no string matching)
         dt_h, cpu_h, counts_h, out_bytes_h = run(-1, "huff")
+        # ... at the driver's own default output level (conf.py: gzip_level 6; the reference's gzip.open default is 9)
+        dt_6, cpu_6, counts_6, out_bytes_6 = run(6, "lvl6")
         in_bytes = sum(os.path.getsize(p) for p in paths.values()) * n_chunks
+        # ... and on the reference's real input format: every input file ONE ordinary gzip member (src/Quade.py:203-206
+        # opens plain .fastq.gz; its fixtures are single members) -- inflated in parallel by quade_pgz.cpp
+        bgzf_paths = paths
+        single_dir = os.path.join(work, "single")
+        os.mkdir(single_dir)
+        paths, _ = synth.write_fastq_dataset(single_dir, n_pairs, member_bytes=0)
+        dt_s, cpu_s1, counts_s, out_bytes_s = run(gzip_level, "single")
+        in_bytes_s = sum(os.path.getsize(p) for p in paths.values()) * n_chunks
+        paths = bgzf_paths
+
+        def sub(dt_x, cpu_x, counts_x, level, what, **more):
+            d = {"value": n / dt_x, "unit": "read-pairs/s", "seconds": dt_x, "gzip_level": level,
+                 "cpu_seconds_per_M_pairs": cpu_x / (n / 1e6), "core_utilisation": cpu_x / (dt_x * max(host_cores(), 1)),
+                 "counts_equal": counts_x == counts, "what": what}
+            d.update(more)
+            return d
         huff = {"value": n / dt_h, "unit": "read-pairs/s", "seconds": dt_h, "gzip_level": -1, "output_gz_bytes": out_bytes_h,
                 "cpu_seconds_per_M_pairs": cpu_h / (n / 1e6), "core_utilisation": cpu_h / (dt_h * max(host_cores(), 1)),
                 "counts_equal": counts_h == counts,
                 "what": "same input, [gpu] gzip_level : -1 (Huffman coding only; on real fastq ~25 % larger files than level 1)"}
-        return {"value": n / dt, "huffman_only": huff, "unit": "read-pairs/s", "pairs": n, "chunks": n_chunks, "seconds": dt, "gzip_level": gzip_level,
+        single = sub(dt_s, cpu_s1, counts_s, gzip_level,
+                     "same records, every input file ONE gzip member (the reference's input format), inflated by the "
+                     "parallel gunzip (speculative chunks over a marker window, proven by the chain)",
+                     input_gz_bytes=in_bytes_s, output_gz_bytes=out_bytes_s, vs_bgzf_input=(n / dt_s) / (n / dt))
+        lvl6 = sub(dt_6, cpu_6, counts_6, 6, "same BGZF input, [gpu] gzip_level : 6 (the driver's default output level)",
+                   output_gz_bytes=out_bytes_6)
+        return {"value": n / dt, "huffman_only": huff, "single_member_gzip": single, "default_level": lvl6, "unit": "read-pairs/s", "pairs": n, "chunks": n_chunks, "seconds": dt, "gzip_level": gzip_level,
                 "samples": len(bcs), "gzip_backend": io_backend(), "io_threads": io_threads(), "host_cores": host_cores(),
                 "input_gz_bytes": in_bytes, "output_gz_bytes": out_bytes, "counts_total_pass_fail_undetermined": counts,
                 "dataset_seconds": t_gen,
@@ -222,6 +246,22 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
                         "report through quade_amd.quade (CLI driver), one process, one GPU" % len(bcs)}
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def mapped_libraries(word):
+    """Distinct shared objects of this process whose file name contains `word` (from /proc/self/maps): with torch's
+    `nccl` process group AND the library's own dlopen("librccl.so.1") in one process, two different copies would
+    show here as two paths."""
+    seen = []
+    try:
+        with open("/proc/self/maps") as fh:
+            for ln in fh:
+                path = ln.rstrip("\n").split(None, 5)[-1] if ln.count("/") else ""
+                if word in os.path.basename(path) and path not in seen:
+                    seen.append(path)
+    except OSError:
+        pass
+    return seen
 
 
 def spawn_ranks(n):
@@ -468,17 +508,24 @@ def main():
         if dist:
             assert int(total_counts[0]) == n * args.steps * world
 
+    librccl_paths = mapped_libraries("rccl") if dist else []
     algo_bytes = synth.ALGO_BYTES[args.config]
     achieved = n * algo_bytes / (kern_ms_mean * 1e-3) / 1e9
     # HBM bytes per launch from the PMC counters: a separate rocprofv3 --pmc run of this same command
     # (tools/gpu_prof_cfg.sh), committed under profiles/ -- replayed here, not observed in this run
-    traffic, traffic_source = None, None
+    traffic, traffic_source, traffic_commit = None, None, None
     tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
     if os.path.exists(tfile):
         with open(tfile) as fh:
             tj = json.load(fh)
         if tj.get("n_pairs") == n:
             traffic = tj.get("hbm_bytes_per_launch")
+            traffic_commit = tj.get("commit")  # the kernel sources the PMC passes were taken at (tools/stamp_traffic.py)
+            if tj.get("kernel_source_sha16"):
+                import hashlib
+                with open(os.path.join(ROOT, "quade_amd", "csrc", "quade_kernels.hip"), "rb") as kf:
+                    same = hashlib.sha256(kf.read()).hexdigest()[:16] == tj["kernel_source_sha16"]
+                traffic_source += "; kernel source %s since" % ("unchanged" if same else "CHANGED")
             traffic_source = "profiles/%s (earlier rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \
                              "replayed, not measured in this run)" % tj.get("source", os.path.basename(tfile))
 
@@ -488,7 +535,8 @@ def main():
         "unit": "read-pairs/s",
         "n_gpus": world,
         "steps": args.steps,
-        "warmup": args.warmup,
+        "warmup": untimed,              # untimed launches that ran before the timed region
+        "warmup_requested": args.warmup,  # --warmup W, topped up until the launch time settles (>= 50)
         "untimed_launches": untimed,  # W topped up until the launch time settles (>= 50; outside the timed region)
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
@@ -505,12 +553,17 @@ def main():
         },
         "verified": verified,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "traffic_source": traffic_source,
+                     "frac": achieved / HBM_PEAK_GBPS,
+                     # the conservative reading: the same bytes over the whole step (launch gaps, sync and the count
+                     # reduce included); `frac` (HIP events around the K launches on their stream) is the headline
+                     "frac_by_step": n * algo_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS,
+                     "traffic": traffic, "traffic_source": traffic_source, "traffic_age_commit": traffic_commit,
                      "kernel_ms": kern_ms_mean, "algorithmic_bytes_per_pair": algo_bytes},
         "world": comm_world,  # as the communicator reports it (1 = no process group)
         "count_reduce": {"backend": ("rccl via qd_reduce_counts" if comm is not None else backend) if dist else None,
                          "note": comm_note,
+                         # every librccl mapped into rank 0 (torch's group and / or the library's communicator)
+                         "librccl": librccl_paths,
                          "ms_max_over_ranks": max(r["allreduce_ms"] for r in per_rank) if dist else 0.0},
         "ranks": per_rank,
         "launched_by": "self-spawn" if os.environ.get("QUADE_BENCH_SPAWNED") else

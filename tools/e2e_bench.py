@@ -3,7 +3,7 @@
 the CLI driver.  Host bound (gunzip, scan, format, gzip); printed as one JSON line.
 usage: python tools/e2e_bench.py [pairs] [gzip level] [chunks] [--single-member | --members] [--ranks N]
 input files: BGZF (bgzip layout) by default, --members = 8 MB gzip members, --single-member = one gzip member
-env: E2E_DEVICE_INFLATE (0; 1 = BGZF inflate on the GPU), E2E_WORKERS (chunk_workers), E2E_IO_THREADS, E2E_SAMPLES (96), E2E_BATCH (500000), QUADE_PROFILE=1 (stage timers)"""
+env: E2E_PARALLEL_GUNZIP (1; 0 = ordinary gzip files on one thread each), E2E_GUNZIP_CHUNK, E2E_GUNZIP_IN_FLIGHT, E2E_DEVICE_INFLATE (0; 1 = BGZF inflate on the GPU), E2E_WORKERS (chunk_workers), E2E_IO_THREADS, E2E_SAMPLES (96), E2E_BATCH (500000), QUADE_PROFILE=1 (stage timers)"""
 import json
 import os
 import shutil
@@ -28,6 +28,10 @@ io_thr = int(os.environ.get("E2E_IO_THREADS", "0"))
 n_samples = int(os.environ.get("E2E_SAMPLES", "96"))
 batch = int(os.environ.get("E2E_BATCH", "500000"))
 work = tempfile.mkdtemp(prefix="quade_e2e_")
+from quade_amd import hip_backend as _hb  # noqa: E402
+for _name, _env in (("parallel_gunzip", "E2E_PARALLEL_GUNZIP"), ("gunzip_chunk_bytes", "E2E_GUNZIP_CHUNK"), ("gunzip_in_flight", "E2E_GUNZIP_IN_FLIGHT")):
+    if os.environ.get(_env):  # ordinary gzip inputs: the parallel inflater on / off, its chunk size, chunks in flight per file
+        assert _hb.load_library().qd_io_set_option(_name.encode(), int(os.environ[_env])) == 0
 try:
     t0 = time.perf_counter()
     paths, bcs = synth.write_fastq_dataset(work, n, n_samples=n_samples, member_bytes=fmt)
@@ -65,7 +69,7 @@ try:
     from quade_amd.fastq_writer import host_cores, io_backend, io_threads
     print(json.dumps({"mode": "end-to-end fastq.gz -> fastq.gz", "chunks": n_chunks, "pairs": n * n_chunks, "seconds": dt,
                       "pairs_per_s": n * n_chunks / dt, "gzip_level": level, "counts": counts, "chunk_workers": workers,
-                      "ranks": ranks, "device_inflate": dev_inflate, "samples": n_samples, "batch_pairs": batch, "input": {0: "single gzip member", "bgzf": "BGZF"}.get(fmt, "8 MB gzip members"), "gzip_backend": io_backend(),
+                      "ranks": ranks, "device_inflate": dev_inflate, "parallel_gunzip": os.environ.get("E2E_PARALLEL_GUNZIP", "1") != "0", "samples": n_samples, "batch_pairs": batch, "input": {0: "single gzip member", "bgzf": "BGZF"}.get(fmt, "8 MB gzip members"), "gzip_backend": io_backend(),
                       "io_threads": io_threads(), "host_cores": host_cores(), "host_logical_cpus": os.cpu_count(), "dataset_seconds": round(t_gen, 1),
                       "cpu_seconds": cpu_s, "cpu_user_sys": [round(cpu_user, 2), round(cpu_sys, 2)] if cpu_s else None, "cpu_seconds_per_M_pairs": cpu_s / (n * n_chunks / 1e6) if cpu_s else None,
                       "core_utilisation": cpu_s / (dt * host_cores()) if cpu_s else None}))

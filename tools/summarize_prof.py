@@ -98,5 +98,10 @@ with open(os.path.join(dst, "%s_%s_pmc_summary.json" % (tag, cfg)), "w") as fh:
     json.dump(out, fh, indent=1)
 if out.get("hbm_bytes_per_launch"):
     with open(os.path.join(dst, "traffic_%s.json" % cfg), "w") as fh:
-        json.dump({"n_pairs": pairs, "hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "source": "%s_%s_pmc_summary.json" % (tag, cfg)}, fh)
+        import hashlib
+        with open(os.path.join(root, "quade_amd", "csrc", "quade_kernels.hip"), "rb") as kf:
+            ksha = hashlib.sha256(kf.read()).hexdigest()[:16]
+        # "commit" is stamped afterwards in the repository (tools/stamp_traffic.py): the GPU box has no .git
+        json.dump({"n_pairs": pairs, "hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "source": "%s_%s_pmc_summary.json" % (tag, cfg),
+                   "kernel_source_sha16": ksha, "commit": None}, fh)
 print("wrote profiles/%s_%s_*" % (tag, cfg))
