@@ -356,7 +356,9 @@ def main():
     n = args.pairs or per_gpu_default[args.config]
 
     t_gen = time.perf_counter()
-    w = synth.generate(args.config, n, seed=20260000 + int(args.config[3:]) + 1000 * rank, device="cuda")
+    # every rank its own reads, all ranks ONE sample sheet (the count reduce sums per-sample counters)
+    w = synth.generate(args.config, n, seed=20260000 + int(args.config[3:]) + 1000 * rank, device="cuda",
+                       barcode_seed=20260000 + int(args.config[3:]))
     torch.cuda.synchronize()
     log("[rank %d] generated %d pairs of %s on the GPU in %.1f s" % (rank, n, args.config, time.perf_counter() - t_gen))
 

@@ -6,6 +6,8 @@
 #include <map>
 
 #define QD_CODE_UNDET 0xFFFFu
+#define QD_WQ_SET_WORDS (16 * 32) /* one counter set of the work queue: 16 x 128 bytes (9 used)                  */
+#define QD_WQ_SETS 64             /* ring of sets: one per launch in flight                                     */
 #define QD_MAX_KEY_BYTES 32
 
 #ifndef QD_FAST_BLOCK
@@ -43,6 +45,15 @@
 #endif
 #ifndef QD_FAST_CODE_STRIPS
 #define QD_FAST_CODE_STRIPS 1 /* with runs: codes leave through the wave's LDS strip, 16 B per lane          */
+#endif
+#ifndef QD_WORK_QUEUE
+#define QD_WORK_QUEUE 1 /* the persistent launch form deals wave runs out at run time (see demux_fast)        */
+#endif
+#ifndef QD_WQ_MAXTAKE
+#define QD_WQ_MAXTAKE 8 /* work queue: most runs a wave takes with one atomic (fewer at the end of the batch)       */
+#endif
+#ifndef QD_MOL_RUN_STRIPS
+#define QD_MOL_RUN_STRIPS 1 /* with runs: the molecular bytes of a whole run leave in one burst (else: per step)   */
 #endif
 #ifndef QD_FAST_GRID_FILLS
 #define QD_FAST_GRID_FILLS 1 /* automatic grid = a whole number of device fills                     */
@@ -93,6 +104,7 @@ struct DemuxParams {
     uint32_t slot_mask, seed, n_samples, cnt_stride, partial_rows;
     uint32_t lds_bk_off, lds_hist_off;
     uint32_t mol_strip_off;  // LDS offset of the per-wave molecular staging strips, 0 = not used
+    uint32_t mol_run_strips; // 1: the molecular strips hold a whole wave run (R x 128 x M bytes per wave), flushed by its last step; set by the launcher
     uint32_t code_strip_off; // LDS offset of the per-wave code strips (wave runs), 0 = one dword store per step; set by the launcher
     uint32_t thr;  // minimal_qual + 33, compared with raw quality bytes
     int32_t n_streams, K, M;
@@ -111,6 +123,11 @@ struct DemuxParams {
     const uint32_t* gslots;
     uint32_t gmask, gseed;
     // exception pairs (reads shorter than their window) redone by demux_fixup after a fast launch
+    uint32_t* wq;  // work queue of the persistent launch form: 8 run counters + 1 exit counter, 128 bytes apart, zero at launch (the
+                   // last workgroup to leave zeroes them again); NULL = static split
+#ifdef QD_DEBUG_TIMES  // measurement builds only (tools/wg_times.py): per workgroup {start, end, hardware id}
+    uint64_t* dbg;
+#endif
     const uint32_t* exc;
     const uint8_t* exc_len[2];  // lengths of the exception pairs' reads, compact (NULL: taken from len[k][pair])
     uint32_t n_exc;

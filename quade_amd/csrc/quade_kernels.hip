@@ -367,10 +367,16 @@ __device__ __forceinline__ void store_unit(const DemuxParams& p, int64_t p0, boo
 // 16-byte pieces, lane i <-> consecutive 16 B: full-line, coalesced, write-through stores instead of
 // 8-byte pieces 2M bytes apart.  No workgroup barrier: a wave's LDS operations execute in order and
 // no other wave touches its strip.
-__device__ __forceinline__ void store_mol_wave(const DemuxParams& p, uint8_t* strip, int64_t p0, u64 m0lo, u64 m0hi,
-                                               u64 m1lo, u64 m1hi) {
+// With wave runs and a run-sized strip (p.mol_run_strips, R x 128 x M bytes per wave) the R steps of a run collect
+// their bytes in the strip and the last step writes all R x 128 x M contiguous bytes out at once: one burst of
+// stores per wave and run (beside the codes' one) instead of one per step.
+template <int R>
+__device__ __forceinline__ void store_mol_wave(const DemuxParams& p, uint8_t* strips, const CodeOut& co, int64_t p0, u64 m0lo,
+                                               u64 m0hi, u64 m1lo, u64 m1hi) {
     const int M = p.M;
     const uint32_t lane = threadIdx.x & 63u;
+    const bool run = R >= 4 && p.mol_run_strips && co.strip;  // (a run-sized strip exists only where the codes have theirs)
+    uint8_t* strip = strips + (threadIdx.x >> 6) * (run ? R * 128 * M : 128 * M) + (run ? co.step * 128 * M : 0);
     uint32_t* mine = reinterpret_cast<uint32_t*>(strip + lane * 2 * M);
     const uint32_t w0[4] = {(uint32_t)m0lo, (uint32_t)(m0lo >> 32), (uint32_t)m0hi, (uint32_t)(m0hi >> 32)};
     const uint32_t w1[4] = {(uint32_t)m1lo, (uint32_t)(m1lo >> 32), (uint32_t)m1hi, (uint32_t)(m1hi >> 32)};
@@ -381,12 +387,34 @@ __device__ __forceinline__ void store_mol_wave(const DemuxParams& p, uint8_t* st
             mine[j] = w0[j];
             mine[nd + j] = w1[j];
         }
+    typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+    if (run) {
+        if (!co.last) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint8_t* first = strip - co.step * 128 * M;                                   // the run's strip
+        uint8_t* dst = p.mol + (p0 - 2 * (int64_t)lane - (int64_t)co.step * 128) * M;       // the run's first pair
+        const int pieces = R * 8 * M;  // R x 64 lanes x 2M bytes / 16
+#pragma unroll
+        for (int r = 0; r < 2 * R; ++r) {
+            const int piece = r * 64 + (int)lane;
+            if (piece < pieces) {
+                const v4u32 v = *reinterpret_cast<const v4u32*>(first + 16 * piece);
+#if QD_FAST_WT_STORES
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + 16 * piece), "v"(v) : "memory");  // pad: 5.7
+#else
+                *reinterpret_cast<v4u32*>(dst + 16 * piece) = v;
+#endif
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the strip is reused by the wave's next run
+        return;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // the wave's first pair is p0 - 2*lane; its strip starts 16-byte aligned in `mol`
     uint8_t* dst = p.mol + (p0 - 2 * (int64_t)lane) * M;
     const int pieces = 8 * M;  // 64 lanes x 2M bytes / 16
-    typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int piece = r * 64 + (int)lane;
@@ -590,7 +618,7 @@ struct Rows8 {
             undet += (c0 == QD_CODE_UNDET) + (two && c1 == QD_CODE_UNDET);
             if (FULL && p.mol_strip_off) {
                 store_codes_full<RUNS>(p, co, p0, c0 | (c1 << 16));
-                store_mol_wave(p, t.strips + (tid >> 6) * (128 * p.M), p0, m0lo, m0hi, m1lo, m1hi);
+                store_mol_wave<RUNS>(p, t.strips, co, p0, m0lo, m0hi, m1lo, m1hi);
             } else if (FULL && p.M == 0) {
                 store_codes_full<RUNS>(p, co, p0, c0 | (c1 << 16));
             } else {
@@ -686,7 +714,7 @@ struct RowsX {
             undet += (c[0] == QD_CODE_UNDET) + (two && c[1] == QD_CODE_UNDET);
             if (FULL && p.mol_strip_off) {
                 store_codes_full<RUNS>(p, co, p0, c[0] | (c[1] << 16));
-                store_mol_wave(p, t.strips + (tid >> 6) * (128 * p.M), p0, m0lo, m0hi, m1lo, m1hi);
+                store_mol_wave<RUNS>(p, t.strips, co, p0, m0lo, m0hi, m1lo, m1hi);
             } else if (FULL && p.M == 0) {
                 store_codes_full<RUNS>(p, co, p0, c[0] | (c[1] << 16));
             } else {
@@ -809,7 +837,7 @@ struct RowsW {
         const uint32_t undet = (c[0] == QD_CODE_UNDET) + (two && c[1] == QD_CODE_UNDET);
         if (FULL && p.mol_strip_off) {
             store_codes_full<RUNS>(p, co, p0, c[0] | (c[1] << 16));
-            store_mol_wave(p, t.strips + (tid >> 6) * (128 * p.M), p0, m0lo, m0hi, m1lo, m1hi);
+            store_mol_wave<RUNS>(p, t.strips, co, p0, m0lo, m0hi, m1lo, m1hi);
         } else if (FULL && p.M == 0) {
             store_codes_full<RUNS>(p, co, p0, c[0] | (c[1] << 16));
         } else {
@@ -824,9 +852,14 @@ struct RowsW {
 #else
 #define QD_FAST_BOUNDS __launch_bounds__(OPS::BLOCK)
 #endif
-template <class OPS>
+// QUEUED: the persistent form whose waves draw their runs from the work queue (its own instantiation: both loops in
+// one kernel cost the static one 17 VGPRs and an occupancy step)
+template <class OPS, bool QUEUED>
 __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
     DemuxParams p = p_in;
+#ifdef QD_DEBUG_TIMES
+    const uint64_t dbg_t0 = wall_clock64();
+#endif
     OPS::Shape::apply(p);  // a static shape overwrites the layout fields with its constants
     constexpr int BLOCK = OPS::BLOCK;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -877,7 +910,8 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
     const CodeOut direct{nullptr, 0, false};
     int64_t it = 0;
     TileT A, B;
-    if (live(0)) OPS::template load<true>(A, p, base_of(0), tid);
+    constexpr bool queued = QD_WORK_QUEUE && QUEUED && RUNS > 0;
+    if (!queued && live(0)) OPS::template load<true>(A, p, base_of(0), tid);
 
     // stage the table: global (L2) -> LDS, once per workgroup
     for (uint32_t i = tid; i <= p.slot_mask; i += BLOCK) slots[i] = p.slots[i];
@@ -887,6 +921,119 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
     const LdsTable t{slots, bk, hist, lds_raw + p.mol_strip_off};
 
     uint32_t undet = 0;
+#if QD_WORK_QUEUE
+    // ---- persistent grid, runs dealt out at run time (p.wq != nullptr; dual-index forms) ------------------------
+    // Measured on cfg3 with a truly persistent grid (tools/wg_times.py, profiles/r03_wg_times_*.txt): of the two
+    // workgroups that share a CU the OLDER one wins the arbitration -- it ends after 460 us, the younger after 640 --
+    // so with a static split the CU runs half empty for the last 28 %; an oversubscribed grid hides that behind
+    // workgroup turnover (7 % of the slot time idle, and a table image restaged per workgroup, which a large image
+    // cannot afford).  Here every WAVE draws its next wave runs (512 consecutive pairs each) from counters in
+    // global memory: one counter per XCD-sized shard (blockIdx & 7), blocks of 8 runs interleaved over the shards
+    // so that the chip still sweeps the arrays as one window; a wave takes up to 8 runs per atomic while plenty
+    // are left and single runs at the end (guided self-scheduling), asks for its next granule while it works on the
+    // last run of the current one, and helps the other shards out when its own is empty.  Whatever the arbitration
+    // does, every wave is busy until the batch is.
+    if constexpr (QUEUED && RUNS > 0) {
+        constexpr int R = RUNS > 0 ? RUNS : 1;
+        constexpr int64_t RUN_PAIRS = 128 * R;
+        const int64_t nrun = (OPS::GUARD_LAST ? (p.n >= 8 ? p.n - 8 : 0) : p.n) / RUN_PAIRS;  // full runs, dealt out below
+        const int64_t nblk = (nrun + 7) >> 3;                                                // blocks of 8 runs
+        const uint32_t lane = tid & 63u;
+        const int64_t wave_off = (int64_t)(tid >> 6) * 128;  // base + 2 * tid = run * 512 + step * 128 + 2 * lane
+        const uint32_t waves_per_shard = (gridDim.x * (BLOCK / 64) + 7) >> 3;
+        uint32_t shard = blockIdx.x & 7u, tried = 0;
+        auto shard_runs = [&](uint32_t x) -> uint32_t { return (uint32_t)(((nblk > x ? (nblk - 1 - x) / 8 + 1 : 0)) << 3); };
+        auto take_size = [&](uint32_t seen, uint32_t total) -> uint32_t {  // runs to ask for, given how far the shard was
+            const uint32_t left = total > seen ? total - seen : 0, k = left / (4 * waves_per_shard);
+            return k < 1 ? 1u : (k > QD_WQ_MAXTAKE ? (uint32_t)QD_WQ_MAXTAKE : k);
+        };
+        auto ask = [&](uint32_t x, uint32_t k) -> uint32_t {  // this wave's ticket: lane 0 adds, everybody learns
+            uint32_t v = 0;
+            if (lane == 0) v = atomicAdd(p.wq + x * 32, k);
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        };
+        uint32_t pend_k = take_size(0, shard_runs(shard)), pend_v = ask(shard, pend_k);  // in flight while the table is staged
+        uint32_t cur = 0, cur_end = 0;  // shard-local runs [cur, cur_end) in hand
+        // next run of this wave -> its global index, or -1 when every shard is empty
+        auto next_run = [&]() -> int64_t {
+            for (;;) {
+                if (cur < cur_end) {
+                    const uint32_t r = cur++;
+                    if (cur == cur_end) {  // the last run of the granule: ask for the next one now
+                        pend_k = take_size(cur_end, shard_runs(shard));
+                        pend_v = ask(shard, pend_k);
+                    }
+                    const int64_t g = ((int64_t)(r >> 3) * 8 + shard) * 8 + (r & 7);
+                    if (g < nrun) return g;
+                    continue;  // (only inside the batch's last block of 8)
+                }
+                const uint32_t total = shard_runs(shard);
+                if (pend_v < total) {
+                    cur = pend_v;
+                    cur_end = pend_v + pend_k < total ? pend_v + pend_k : total;
+                    if (cur_end - cur > 1) continue;  // (a single run asks for its successor above)
+                    continue;
+                }
+                if (++tried >= 8) return -1;  // this shard is empty: help the next one
+                shard = (shard + 1) & 7u;
+                pend_k = 1;  // a guest takes single runs: the shard is about as far as the one that just ran dry
+                pend_v = ask(shard, pend_k);
+            }
+        };
+        struct Pos {
+            int64_t base;
+            int step;
+        };
+        int64_t run = next_run();
+        auto pos_of = [&](int64_t g, int step) -> Pos { return Pos{g * RUN_PAIRS + (int64_t)step * 128 - wave_off, step}; };
+        auto advance = [&](Pos& ps) -> bool {  // the position after ps; false: nothing left
+            if (ps.step + 1 < R) {
+                ps = Pos{ps.base + 128, ps.step + 1};
+                return true;
+            }
+            run = next_run();
+            if (run < 0) return false;
+            ps = pos_of(run, 0);
+            return true;
+        };
+        auto out_at = [&](const Pos& ps) -> CodeOut { return CodeOut{code_strip, ps.step, ps.step == R - 1}; };
+        if (run >= 0) {
+            Pos pa = pos_of(run, 0), pb;
+            OPS::template load<true>(A, p, pa.base, tid);
+            if (OPS::PREFETCH) {
+                for (;;) {
+                    pb = pa;
+                    if (!advance(pb)) {
+                        undet += OPS::template compute<true, 6>(A, p, t, pa.base, tid, out_at(pa));
+                        break;
+                    }
+                    OPS::template load<true>(B, p, pb.base, tid);
+                    undet += OPS::template compute<true, 7>(A, p, t, pa.base, tid, out_at(pa));
+                    pa = pb;
+                    if (!advance(pa)) {
+                        undet += OPS::template compute<true, 8>(B, p, t, pb.base, tid, out_at(pb));
+                        break;
+                    }
+                    OPS::template load<true>(A, p, pa.base, tid);
+                    undet += OPS::template compute<true, 9>(B, p, t, pb.base, tid, out_at(pb));
+                }
+            } else {
+                for (;;) {
+                    undet += OPS::template compute<true, 10>(A, p, t, pa.base, tid, out_at(pa));
+                    if (!advance(pa)) break;
+                    OPS::template load<true>(A, p, pa.base, tid);
+                }
+            }
+        }
+        // what no run covers: the last < 512 (+ 8) pairs of the batch, lane-guarded, by workgroup 0
+        if (blockIdx.x == 0)
+            for (int64_t base = nrun * RUN_PAIRS; base < p.n; base += TILE) {
+                OPS::template load<false>(A, p, base, tid);
+                undet += OPS::template compute<false, 11>(A, p, t, base, tid, direct);
+            }
+    } else
+#endif
+    {
     // Register double buffering (tile k+1 in flight while tile k is matched) when a tile is 64 B per
     // lane; wider tiles run single-buffered.  Every "load next, then match current" pair is
     // straight-line code with its own copy of the match (no control-flow join between issuing the
@@ -919,9 +1066,10 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
             }
         }
     }
+    }
     // what is left: the lane-guarded tiles at the end of the batch (at most two) and, with runs, the full
     // tiles behind the last whole super-tile
-    for (int64_t last = RUNS ? nunits * RUNS : nfull; last < ntiles; ++last) {
+    for (int64_t last = queued ? ntiles : (RUNS ? nunits * RUNS : nfull); last < ntiles; ++last) {
         if ((int64_t)blockIdx.x != last % G) continue;
         OPS::template load<false>(A, p, last * TILE, tid);
         undet += OPS::template compute<false, 5>(A, p, t, last * TILE, tid, direct);
@@ -941,6 +1089,27 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
     for (uint32_t i = tid; i < 2 * S + 1; i += BLOCK) {
         const uint32_t v = hist[i];
         if (v) atomicAdd(&row[i], (qd_row_t)v);
+    }
+#endif
+#if QD_WORK_QUEUE
+    // the workgroup that leaves last puts the queue's counters back to zero for the launch that uses this set next
+    // (no wave of this launch asks again: every workgroup passed its last barrier above before it ticks `done`)
+    if (QUEUED && RUNS > 0 && tid == 0) {
+        __threadfence();
+        if (atomicAdd(p.wq + 8 * 32, 1u) == gridDim.x - 1) {
+#pragma unroll
+            for (int x = 0; x < 9; ++x) __hip_atomic_store(p.wq + x * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#endif
+#ifdef QD_DEBUG_TIMES
+    if (p.dbg && tid == 0 && blockIdx.x < 65536) {
+        uint32_t hw = 0, xcc = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p.dbg[3 * blockIdx.x] = dbg_t0;
+        p.dbg[3 * blockIdx.x + 1] = wall_clock64();
+        p.dbg[3 * blockIdx.x + 2] = (uint64_t)hw | ((uint64_t)xcc << 32);
     }
 #endif
 }
@@ -1179,14 +1348,26 @@ __global__ void reduce_partials(const qd_row_t* partial, uint32_t rows, uint32_t
 // lds = dynamic LDS of the launch (table image + histogram + molecular strips); table_lds = the part
 // every workgroup has to stage and flush (decides the grid form)
 template <class OPS>
-hipError_t launch_fast_t(const DemuxParams& p_launch, QdKernelCache& cache, int cus, int wg_per_cu, size_t lds, size_t table_lds,
+hipError_t launch_fast_t(const DemuxParams& p_launch, QdKernelCache& cache, int cus, int wg_per_cu, size_t table_lds, size_t strip_bytes_per_wave,
                          hipStream_t st) {
     constexpr int BLOCK = OPS::BLOCK;
-    auto k = demux_fast<OPS>;
+    const bool queued = QD_WORK_QUEUE && OPS::RUNS > 0 && p_launch.wq;
+    auto k = queued ? demux_fast<OPS, (QD_WORK_QUEUE && OPS::RUNS > 0)> : demux_fast<OPS, false>;
+    // dynamic LDS: table image + histogram | molecular strips (per wave: one step's 128 x M bytes, or a whole run's
+    // with QD_MOL_RUN_STRIPS while two workgroups of this size still fit a CU) | code strips
+    size_t lds = table_lds;
+    bool mol_runs = false;
+    if (p_launch.mol_strip_off && strip_bytes_per_wave) {
+        const size_t per_step = strip_bytes_per_wave * (BLOCK / 64), per_run = per_step * (size_t)(OPS::RUNS > 0 ? OPS::RUNS : 1);
+        mol_runs = OPS::RUNS >= 4 && QD_MOL_RUN_STRIPS && QD_FAST_CODE_STRIPS &&
+                   2 * (table_lds + per_run + (size_t)OPS::RUNS * 256 * (BLOCK / 64)) <= 156 * 1024;
+        lds += mol_runs ? per_run : per_step;
+    }
     // the attribute and the occupancy answer belong to (device, instantiation): kept in the context
     // code strips (wave runs): R x 256 B per wave behind the table image and the molecular strips, while the
     // table image is small (a large one leaves no room without giving up a co-resident workgroup)
     DemuxParams p = p_launch;
+    p.mol_run_strips = mol_runs ? 1 : 0;
     if (OPS::RUNS >= 4 && QD_FAST_CODE_STRIPS &&
         (table_lds <= 24 * 1024 || 2 * (lds + (size_t)OPS::RUNS * 256 * (BLOCK / 64)) <= QD_STRIPS_LDS_BUDGET)) {
         p.code_strip_off = (uint32_t)lds;
@@ -1217,8 +1398,11 @@ hipError_t launch_fast_t(const DemuxParams& p_launch, QdKernelCache& cache, int 
     //  * large table image: a persistent grid of at most 2 co-resident workgroups per CU (staging
     //    tens of KB and flushing thousands of counters per workgroup is not free).
     int64_t grid;
+    if (!queued) p.wq = nullptr;
     if (wg_per_cu > 0) {
         grid = (int64_t)cus * wg_per_cu;
+    } else if (queued) {
+        grid = (int64_t)cus * occ_blocks;  // the resident set: every wave draws its runs from the queue
     } else if (table_lds > 24 * 1024) {
         grid = (int64_t)cus * (occ_blocks < 2 ? occ_blocks : 2);
     } else {
@@ -1241,22 +1425,23 @@ hipError_t launch_fast_t(const DemuxParams& p_launch, QdKernelCache& cache, int 
     }
     if (grid > ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
+
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(BLOCK), lds, st, p);
     return hipGetLastError();
 }
 
 template <int BLOCK>
-hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, int wg_per_cu, size_t lds_bytes,
-                         size_t table_lds, hipStream_t st) {
+hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, int wg_per_cu, size_t table_lds,
+                         size_t lds_bytes /* = strip bytes per wave, handed on */, hipStream_t st) {
     constexpr int U = QD_FAST_UNITS;
     const bool dual = p.n_streams > 1;
     if (p.wide) {  // K > 16 with slices <= 16 bytes means two index reads
         if (!dual) return hipErrorInvalidValue;
 #ifndef QD_NO_STATIC_SHAPES
         if (StaticWide<10>::matches(p))  // dual 10 bp indexes
-            return launch_fast_t<RowsW<BLOCK, true, StaticWide<10>>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
+            return launch_fast_t<RowsW<BLOCK, true, StaticWide<10>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
 #endif
-        return launch_fast_t<RowsW<BLOCK, true>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
+        return launch_fast_t<RowsW<BLOCK, true>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
     }
     const bool all8 = p.seq_stride[0] == 8 && p.qual_stride[0] == 8 &&
                       (!dual || (p.seq_stride[1] == 8 && p.qual_stride[1] == 8));
@@ -1266,27 +1451,27 @@ hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, in
         // launch form (cfg5), -1.4 % for the small-table one (cfg3) -> used where it pays
         // (profiles/r02_static_vs_dynamic_shape_cfg{3,5}.txt)
         if (StaticShape<8, 0>::matches(p) && (table_lds > 24 * 1024 || QD_STATIC80_ALWAYS))
-            return launch_fast_t<Rows8<BLOCK, true, U, StaticShape<8, 0>>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
+            return launch_fast_t<Rows8<BLOCK, true, U, StaticShape<8, 0>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
 #endif
-        if (dual) return launch_fast_t<Rows8<BLOCK, true, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
+        if (dual) return launch_fast_t<Rows8<BLOCK, true, U>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
 #ifndef QD_SWEEP_BUILD  // tuning builds instantiate the dual 8+8 kernel only
-        return launch_fast_t<Rows8<BLOCK, false, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
+        return launch_fast_t<Rows8<BLOCK, false, U>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
 #endif
     }
 #ifndef QD_SWEEP_BUILD
     const int nl1 = p.seq_stride[0] > 8 ? 2 : 1, nl2 = p.seq_stride[1] > 8 ? 2 : 1;
     if (!dual) {
-        if (nl1 == 1) return launch_fast_t<RowsX<BLOCK, 1, 1, false, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
-        return launch_fast_t<RowsX<BLOCK, 2, 1, false, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
+        if (nl1 == 1) return launch_fast_t<RowsX<BLOCK, 1, 1, false, U>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+        return launch_fast_t<RowsX<BLOCK, 2, 1, false, U>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
     }
 #ifndef QD_NO_STATIC_SHAPES
     if (StaticShape<8, 6>::matches(p))  // 8 bp barcode + 6 bp molecular index per index read (BASELINE cfg4)
-        return launch_fast_t<RowsX<BLOCK, 2, 2, true, U, StaticShape<8, 6>>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
+        return launch_fast_t<RowsX<BLOCK, 2, 2, true, U, StaticShape<8, 6>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
 #endif
-    if (nl1 == 1 && nl2 == 1) return launch_fast_t<RowsX<BLOCK, 1, 1, true, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
-    if (nl1 == 1 && nl2 == 2) return launch_fast_t<RowsX<BLOCK, 1, 2, true, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
-    if (nl1 == 2 && nl2 == 1) return launch_fast_t<RowsX<BLOCK, 2, 1, true, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
-    return launch_fast_t<RowsX<BLOCK, 2, 2, true, U>>(p, cache, cus, wg_per_cu, lds_bytes, table_lds, st);
+    if (nl1 == 1 && nl2 == 1) return launch_fast_t<RowsX<BLOCK, 1, 1, true, U>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+    if (nl1 == 1 && nl2 == 2) return launch_fast_t<RowsX<BLOCK, 1, 2, true, U>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+    if (nl1 == 2 && nl2 == 1) return launch_fast_t<RowsX<BLOCK, 2, 1, true, U>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+    return launch_fast_t<RowsX<BLOCK, 2, 2, true, U>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
 #else
     return hipErrorInvalidValue;
 #endif
@@ -1301,12 +1486,16 @@ hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, in
 // tile is 128 B per lane; -4 %).  block_override: 0 = this rule.
 hipError_t qd_launch_fast(const DemuxParams& p, QdKernelCache& cache, int cus, int wg_per_cu, int block_override,
                           size_t lds_bytes, size_t strip_bytes_per_wave, hipStream_t st) {
+    // (with the work queue a large image runs as two 512-thread workgroups per CU when both fit: on the 8 bp configs
+    // 1024-thread workgroups measured 12 % slower than 512-thread ones in every grid form, profiles/r03_cfg3_launch_forms.txt)
+    const bool big = lds_bytes > QD_FAST_BIG_LDS;
+    const bool two_fit = 2 * (lds_bytes + strip_bytes_per_wave * 8) <= 158 * 1024;
     int block = block_override ? block_override
-                               : (lds_bytes > QD_FAST_BIG_LDS ? 1024 : ((p.n <= QD_FAST_SMALL_BATCH || p.wide) ? 256 : QD_FAST_BLOCK));
-    const size_t lds = lds_bytes + strip_bytes_per_wave * (size_t)(block / 64);  // table | histogram | strips
-    if (block == 1024) return launch_fast_b<1024>(p, cache, cus, wg_per_cu, lds, lds_bytes, st);
-    if (block == 256) return launch_fast_b<256>(p, cache, cus, wg_per_cu, lds, lds_bytes, st);
-    return launch_fast_b<512>(p, cache, cus, wg_per_cu, lds, lds_bytes, st);
+                               : (big ? ((QD_WORK_QUEUE && p.wq && two_fit) ? 512 : 1024)
+                                      : ((p.n <= QD_FAST_SMALL_BATCH || p.wide) ? 256 : QD_FAST_BLOCK));
+    if (block == 1024) return launch_fast_b<1024>(p, cache, cus, wg_per_cu, lds_bytes, strip_bytes_per_wave, st);
+    if (block == 256) return launch_fast_b<256>(p, cache, cus, wg_per_cu, lds_bytes, strip_bytes_per_wave, st);
+    return launch_fast_b<512>(p, cache, cus, wg_per_cu, lds_bytes, strip_bytes_per_wave, st);
 }
 
 hipError_t qd_launch_generic(const DemuxParams& p, int grid, hipStream_t st) {

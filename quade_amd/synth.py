@@ -94,9 +94,11 @@ class Workload(object):
         return [bytes(r.tolist()).decode() for r in self.barcodes.cpu()]
 
 
-def generate(name, n, seed=None, device="cpu", chunk=8_000_000, layout=None):
+def generate(name, n, seed=None, device="cpu", chunk=8_000_000, layout=None, barcode_seed=None):
     """Builds `n` pairs of config `name`.  Deterministic for a given (name, n, seed, device type).
-    layout: row layout to build for (default: the library's qd_plan_layout of the config's plan)."""
+    layout: row layout to build for (default: the library's qd_plan_layout of the config's plan).
+    barcode_seed: draw the sample sheet from a generator of its own (shards of one job: different reads, one
+    sheet); default: from the read generator's seed, as always."""
     c = CONFIGS[name]
     cfg_no = int(name[3:]) if name[3:].isdigit() else 9
     seed = 20260000 + cfg_no if seed is None else seed
@@ -110,7 +112,7 @@ def generate(name, n, seed=None, device="cpu", chunk=8_000_000, layout=None):
     L = c["read_len"]
     plan = config_plan(name)
     lay = layout if layout is not None else plan_layout(plan)
-    bcs_cpu = make_barcodes(S, K, gcpu)
+    bcs_cpu = make_barcodes(S, K, gcpu if barcode_seed is None else torch.Generator(device="cpu").manual_seed(barcode_seed))
     bcs = bcs_cpu.to(dev)
     table_h = _mix(_key64(bcs))
     acgt, acgtn = ACGT.to(dev), ACGTN.to(dev)

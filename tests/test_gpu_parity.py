@@ -53,6 +53,23 @@ def test_fast_kernel_vs_oracle(torch_cuda, engine, name, n):
     _check_workload(torch_cuda, engine, synth.generate(name, n, seed=1000 + n))
 
 
+@pytest.mark.parametrize("name", ["cfg3", "cfg4", "cfg5", "wide10"])
+@pytest.mark.parametrize("n", [0, 1, 2, 511, 512, 513, 519, 520, 1023, 4097, 30001, 70003, 300007])
+def test_work_queue_form_vs_oracle(torch_cuda, engine, name, n):
+    """The persistent launch form whose waves draw their runs of 512 pairs from counters in global memory (option
+    work_queue; the default for large table images): sizes around one run, the guard of the exact-width rows (8 pairs),
+    a block of 8 runs and many blocks; launched twice in a row, so a second launch finds its counters at zero."""
+    from quade_amd import synth
+    engine.set_option("work_queue", 1)
+    w = synth.generate(name, n, seed=5000 + n)
+    _check_workload(torch_cuda, engine, w)
+    engine.reset_counts()
+    _check_workload(torch_cuda, engine, w)
+    engine.set_option("work_queue", 2)  # and the static split, whatever the image size
+    engine.reset_counts()
+    _check_workload(torch_cuda, engine, w)
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 511, 1023, 4097, 30001, 70003])
 def test_wide_fast_kernel_vs_oracle(torch_cuda, engine, n):
     """Dual 10 bp indexes (fused barcode of 20 bytes): the wide form of the fast kernel, and the generic one."""

@@ -18,6 +18,7 @@ default_n = {"cfg2": 10_000_000, "cfg3": 100_000_000, "cfg4": 62_500_000, "cfg5"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else default_n[cfg]
 blocks = [int(x) for x in os.environ.get("TUNE_BLOCKS", "0,256,512,1024").split(",")]
 wgs = [int(x) for x in os.environ.get("TUNE_WG", "0,4,16,64").split(",")]
+wqs = [int(x) for x in os.environ.get("TUNE_WQ", "0").split(",")]  # work_queue option: 0 automatic, 1 always, 2 never
 libs = [LIB_PATH] + [p for p in os.environ.get("TUNE_LIBS", "").split(",") if p]
 rounds, reps = int(os.environ.get("TUNE_ROUNDS", "3")), 4
 
@@ -43,8 +44,9 @@ with torch.cuda.stream(st):
         for lp, e in zip(libs, engines):
             for b in blocks:
                 e.set_option("fast_block", b)
-                for wg in wgs:
+                for wg, wq in [(a, b) for a in wgs for b in wqs]:
                     e.set_option("fast_workgroups_per_cu", wg)
+                    e.set_option("work_queue", wq)
                     for i in range(reps + 1):
                         a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         a.record(st)
@@ -54,10 +56,13 @@ with torch.cuda.stream(st):
                         z.record(st)
                         z.synchronize()
                         if i:
-                            res.setdefault((os.path.basename(lp), b, wg), []).append(a.elapsed_time(z))
+                            res.setdefault((os.path.basename(lp), b, wg, wq), []).append(a.elapsed_time(z))
                     assert torch.equal(codes.view(torch.int16).to(torch.int32) & 0xFFFF, w.expected) or os.environ.get("TUNE_NOCHECK")
+                    if cfg == "cfg4" and not os.environ.get("TUNE_NOCHECK"):  # molecular bytes: columns 8..13 of both index reads
+                        assert torch.equal(mol, torch.cat([w.seq[0][:, 8:14], w.seq[1][:, 8:14]], dim=1)), (lp, b, wg, wq)
+                        mol.zero_()
 B = synth.ALGO_BYTES[cfg]
 print("%s n=%d  algorithmic %d B/pair" % (cfg, n, B))
-print("%-24s %5s %4s %9s %9s %9s" % ("lib", "block", "wg", "min ms", "med ms", "GB/s(med)"))
-for (lp, b, wg), v in sorted(res.items(), key=lambda kv: np.median(kv[1])):
-    print("%-24s %5d %4d %9.4f %9.4f %9.0f" % (lp, b, wg, min(v), np.median(v), n * B / np.median(v) / 1e6))
+print("%-24s %5s %4s %3s %9s %9s %9s" % ("lib", "block", "wg", "wq", "min ms", "med ms", "GB/s(med)"))
+for (lp, b, wg, wq), v in sorted(res.items(), key=lambda kv: np.median(kv[1])):
+    print("%-24s %5d %4d %3d %9.4f %9.4f %9.0f" % (lp, b, wg, wq, min(v), np.median(v), n * B / np.median(v) / 1e6))
