@@ -161,8 +161,8 @@ int qd_kernel_kind(const qd_ctx* ctx, int has_len);
  *   "mol_strips"              1 = stage molecular bytes through LDS for 16-byte stores (default), 0 = off
  *   "force_generic"           1 = always launch the generic kernel
  *   "kernel"                  0 = automatic (default), 1 = fast (when the plan is eligible), 2 = generic
- *   "work_queue"              fast kernel, dual-index forms: a persistent grid whose waves draw their work from counters in
- *                             global memory; 0 = automatic (default), 1 = always, 2 = never (static split / oversubscribed grid)
+ *   "work_queue"              fast kernel, dual-index forms: 1 = a persistent grid whose waves draw their work from counters
+ *                             in global memory; 0 (default, automatic: currently never) and 2 = static split / oversubscribed grid
  *   "fold_pairs"              the device counts into 32-bit per-workgroup rows that are folded into 64-bit totals
  *                             before this many pairs have been launched since the last fold (default and
  *                             maximum 2^32 - 1; tests lower it) */

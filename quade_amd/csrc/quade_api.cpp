@@ -76,7 +76,7 @@ struct qd_ctx {
     int opt_block = 0;        // 0 = automatic
     int opt_mol_strips = 1;   // LDS-staged molecular stores in the fast kernel
     int opt_kernel = 0;       // 0 = automatic, K_FAST / K_GENERIC
-    int opt_work_queue = 0;   // fast kernel, dual-index forms: 0 = automatic (large table images), 1 = always, 2 = never
+    int opt_work_queue = 0;   // fast kernel, dual-index forms: 1 = waves draw their runs from a work queue; 0 (automatic) and 2 = static split
     uint32_t* d_wq = nullptr; // ring of QD_WQ_SETS counter sets of the work queue; one per launch in flight
     uint32_t wq_next = 0;
     QdKernelCache kcache;     // per-context launch memo (attribute set, occupancy)
@@ -450,7 +450,9 @@ int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* 
     p.dbg = c->d_dbg;
 #endif
     if (kind == K_FAST) {
-        if (c->opt_work_queue == 1 || (c->opt_work_queue == 0 && c->lds_bytes > 24 * 1024)) {
+        // (automatic = never: the form measured 1 % behind the static persistent grid on a large table image and 12 %
+        // behind the oversubscribed grid on small ones, profiles/r03_work_queue_*.txt; it stays selectable)
+        if (c->opt_work_queue == 1) {
             if (!c->d_wq) {  // zero once: every launch leaves its set zeroed behind it
                 HIPCHK(c, hipMalloc(&c->d_wq, (size_t)QD_WQ_SETS * QD_WQ_SET_WORDS * 4));
                 HIPCHK(c, hipMemset(c->d_wq, 0, (size_t)QD_WQ_SETS * QD_WQ_SET_WORDS * 4));

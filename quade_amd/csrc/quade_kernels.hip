@@ -498,12 +498,14 @@ __device__ __forceinline__ u64 take8(const u64 (&w)[NW], int start) {
 // spills them through VGPR lanes: a third of its vector instructions were v_readlane / v_writelane).
 struct DynShape {
     static constexpr bool STATIC = false;
+    static constexpr int MOLW = -1;  // not known at compile time
     static __device__ __forceinline__ void apply(DemuxParams&) {}
     static bool matches(const DemuxParams&) { return true; }
 };
 template <int IW, int MW>  // dual index, IW-base barcodes at columns 0..IW-1, MW-base molecular index behind them
 struct StaticShape {
     static constexpr bool STATIC = true;
+    static constexpr int MOLW = MW;
     static constexpr int STRIDE = (IW + MW + 1) & ~1, QSTRIDE = (IW + 1) & ~1;
     static __device__ __forceinline__ void apply(DemuxParams& p) {
         p.n_streams = 2;
@@ -634,9 +636,14 @@ template <int BLOCK_, int NL1, int NL2, bool DUAL, int UNITS, class SH = DynShap
 struct RowsX {
     typedef SH Shape;
     static constexpr int BLOCK = BLOCK_;
-    // register double buffering: always with a static shape (its code is lean enough that the next tile's
-    // loads in flight pay: -3 % on cfg4), for dynamic shapes only while the tile is small
-    static constexpr bool PREFETCH = QD_FAST_PREFETCH != 0 && (SH::STATIC || (NL1 + (DUAL ? NL2 : 0)) <= QD_FASTX_PREFETCH_MAXNL);
+    // register double buffering: with a static shape without molecular index (its code is lean enough that the next
+    // tile's loads in flight pay), for dynamic shapes only while the tile is small.  Static shapes WITH a molecular
+    // index run single-buffered since their bytes leave once per wave run (QD_MOL_RUN_STRIPS): measured in one
+    // process, cfg4: run strips + single buffer 0.6625 ms, run strips + double buffer 0.6749, r02's form (strip per
+    // step + double buffer) 0.6733, strip per step + single buffer 0.6796 (profiles/r03_cfg4_molrun_prefetch.txt)
+    static constexpr bool PREFETCH = QD_FAST_PREFETCH != 0 &&
+                                     (SH::STATIC ? !(QD_MOL_RUN_STRIPS && SH::MOLW > 0 && DUAL && UNITS == 1 && QD_FAST_RUNS >= 4)
+                                                 : (NL1 + (DUAL ? NL2 : 0)) <= QD_FASTX_PREFETCH_MAXNL);
     static constexpr bool GUARD_LAST = true;  // a 16-byte load of the batch's last rows could pass the array end
     static constexpr int RUNS = (DUAL && UNITS == 1) ? QD_FAST_RUNS : 0;
     struct Tile {
@@ -732,29 +739,34 @@ struct RowsX {
 // StaticWide<IW>: dual IW-base barcodes (8 < IW <= 16) at the start of both index reads, no molecular index --
 // the layout of the dual 10 bp index kits -- baked in, as StaticShape does for the 8-byte forms (the dynamic
 // code of this policy keeps ~250 scalars alive: 577 SGPR spills, a third of its instructions move lanes).
-template <int IW>
+template <int IW, int MW = 0>  // MW: a molecular index of MW bases right behind the barcode, in both index reads (IW + MW <= 16)
 struct StaticWide {
     static constexpr bool STATIC = true;
-    static constexpr int STRIDE = (IW + 1) & ~1;
+    static constexpr int MOLW = MW;
+    static constexpr int STRIDE = (IW + MW + 1) & ~1, QSTRIDE = (IW + 1) & ~1;
+    static_assert(IW > 8 && IW + MW <= 16 && MW <= 8, "wide static shapes: 8 < barcode, barcode + molecular index <= 16 bytes");
     static __device__ __forceinline__ void apply(DemuxParams& p) {
         p.n_streams = 2;
         p.K = 2 * IW;
-        p.M = 0;
+        p.M = 2 * MW;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            p.seq_stride[k] = p.qual_stride[k] = STRIDE;
+            p.seq_stride[k] = STRIDE;
+            p.qual_stride[k] = QSTRIDE;
             p.idx_off[k] = 0;
             p.idx_w[k] = IW;
-            p.mol_off[k] = p.mol_w[k] = 0;
+            p.mol_off[k] = MW ? IW : 0;
+            p.mol_w[k] = MW;
             p.idx_mask[k] = ~0ull;
             p.idx_mask_hi[k] = IW >= 16 ? ~0ull : ((1ull << (8 * (IW - 8))) - 1);
-            p.mol_mask[k] = 0;
+            p.mol_mask[k] = MW >= 8 ? ~0ull : ((1ull << (8 * MW)) - 1);
         }
     }
     static bool matches(const DemuxParams& p) {
-        if (p.n_streams != 2 || p.K != 2 * IW || p.M != 0) return false;
+        if (p.n_streams != 2 || p.K != 2 * IW || p.M != 2 * MW) return false;
         for (int k = 0; k < 2; ++k)
-            if (p.seq_stride[k] != STRIDE || p.qual_stride[k] != STRIDE || p.idx_off[k] != 0 || p.idx_w[k] != IW || p.mol_w[k] != 0)
+            if (p.seq_stride[k] != STRIDE || p.qual_stride[k] != QSTRIDE || p.idx_off[k] != 0 || p.idx_w[k] != IW ||
+                p.mol_w[k] != MW || (MW && p.mol_off[k] != IW))
                 return false;
         return true;
     }
@@ -1009,6 +1021,9 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
                     }
                     OPS::template load<true>(B, p, pb.base, tid);
                     undet += OPS::template compute<true, 7>(A, p, t, pa.base, tid, out_at(pa));
+#ifdef QD_WQ_SLEEP  // experiment: idle cycles in the persistent form
+                    __builtin_amdgcn_s_sleep(QD_WQ_SLEEP);
+#endif
                     pa = pb;
                     if (!advance(pa)) {
                         undet += OPS::template compute<true, 8>(B, p, t, pb.base, tid, out_at(pb));
@@ -1016,6 +1031,9 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
                     }
                     OPS::template load<true>(A, p, pa.base, tid);
                     undet += OPS::template compute<true, 9>(B, p, t, pb.base, tid, out_at(pb));
+#ifdef QD_WQ_SLEEP
+                    __builtin_amdgcn_s_sleep(QD_WQ_SLEEP);
+#endif
                 }
             } else {
                 for (;;) {
@@ -1440,6 +1458,10 @@ hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, in
 #ifndef QD_NO_STATIC_SHAPES
         if (StaticWide<10>::matches(p))  // dual 10 bp indexes
             return launch_fast_t<RowsW<BLOCK, true, StaticWide<10>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+        if (StaticWide<12>::matches(p))  // dual 12 bp indexes
+            return launch_fast_t<RowsW<BLOCK, true, StaticWide<12>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+        if (StaticWide<10, 6>::matches(p))  // dual 10 bp indexes, each followed by a 6-base molecular index
+            return launch_fast_t<RowsW<BLOCK, true, StaticWide<10, 6>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
 #endif
         return launch_fast_t<RowsW<BLOCK, true>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
     }
@@ -1467,6 +1489,10 @@ hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, in
 #ifndef QD_NO_STATIC_SHAPES
     if (StaticShape<8, 6>::matches(p))  // 8 bp barcode + 6 bp molecular index per index read (BASELINE cfg4)
         return launch_fast_t<RowsX<BLOCK, 2, 2, true, U, StaticShape<8, 6>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+    if (StaticShape<8, 8>::matches(p))  // 8 bp barcode + 8 bp molecular index per index read
+        return launch_fast_t<RowsX<BLOCK, 2, 2, true, U, StaticShape<8, 8>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+    if (StaticShape<6, 0>::matches(p))  // dual 6 bp indexes
+        return launch_fast_t<RowsX<BLOCK, 1, 1, true, U, StaticShape<6, 0>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
 #endif
     if (nl1 == 1 && nl2 == 1) return launch_fast_t<RowsX<BLOCK, 1, 1, true, U>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
     if (nl1 == 1 && nl2 == 2) return launch_fast_t<RowsX<BLOCK, 1, 2, true, U>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);

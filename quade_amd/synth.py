@@ -34,15 +34,23 @@ CONFIGS = {
     "cfg5": dict(dual=True, S=1536, read_len=8, mol=False, min_qual=25, pairs=1_000_000_000),
     # not a BASELINE config: dual 10 bp indexes (fused barcode of 20 bytes: the wide fast kernel), tools and tests only
     "wide10": dict(dual=True, S=96, read_len=10, mol=False, min_qual=25, pairs=100_000_000, iw=10),
+    # layouts of other common kits (tools and tests only): iw = barcode bases per index read, a molecular index of
+    # read_len - iw bases right behind it in both index reads
+    "kit6": dict(dual=True, S=96, read_len=6, mol=False, min_qual=25, pairs=100_000_000, iw=6),
+    "kit8u8": dict(dual=True, S=96, read_len=16, mol=True, min_qual=25, pairs=60_000_000, iw=8),
+    "kit12": dict(dual=True, S=96, read_len=12, mol=False, min_qual=25, pairs=60_000_000, iw=12),
+    "kit10u6": dict(dual=True, S=96, read_len=16, mol=True, min_qual=25, pairs=60_000_000, iw=10),
 }
-# algorithmic bytes per pair (SURVEY.md 8d / BASELINE.md section 3)
-ALGO_BYTES = {"cfg2": 18, "cfg3": 34, "cfg4": 58, "cfg5": 34, "wide10": 42}
+# algorithmic bytes per pair (SURVEY.md 8d / BASELINE.md section 3): barcode + molecular bases and barcode qualities
+# read, code and molecular bytes written
+ALGO_BYTES = {"cfg2": 18, "cfg3": 34, "cfg4": 58, "cfg5": 34, "wide10": 42,
+              "kit6": 26, "kit8u8": 66, "kit12": 50, "kit10u6": 66}
 
 
 def config_plan(name):
     c = CONFIGS[name]
     iw = c.get("iw", 8)
-    mol = (8, 14) if c["mol"] else (0, 0)
+    mol = (iw, c["read_len"]) if c["mol"] else (0, 0)
     return make_plan(c["dual"], c["min_qual"], (0, iw), (0, iw) if c["dual"] else (0, 0),
                      mol, mol if c["dual"] else (0, 0))
 
@@ -166,7 +174,7 @@ def generate(name, n, seed=None, device="cpu", chunk=8_000_000, layout=None, bar
             seq[k][a:a + m].zero_()
             seq[k][a:a + m, 0:iw] = key[:, iw * k:iw * k + iw]
             if c["mol"]:
-                seq[k][a:a + m, 8:L] = acgt[ri(0, 4, (m, L - 8))]
+                seq[k][a:a + m, iw:L] = acgt[ri(0, 4, (m, L - iw))]
             qual[k][a:a + m].fill_(0xFF)
             qual[k][a:a + m, 0:iw] = q[:, iw * k:iw * k + iw]
     return Workload(name, n, seq, qual, expected, bcs_cpu, plan, lay)

@@ -57,7 +57,7 @@ def test_fast_kernel_vs_oracle(torch_cuda, engine, name, n):
 @pytest.mark.parametrize("n", [0, 1, 2, 511, 512, 513, 519, 520, 1023, 4097, 30001, 70003, 300007])
 def test_work_queue_form_vs_oracle(torch_cuda, engine, name, n):
     """The persistent launch form whose waves draw their runs of 512 pairs from counters in global memory (option
-    work_queue; the default for large table images): sizes around one run, the guard of the exact-width rows (8 pairs),
+    work_queue = 1; not the default: it measured behind the static forms): sizes around one run, the guard of the exact-width rows (8 pairs),
     a block of 8 runs and many blocks; launched twice in a row, so a second launch finds its counters at zero."""
     from quade_amd import synth
     engine.set_option("work_queue", 1)
@@ -68,6 +68,17 @@ def test_work_queue_form_vs_oracle(torch_cuda, engine, name, n):
     engine.set_option("work_queue", 2)  # and the static split, whatever the image size
     engine.reset_counts()
     _check_workload(torch_cuda, engine, w)
+
+
+@pytest.mark.parametrize("name", ["kit6", "kit8u8", "kit12", "kit10u6"])
+@pytest.mark.parametrize("n", [0, 1, 2, 7, 8, 9, 511, 1023, 4097, 30001, 70003])
+def test_kit_layouts_on_their_static_shapes(torch_cuda, engine, name, n):
+    """Layouts of other common kits, each with its own static instantiation of the fast kernel: dual 6 bp (rows of 6
+    bytes: a lane's 16-byte load reaches into its neighbour's rows), dual 8 bp + 8-base molecular index (16-byte rows,
+    16 molecular bytes per pair), dual 12 bp and dual 10 bp + 6-base molecular index (the wide form: nibble-packed
+    24- / 20-byte keys, byte compare on a hit) -- codes, molecular bytes and counters against the oracle."""
+    from quade_amd import synth
+    _check_workload(torch_cuda, engine, synth.generate(name, n, seed=7000 + n))
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 511, 1023, 4097, 30001, 70003])

@@ -60,6 +60,8 @@ for frac in (0.5, 0.25, 0.1):
 ts = np.linspace(0, span, 21)
 running = [(int(((start <= x) & (end > x)).sum())) for x in ts]
 print("  workgroups running at 0 %, 5 %, ... 100 % of the span:", running)
+slots = max(running)
+print("  sum of workgroup durations / %d resident slots = %.1f us (the span if every slot were busy throughout: %.1f %% of the span)" % (slots, dur.sum() / slots, dur.sum() / slots / span * 100))
 for x in range(8):
     m = xcc == x
     if m.any():
