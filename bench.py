@@ -180,9 +180,9 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
         from quade_amd.sample import Sample
         n = n_pairs * n_chunks
 
-        def run(level, tag):
+        def run(level, tag, more=""):
             conf = os.path.join(work, "conf_%s.txt" % tag)
-            synth.write_conf(conf, paths, bcs, n_chunks, gpu="[gpu]\ngzip_level : %d\n" % level)
+            synth.write_conf(conf, paths, bcs, n_chunks, gpu="[gpu]\ngzip_level : %d\n%s" % (level, more))
             out = os.path.join(work, "out_" + tag)
             os.mkdir(out)
             cwd = os.getcwd()
@@ -204,7 +204,8 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
 
         dt, cpu_s, counts, out_bytes = run(gzip_level, "lvl")
         # the same job with gzip_level -1: output members are one dynamic-Huffman block of literals (no string matching)
-        dt_h, cpu_h, counts_h, out_bytes_h = run(-1, "huff")
+        dt_h, cpu_h, counts_h, out_bytes_h = run(-1, "huff")  # (its members are made on the GPU: [gpu] device_deflate, the default)
+        dt_hh, cpu_hh, counts_hh, _ = run(-1, "huffhost", "device_deflate : False\n")  # ... and by the host's pool alone
         # ... at the driver's own default output level (conf.py: gzip_level 6; the reference's gzip.open default is 9)
         dt_6, cpu_6, counts_6, out_bytes_6 = run(6, "lvl6")
         in_bytes = sum(os.path.getsize(p) for p in paths.values()) * n_chunks
@@ -227,6 +228,10 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
         huff = {"value": n / dt_h, "unit": "read-pairs/s", "seconds": dt_h, "gzip_level": -1, "output_gz_bytes": out_bytes_h,
                 "cpu_seconds_per_M_pairs": cpu_h / (n / 1e6), "core_utilisation": cpu_h / (dt_h * max(host_cores(), 1)),
                 "counts_equal": counts_h == counts,
+                "members_made_by": "the GPU (quade_deflate.hip) while page-locked buffers last, the host's pool otherwise",
+                "host_pool_only": {"value": n / dt_hh, "seconds": dt_hh, "cpu_seconds_per_M_pairs": cpu_hh / (n / 1e6),
+                                   "core_utilisation": cpu_hh / (dt_hh * max(host_cores(), 1)), "counts_equal": counts_hh == counts,
+                                   "what": "[gpu] device_deflate : False"},
                 "what": "same input, [gpu] gzip_level : -1 (Huffman coding only; on real fastq ~25 % larger files than level 1)"}
         single = sub(dt_s, cpu_s1, counts_s, gzip_level,
                      "same records, every input file ONE gzip member (the reference's input format), inflated by the "

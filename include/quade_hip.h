@@ -395,6 +395,29 @@ int qd_reader_open_on(const char* path, int64_t batch_records, int32_t queue_dep
 /* BGZF runs of this reader inflated by the device / by host threads so far (read it after the last batch). */
 int qd_reader_inflate_stats(const qd_reader* reader, int64_t* device_runs, int64_t* host_runs);
 
+/* ---- Huffman-only gzip members on the device --------------------------------------------------------------------
+ * The gzip inside FastqWriter.flush_buffers (src/FastqWriter.py:83-90 appends gzip members to the destination files),
+ * for the driver's `gzip_level : -1`: a member is one dynamic-Huffman DEFLATE block of literals (a byte histogram, a
+ * length-limited Huffman code, one table lookup per byte; no string matching) -- any gunzip reads it.  One workgroup
+ * codes one piece of text (quade_amd/csrc/quade_deflate.hip); the CRC-32 of every piece is made by the caller.
+ * A deflater owns a stream and grow-only staging buffers on one device and is driven by one thread at a time.
+ * qd_deflater_run: piece i = text[i][0 .. text_len[i]) (text_pinned != 0: every text[i] is page-locked memory from
+ * qd_pinned_alloc and is copied to the device without a staging copy); member i lands at out + i * out_stride
+ * (ordinary memory, out_stride >= qd_huffman_member_bound(longest piece), a multiple of 4), its length in
+ * member_len[i]; member_len[i] == 0: that member did not fit out_stride (make it on the host).  Blocking.
+ * qd_sink_set_device_deflate: the sink's Huffman-only members are made on `device_id` while the process has
+ * page-locked buffers to spare (192 x 2.5 MB); a piece that finds none is coded on its pool thread as before, so the
+ * host and the device share the work; device_id < 0: host only (the default).  Only gzip_level -1 is affected. */
+typedef struct qd_deflater qd_deflater;
+int qd_deflater_create(int device_id, qd_deflater** out);
+int qd_deflater_run(qd_deflater* deflater, int32_t n_pieces, const uint8_t* const* text, const int64_t* text_len,
+                    const uint32_t* crc32, int32_t text_pinned, uint8_t* out, int64_t out_stride, int64_t* member_len);
+int64_t qd_huffman_member_bound(int64_t text_len);
+int qd_deflater_destroy(qd_deflater* deflater);
+const char* qd_deflater_last_error(const qd_deflater* deflater);
+int qd_sink_set_device_deflate(qd_sink* sink, int32_t device_id);
+int qd_sink_device_members(qd_sink* sink, int64_t* device_members); /* of qd_sink_stats' members: made on the device */
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,9 @@ Optional [gpu] section (not in Quade 0.3.2; a conf file without it runs with the
                          speed of level 1, files ~25 % larger on real data)
   chunk_workers : 1      chunks processed concurrently by host threads (outputs identical)
   io_threads : 0         threads of the native gunzip / gzip pool (0 = one per core)
+  device_deflate : True  with gzip_level -1: the output members are made on the GPU (one workgroup per ~2 MB piece of
+                         formatted text) while page-locked buffers last, on the host's pool otherwise (+24 % end to end
+                         on a 16-core host); no effect at the other levels
   device_inflate : False BGZF (bgzip) input files are inflated on the GPU, one block per wave (default: on host threads --
                          on a 16-core host both ways run at the same rate; the GPU way uses 5-10 % less CPU)
 """
@@ -105,6 +108,7 @@ class QuadeConf(object):
         self.chunk_workers = opt("chunk_workers", 1)
         self.io_threads = opt("io_threads", 0)
         self.device_inflate = opt("device_inflate", "False", str).strip().lower() in ("true", "1", "yes", "on")
+        self.device_deflate = opt("device_deflate", "True", str).strip().lower() in ("true", "1", "yes", "on")
 
         self._test_values()
 

@@ -16,6 +16,7 @@
 #include "quade_common.h"
 #include "quade_kernels.h"
 #include "quade_inflate.h"
+#include "quade_deflate.h"
 
 typedef uint64_t u64;
 
@@ -1261,6 +1262,139 @@ static int inflater_run(qd_inflater* f, const uint8_t* comp, int64_t comp_len, u
         }
     }
     if (!out_pinned) memcpy(out, f->h_out, (size_t)out_len);
+    return QD_OK;
+}
+
+}  // extern "C"
+
+// ---- Huffman-only gzip members on the device (include/quade_hip.h; kernel: quade_deflate.hip) -------------------------
+struct qd_deflater {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    std::string err;
+    // grow-only staging: pinned host + device, for the text, the members, the piece table and the member lengths
+    uint8_t *h_text = nullptr, *d_text = nullptr, *h_out = nullptr, *d_out = nullptr;
+    size_t cap_text = 0, cap_out = 0;
+    qd_deflate_piece *h_pc = nullptr, *d_pc = nullptr;
+    uint32_t *h_len = nullptr, *d_len = nullptr;
+    size_t cap_pc = 0, cap_len = 0;
+};
+
+namespace {
+thread_local std::string g_deflater_error;
+int def_fail(qd_deflater* f, int code, const std::string& msg) {
+    if (f) f->err = msg;
+    else g_deflater_error = msg;
+    return code;
+}
+#define DEFCHK(f, call)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) return def_fail((f), QD_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+}  // namespace
+
+extern "C" {
+
+int64_t qd_huffman_member_bound(int64_t text_len) {
+    // a code for 257 symbols never needs more than 9 bits per byte on average (the fixed 9-bit code is a candidate); the
+    // 15-bit limit's repair and the header (149 bytes), end-of-block code and trailer ride in the slack
+    return text_len < 0 ? -1 : ((text_len * 9 + 7) / 8 + text_len / 64 + 1024 + 3) & ~(int64_t)3;
+}
+
+int qd_deflater_create(int device_id, qd_deflater** out) {
+    if (!out) return QD_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return def_fail(nullptr, QD_ERR_NO_DEVICE, "no such HIP device");
+    qd_deflater* f = new qd_deflater();
+    f->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&f->done, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
+        delete f;
+        return def_fail(nullptr, QD_ERR_HIP, "hipStreamCreate failed");
+    }
+    *out = f;
+    return QD_OK;
+}
+
+const char* qd_deflater_last_error(const qd_deflater* f) { return f ? f->err.c_str() : g_deflater_error.c_str(); }
+
+int qd_deflater_destroy(qd_deflater* f) {
+    if (!f) return QD_OK;
+    (void)hipSetDevice(f->device);
+    if (f->stream) {
+        (void)hipStreamSynchronize(f->stream);
+        (void)hipStreamDestroy(f->stream);
+    }
+    if (f->done) (void)hipEventDestroy(f->done);
+    if (f->h_text) (void)hipHostFree(f->h_text);
+    if (f->d_text) (void)hipFree(f->d_text);
+    if (f->h_out) (void)hipHostFree(f->h_out);
+    if (f->d_out) (void)hipFree(f->d_out);
+    if (f->h_pc) (void)hipHostFree(f->h_pc);
+    if (f->d_pc) (void)hipFree(f->d_pc);
+    if (f->h_len) (void)hipHostFree(f->h_len);
+    if (f->d_len) (void)hipFree(f->d_len);
+    delete f;
+    return QD_OK;
+}
+
+int qd_deflater_run(qd_deflater* f, int32_t n_pieces, const uint8_t* const* text, const int64_t* text_len, const uint32_t* crc32,
+                    int32_t text_pinned, uint8_t* out, int64_t out_stride, int64_t* member_len) {
+    if (!f || n_pieces < 0 || (n_pieces && (!text || !text_len || !crc32 || !out || !member_len)) || out_stride < 64 || (out_stride & 3))
+        return def_fail(f, QD_ERR_INVALID, "bad arguments");
+    if (n_pieces == 0) return QD_OK;
+    size_t total = 0;
+    for (int i = 0; i < n_pieces; ++i) {
+        if (text_len[i] < 0 || text_len[i] > (int64_t)0x7FFFFFFF || (text_len[i] && !text[i])) return def_fail(f, QD_ERR_INVALID, "bad piece");
+        total += ((size_t)text_len[i] + 15) & ~(size_t)15;
+    }
+    DEFCHK(f, hipSetDevice(f->device));
+    DEFCHK(f, grow_pair(f->h_pc, f->d_pc, f->cap_pc, (size_t)n_pieces));
+    DEFCHK(f, grow_pair(f->h_len, f->d_len, f->cap_len, (size_t)n_pieces));
+    DEFCHK(f, grow_pair(f->h_out, f->d_out, f->cap_out, (size_t)n_pieces * (size_t)out_stride));
+    if (total + 16 > f->cap_text) {  // device text always; the pinned staging copy only for pageable callers
+        if (f->h_text) (void)hipHostFree(f->h_text);
+        if (f->d_text) (void)hipFree(f->d_text);
+        f->h_text = f->d_text = nullptr;
+        f->cap_text = 0;
+        const size_t n = total + total / 4 + 4096;
+        DEFCHK(f, hipMalloc((void**)&f->d_text, n));
+        f->cap_text = n;
+    }
+    if (!text_pinned && !f->h_text) DEFCHK(f, hipHostMalloc((void**)&f->h_text, f->cap_text, hipHostMallocDefault));
+    size_t at = 0;
+    for (int i = 0; i < n_pieces; ++i) {
+        f->h_pc[i] = qd_deflate_piece{(uint64_t)at, (uint32_t)text_len[i], crc32[i]};
+        if (text_len[i]) {
+            const uint8_t* src = text[i];
+            if (!text_pinned) {
+                memcpy(f->h_text + at, text[i], (size_t)text_len[i]);
+                src = f->h_text + at;
+            }
+            DEFCHK(f, hipMemcpyAsync(f->d_text + at, src, (size_t)text_len[i], hipMemcpyHostToDevice, f->stream));
+        }
+        at += ((size_t)text_len[i] + 15) & ~(size_t)15;
+    }
+    DEFCHK(f, hipMemcpyAsync(f->d_pc, f->h_pc, (size_t)n_pieces * sizeof(qd_deflate_piece), hipMemcpyHostToDevice, f->stream));
+    DEFCHK(f, qd_launch_huffman(f->d_text, f->d_pc, (uint32_t)n_pieces, f->d_out, out_stride, f->d_len, f->stream));
+    DEFCHK(f, hipMemcpyAsync(f->h_len, f->d_len, (size_t)n_pieces * 4, hipMemcpyDeviceToHost, f->stream));
+    DEFCHK(f, hipEventRecord(f->done, f->stream));
+    DEFCHK(f, hipEventSynchronize(f->done));
+    for (int i = 0; i < n_pieces; ++i) {  // the used bytes of every member
+        if (f->h_len[i] > (uint64_t)out_stride) return def_fail(f, QD_ERR_HIP, "member longer than its slot");
+        if (f->h_len[i])
+            DEFCHK(f, hipMemcpyAsync(f->h_out + (size_t)i * (size_t)out_stride, f->d_out + (size_t)i * (size_t)out_stride, f->h_len[i],
+                                     hipMemcpyDeviceToHost, f->stream));
+    }
+    DEFCHK(f, hipEventRecord(f->done, f->stream));
+    DEFCHK(f, hipEventSynchronize(f->done));
+    for (int i = 0; i < n_pieces; ++i) {
+        member_len[i] = f->h_len[i];  // 0: this member did not fit out_stride (the caller makes it itself)
+        if (f->h_len[i]) memcpy(out + (size_t)i * (size_t)out_stride, f->h_out + (size_t)i * (size_t)out_stride, f->h_len[i]);
+    }
     return QD_OK;
 }
 

@@ -443,6 +443,8 @@ struct qd_sink {
     int64_t pending_jobs = 0, pending_bytes = 0;
     std::string err;
     int64_t members = 0, bytes_in = 0, bytes_out = 0;
+    int64_t device_members = 0;  // of `members`: made by the GPU (gzip_level -1 with a deflate device)
+    int deflate_device = -1;     // >= 0: Huffman-only members are made on that device while page-locked buffers last
     int quiet = 0;
 };
 
@@ -503,6 +505,164 @@ struct Piece {  // records order[lo..hi) of one read file of one destination
 
 }  // namespace
 
+// Huffman-only members on the device (quade_api.cpp / quade_deflate.hip); weak: this file also builds without the HIP half
+extern "C" {
+int qd_deflater_create(int device_id, qd_deflater** out) __attribute__((weak));
+int qd_deflater_run(qd_deflater* deflater, int32_t n_pieces, const uint8_t* const* text, const int64_t* text_len, const uint32_t* crc32,
+                    int32_t text_pinned, uint8_t* out, int64_t out_stride, int64_t* member_len) __attribute__((weak));
+int qd_deflater_destroy(qd_deflater* deflater) __attribute__((weak));
+int64_t qd_huffman_member_bound(int64_t text_len) __attribute__((weak));
+void* qd_pinned_alloc(int64_t bytes) __attribute__((weak));
+void qd_pinned_free(void* p) __attribute__((weak));
+}
+
+namespace {
+
+// A formatted piece on its way through the device: the text sits in a page-locked buffer of the service.
+struct DevPiece {
+    qd_sink* s;
+    OutFile* f;
+    uint64_t seq;
+    int64_t text_bytes;  // what the sink's back-pressure counted for this piece
+    uint8_t* text;
+    size_t cap;
+    int64_t len;
+    uint32_t crc;
+};
+
+void finish_piece(qd_sink* s, OutFile* f, uint64_t seq, int64_t text_bytes, int64_t w, Bytes&& member, bool on_device) {
+    const int64_t out_bytes = (int64_t)member.size();
+    deliver(s, f, seq, std::move(member));
+    std::lock_guard<std::mutex> g(s->m);
+    s->pending_bytes -= text_bytes;
+    --s->pending_jobs;
+    ++s->members;
+    if (on_device) ++s->device_members;
+    s->bytes_in += w > 0 ? w : 0;
+    s->bytes_out += out_bytes;
+    s->cv.notify_all();
+}
+
+// One per device, for the life of the process: two lanes (threads that sleep on the device, each with its own
+// deflater: one batch uploads and codes while the other's members come back) and the page-locked text buffers.
+// Pool jobs format a piece straight into such a buffer and queue it here; when no buffer is free the job codes its
+// piece on its own core as before -- the host and the device share the work by whoever is free.
+class DeflateService {
+  public:
+    static constexpr size_t BUF_BYTES = (size_t)JOB_BYTES + (JOB_BYTES >> 2) + (256u << 10);  // a piece, its tags, slack
+    static constexpr int MAX_BUFS = 192, MAX_BATCH = 32;
+    explicit DeflateService(int device) : device_(device) {
+        for (int i = 0; i < 2; ++i) lanes_.emplace_back([this] { lane(); });
+    }
+    // a buffer of BUF_BYTES, or nullptr (none free and the budget is spent, or no page-locked memory to be had)
+    uint8_t* take_buffer() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            if (failed_) return nullptr;
+            if (!free_.empty()) {
+                uint8_t* p = free_.back();
+                free_.pop_back();
+                return p;
+            }
+            if (made_ >= MAX_BUFS) return nullptr;
+            ++made_;
+        }
+        uint8_t* p = qd_pinned_alloc ? (uint8_t*)qd_pinned_alloc((int64_t)BUF_BYTES) : nullptr;
+        if (!p) {
+            std::lock_guard<std::mutex> g(m_);
+            --made_;
+        }
+        return p;
+    }
+    void give_buffer(uint8_t* p) {
+        std::lock_guard<std::mutex> g(m_);
+        free_.push_back(p);
+    }
+    void submit(const DevPiece& d) {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            q_.push_back(d);
+        }
+        cv_.notify_one();
+    }
+
+  private:
+    void lane() {
+        qd_deflater* def = nullptr;
+        bool usable = qd_deflater_create && qd_deflater_run && qd_huffman_member_bound && qd_deflater_create(device_, &def) == QD_OK;
+        const char* fa = getenv("QUADE_TEST_DEFLATE_FAIL_AFTER");  // test hook: the device "fails" after this many batches
+        const int64_t fail_after = fa && *fa ? atoll(fa) : -1;
+        int64_t batches = 0;
+        std::vector<uint8_t> out;
+        for (;;) {
+            std::vector<DevPiece> b;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [this] { return !q_.empty(); });
+                while (!q_.empty() && (int)b.size() < MAX_BATCH) {
+                    b.push_back(q_.front());
+                    q_.pop_front();
+                }
+            }
+            std::vector<const uint8_t*> tp(b.size());
+            std::vector<int64_t> tl(b.size()), ml(b.size(), 0);
+            std::vector<uint32_t> crc(b.size());
+            int64_t longest = 0;
+            for (size_t i = 0; i < b.size(); ++i) {
+                tp[i] = b[i].text;
+                tl[i] = b[i].len;
+                crc[i] = b[i].crc;
+                longest = std::max(longest, b[i].len);
+            }
+            bool ok = usable && !(fail_after >= 0 && batches >= fail_after);
+            int64_t stride = 0;
+            if (ok) {
+                stride = qd_huffman_member_bound(longest);
+                out.resize((size_t)stride * b.size());
+                ok = qd_deflater_run(def, (int32_t)b.size(), tp.data(), tl.data(), crc.data(), 1, out.data(), stride, ml.data()) == QD_OK;
+                ++batches;
+                if (!ok) {  // a HIP error: the host takes over from here (pool jobs stop asking for buffers)
+                    usable = false;
+                    std::lock_guard<std::mutex> g(m_);
+                    failed_ = true;
+                }
+            }
+            for (size_t i = 0; i < b.size(); ++i) {
+                Bytes member;
+                bool dev = ok && ml[i] > 0;
+                if (dev) {
+                    member.resize((size_t)ml[i]);
+                    memcpy(member.data(), out.data() + (size_t)stride * i, (size_t)ml[i]);
+                } else if (!huffman_member(b[i].text, (size_t)b[i].len, member)) {
+                    sink_error(b[i].s, "gzip compression failed");
+                    member.clear();
+                }
+                give_buffer(b[i].text);
+                finish_piece(b[i].s, b[i].f, b[i].seq, b[i].text_bytes, b[i].len, std::move(member), dev);
+            }
+        }
+    }
+    int device_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<DevPiece> q_;
+    std::vector<uint8_t*> free_;
+    int made_ = 0;
+    bool failed_ = false;
+    std::vector<std::thread> lanes_;
+};
+
+std::mutex g_deflate_services_mutex;
+std::map<int, DeflateService*> g_deflate_services;  // never destroyed: their lanes run until the process ends
+DeflateService* deflate_service(int device) {
+    std::lock_guard<std::mutex> g(g_deflate_services_mutex);
+    DeflateService*& sv = g_deflate_services[device];
+    if (!sv) sv = new DeflateService(device);
+    return sv;
+}
+
+}  // namespace
+
 extern "C" {
 
 int qd_io_threads(int32_t n_threads) {
@@ -538,6 +698,20 @@ int qd_sink_create(const char* outdir, int32_t n_samples, const char* const* nam
 }
 
 const char* qd_sink_last_error(const qd_sink* s) { return s ? s->err.c_str() : "sink is NULL"; }
+
+int qd_sink_set_device_deflate(qd_sink* s, int32_t device_id) {
+    if (!s) return QD_ERR_INVALID;
+    if (device_id >= 0 && !(qd_deflater_create && qd_deflater_run && qd_huffman_member_bound && qd_pinned_alloc)) return QD_ERR_NO_DEVICE;
+    s->deflate_device = device_id;
+    return QD_OK;
+}
+
+int qd_sink_device_members(qd_sink* s, int64_t* device_members) {
+    if (!s || !device_members) return QD_ERR_INVALID;
+    std::lock_guard<std::mutex> g(s->m);
+    *device_members = s->device_members;
+    return QD_OK;
+}
 
 int qd_sink_set_quiet(qd_sink* s, int32_t quiet) {
     if (!s) return QD_ERR_INVALID;
@@ -658,6 +832,27 @@ static int route_impl(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_
     Pool& P = pool();
     for (const Piece& p : pieces) {
         P.submit([s, p, tag_rows, tag_stride, tag_len, res]() mutable {
+            // Huffman-only members with a deflate device: format straight into a page-locked buffer and hand the piece
+            // to the device lanes (which deliver it); no buffer free = this core codes the piece itself, as below
+            if (s->level < 0 && s->deflate_device >= 0) {
+                DeflateService* sv = deflate_service(s->deflate_device);
+                const size_t need = (size_t)p.text_bytes + 8 * (size_t)p.n_sel + 16;
+                uint8_t* buf = need <= DeflateService::BUF_BYTES ? sv->take_buffer() : nullptr;
+                if (buf) {
+                    const int64_t w = qd_format_records(p.text, p.rec_off, p.sel, p.n_sel, tag_rows, tag_stride, tag_len, buf,
+                                                        (int64_t)DeflateService::BUF_BYTES);
+                    res->formatted.done();
+                    res.reset();
+                    if (w >= 0) {
+                        sv->submit(DevPiece{s, p.f, p.seq, p.text_bytes, buf, DeflateService::BUF_BYTES, w, qd_io_crc32(buf, (size_t)w)});
+                    } else {
+                        sv->give_buffer(buf);
+                        sink_error(s, "qd_format_records failed (malformed record text)");
+                        finish_piece(s, p.f, p.seq, p.text_bytes, w, Bytes(), false);
+                    }
+                    return;
+                }
+            }
             thread_local Bytes text;  // formatted records of this piece: the pool thread's scratch, grown once
             Bytes member;
             text.clear();
@@ -673,15 +868,7 @@ static int route_impl(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_
                 ok = false;
             }
             if (!ok) member.clear();  // keep the file's sequence moving
-            const int64_t out_bytes = (int64_t)member.size();
-            deliver(s, p.f, p.seq, std::move(member));
-            std::lock_guard<std::mutex> g(s->m);
-            s->pending_bytes -= p.text_bytes;
-            --s->pending_jobs;
-            ++s->members;
-            s->bytes_in += w > 0 ? w : 0;
-            s->bytes_out += out_bytes;
-            s->cv.notify_all();
+            finish_piece(s, p.f, p.seq, p.text_bytes, w, std::move(member), false);
         });
     }
     if (!owned) res->formatted.wait();  // the caller's buffers are free again

@@ -1147,17 +1147,18 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // with a guard per load every load sat in its own exec-masked block and their latencies added up (~10 us
 // per pair and lane).  No word is read that holds no byte of the lane's slice, so the end of an array is
 // passed by at most the 1-3 bytes that share a word (and a page) with its last byte.
-__device__ __forceinline__ void load_bytes32(const uint8_t* p, int nbytes, int wmax, u64 (&w)[4]) {
+template <int NW>  // NW 64-bit words of output: nbytes, wmax <= 8 * NW
+__device__ __forceinline__ void load_bytes(const uint8_t* p, int nbytes, int wmax, u64 (&w)[NW]) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
     const int sh = (int)(a & 3), need = sh + nbytes;
     const int ju = wmax > 0 ? (wmax + 6) >> 2 : 0;    // dwords that can hold 3 + wmax bytes (uniform)
     const int jl = need > 0 ? (need - 1) >> 2 : 0;    // the lane's last needed dword
-    uint32_t d[9];
+    uint32_t d[2 * NW + 1];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) d[j] = (j < ju) ? q[j < jl ? j : jl] : 0u;
+    for (int j = 0; j < 2 * NW + 1; ++j) d[j] = (j < ju) ? q[j < jl ? j : jl] : 0u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NW; ++i) {
         const u64 lo = (u64)d[2 * i] | ((u64)d[2 * i + 1] << 32), nx = d[2 * i + 2];
         const u64 v = sh ? (lo >> (8 * sh)) | (nx << (64 - 8 * sh)) : lo;
         const int left = nbytes - 8 * i;  // wanted bytes of this word
@@ -1165,14 +1166,15 @@ __device__ __forceinline__ void load_bytes32(const uint8_t* p, int nbytes, int w
     }
 }
 
-// w |= v << (8 * off) over the 256 bits (off = 0..32 bytes; what leaves the top is dropped)
-__device__ __forceinline__ void or_shifted32(u64 (&w)[4], const u64 (&v)[4], int off) {
+// w |= v << (8 * off) over the 64 * NW bits (off = 0 .. 8 * NW bytes; what leaves the top is dropped)
+template <int NW>
+__device__ __forceinline__ void or_shifted(u64 (&w)[NW], const u64 (&v)[NW], int off) {
     const int ws = off >> 3, bs = (off & 7) * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NW; ++i) {
         u64 cur = 0, prev = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NW; ++j) {
             cur = (j == i - ws) ? v[j] : cur;
             prev = (j == i - ws - 1) ? v[j] : prev;
         }
@@ -1224,15 +1226,15 @@ __device__ __forceinline__ uint32_t generic_pair(const DemuxParams& p, int64_t r
         for (int k = 0; k < 2; ++k) {
             if (k >= p.n_streams) break;
             u64 v[4], qv[4];
-            load_bytes32(srow[k] + p.idx_off[k], a[k], p.idx_w[k], v);
-            load_bytes32(qrow[k], a[k], p.idx_w[k], qv);
+            load_bytes<4>(srow[k] + p.idx_off[k], a[k], p.idx_w[k], v);
+            load_bytes<4>(qrow[k], a[k], p.idx_w[k], qv);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 v[i] = qd_fold8(v[i]);
                 const int left = a[k] - 8 * i;  // quality bytes of this word that count; the others read as 0xFF
                 pass &= qd_all_ge8(left >= 8 ? qv[i] : (left <= 0 ? ~0ull : qv[i] | (~0ull << (8 * left))), p.thr);
             }
-            or_shifted32(w, v, at);
+            or_shifted<4>(w, v, at);
             at += a[k];
         }
     }
@@ -1274,8 +1276,8 @@ __device__ __forceinline__ uint32_t generic_pair(const DemuxParams& p, int64_t r
         for (int k = 0; k < 2; ++k) {
             if (k >= p.n_streams) break;
             u64 v[4];
-            load_bytes32(srow[k] + p.mol_off[k], ma[k], p.mol_w[k], v);
-            or_shifted32(m, v, at);
+            load_bytes<4>(srow[k] + p.mol_off[k], ma[k], p.mol_w[k], v);
+            or_shifted<4>(m, v, at);
             at += ma[k];
         }
         if ((p.M & 3) == 0) {  // r * M is a multiple of 4 then: dword stores
@@ -1294,6 +1296,120 @@ __device__ __forceinline__ uint32_t generic_pair(const DemuxParams& p, int64_t r
 // lengths from the per-pair len rows (absent: every read covers its window)
 __device__ __forceinline__ uint32_t generic_pair(const DemuxParams& p, int64_t r) {
     return generic_pair(p, r, p.len[0] ? (int)p.len[0][r] : 0x7FFFFFFF, p.len[1] ? (int)p.len[1][r] : 0x7FFFFFFF);
+}
+
+// ---- the generic path specialised by what a plan fixes for a whole launch --------------------------------------
+// Every read covers its window (no len rows), NS index reads, keys of at most 8 * KW bytes, molecular bytes of at
+// most 8 * MWORDS (0: none).  Same steps as generic_pair(); what changes is what the compiler knows: the word
+// arrays have the size the plan needs (a 16-byte key is two words, not four), the slice widths are wave-uniform (no
+// per-lane clamping), and the stream loop has a constant bound -- the catch-all keeps ~160 scalars alive and spills
+// them through VGPR lanes (158 SGPR spills, 942 VALU per pair).
+template <int NS, int KW, int MWORDS>
+__device__ __forceinline__ uint32_t special_pair(const DemuxParams& p, int64_t r) {
+    u64 w[KW];
+#pragma unroll
+    for (int i = 0; i < KW; ++i) w[i] = 0;
+    uint32_t pass = 1;
+    int at = 0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int iw = p.idx_w[k];
+        u64 v[KW], qv[KW];
+        load_bytes<KW>(p.seq[k] + r * p.seq_stride[k] + p.idx_off[k], iw, iw, v);
+        load_bytes<KW>(p.qual[k] + r * p.qual_stride[k], iw, iw, qv);
+#pragma unroll
+        for (int i = 0; i < KW; ++i) {
+            v[i] = qd_fold8(v[i]);                                                    // a3
+            const int left = iw - 8 * i;  // quality bytes of this word that count; the others read as 0xFF
+            pass &= qd_all_ge8(left >= 8 ? qv[i] : (left <= 0 ? ~0ull : qv[i] | (~0ull << (8 * left))), p.thr);  // a5
+        }
+        or_shifted<KW>(w, v, at);                                                     // a1
+        at += iw;
+    }
+    // a4: the global table of every barcode (a K-long key can only equal a K-long barcode)
+    uint32_t code = QD_CODE_UNDET;
+    {
+        uint32_t h = qd_hash_init((uint32_t)at, p.gseed);
+#pragma unroll
+        for (int i = 0; i < KW; ++i)
+            if (8 * i < at) h = qd_hash_step(h, w[i]);
+        h = qd_hash_fini(h);
+        const uint32_t fp = h >> 16;
+        uint32_t s = h & p.gmask;
+        for (;;) {
+            const uint32_t e = p.gslots[s];
+            if (e == QD_EMPTY_SLOT) break;
+            if ((e >> 16) == fp) {
+                const uint32_t id = e & 0xFFFFu;
+                const u64* b = p.bk32 + (size_t)id * QD_KEY_WORDS;
+                bool same = p.blen[id] == (uint8_t)at;
+#pragma unroll
+                for (int i = 0; i < KW; ++i) same = same && b[i] == w[i];
+                if (same) {
+                    code = id * 2u + (pass ^ 1u);
+                    break;
+                }
+            }
+            s = (s + 1) & p.gmask;
+        }
+    }
+    p.codes[r] = (uint16_t)code;
+    if (MWORDS > 0) {  // a2: molecular bytes, I1 part then I2 part
+        constexpr int MW_ = MWORDS > 0 ? MWORDS : 1;
+        u64 m[MW_];
+#pragma unroll
+        for (int i = 0; i < MW_; ++i) m[i] = 0;
+        int mat = 0;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            u64 v[MW_];
+            load_bytes<MW_>(p.seq[k] + r * p.seq_stride[k] + p.mol_off[k], p.mol_w[k], p.mol_w[k], v);
+            or_shifted<MW_>(m, v, mat);
+            mat += p.mol_w[k];
+        }
+        uint8_t* d = p.mol + r * p.M;
+        if ((p.M & 3) == 0) {
+#pragma unroll
+            for (int j = 0; j < 2 * MW_; ++j)
+                if (4 * j < p.M) reinterpret_cast<uint32_t*>(d)[j] = (uint32_t)(m[j >> 1] >> (32 * (j & 1)));
+        } else {
+#pragma unroll
+            for (int o = 0; o < 8 * MW_; ++o)
+                if (o < p.M) d[o] = (uint8_t)(m[o >> 3] >> (8 * (o & 7)));
+        }
+    }
+    return code;
+}
+
+template <int NS, int KW, int MWORDS>
+__global__ __launch_bounds__(QD_GEN_BLOCK) void demux_special(const DemuxParams p, uint32_t hist_entries) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw);
+    const int64_t stride = (int64_t)gridDim.x * QD_GEN_BLOCK;
+    const uint32_t S = p.n_samples;
+    qd_row_t* row = p.partial + (size_t)(blockIdx.x % p.partial_rows) * p.cnt_stride;
+    for (uint32_t i = threadIdx.x; i < hist_entries; i += QD_GEN_BLOCK) hist[i] = 0;
+    if (hist_entries) __syncthreads();
+    uint32_t undet = 0;
+    for (int64_t r = (int64_t)blockIdx.x * QD_GEN_BLOCK + threadIdx.x; r < p.n; r += stride) {
+        const uint32_t code = special_pair<NS, KW, MWORDS>(p, r);
+        if (code == QD_CODE_UNDET)
+            ++undet;
+        else if (hist_entries)
+            atomicAdd(&hist[code], 1u);
+        else
+            atomicAdd(&row[code], (qd_row_t)1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) undet += __shfl_xor(undet, o, 64);
+    if ((threadIdx.x & 63) == 0 && undet) atomicAdd(&row[2 * S], (qd_row_t)undet);
+    if (hist_entries) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < hist_entries; i += QD_GEN_BLOCK) {
+            const uint32_t v = hist[i];
+            if (v) atomicAdd(&row[i], (qd_row_t)v);
+        }
+    }
 }
 
 // hist_entries = 2S+1 when the per-sample counters fit the workgroup's LDS (dynamic, 4 B each): one LDS
@@ -1524,9 +1640,34 @@ hipError_t qd_launch_fast(const DemuxParams& p, QdKernelCache& cache, int cus, i
     return launch_fast_b<512>(p, cache, cus, wg_per_cu, lds_bytes, strip_bytes_per_wave, st);
 }
 
+namespace {
+template <int NS, int KW>
+void launch_special_m(const DemuxParams& p, int grid, size_t lds, uint32_t entries, hipStream_t st) {
+    if (p.M == 0) hipLaunchKernelGGL((demux_special<NS, KW, 0>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
+    else if (p.M <= 16) hipLaunchKernelGGL((demux_special<NS, KW, 2>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
+    else hipLaunchKernelGGL((demux_special<NS, KW, 4>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
+}
+}  // namespace
+
 hipError_t qd_launch_generic(const DemuxParams& p, int grid, hipStream_t st) {
     const uint32_t entries = 2 * p.n_samples + 1 <= 16000 ? 2 * p.n_samples + 1 : 0;  // <= 64 KB of LDS (the default limit)
-    hipLaunchKernelGGL(demux_generic, dim3(grid), dim3(QD_GEN_BLOCK), (size_t)entries * 4, st, p, entries);
+    const size_t lds = (size_t)entries * 4;
+    // every read covers its window and the plan fits the specialised forms (key <= 32 bytes -- always --, at most 16 /
+    // 32 key and 32 molecular bytes, every slice inside the words of its form): NS x KW x molecular words
+    bool special = QD_GENERIC_SPECIAL && !p.len[0] && !p.len[1] && p.M <= 32 && p.K <= 32;
+    const int kw = p.K <= 16 ? 2 : 4, mwords = p.M == 0 ? 0 : (p.M <= 16 ? 2 : 4);
+    for (int k = 0; k < p.n_streams; ++k) special = special && p.idx_w[k] <= 8 * kw && p.mol_w[k] <= 8 * (mwords ? mwords : 1);
+    if (special) {
+        if (p.n_streams == 1) {
+            if (kw == 2) launch_special_m<1, 2>(p, grid, lds, entries, st);
+            else launch_special_m<1, 4>(p, grid, lds, entries, st);
+        } else {
+            if (kw == 2) launch_special_m<2, 2>(p, grid, lds, entries, st);
+            else launch_special_m<2, 4>(p, grid, lds, entries, st);
+        }
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(demux_generic, dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
     return hipGetLastError();
 }
 

@@ -40,7 +40,9 @@ class FastqSink(object):
     """All destinations of one output directory."""
 
     def __init__(self, outdir, sample_names, gzip_level=6, write_pass=True, write_fail=True, write_undetermined=True,
-                 quiet=False):
+                 quiet=False, deflate_device=-1):
+        """deflate_device >= 0: with gzip_level -1 the members are made on that GPU (quade_deflate.hip) while the
+        process has page-locked buffers to spare, on the pool's threads otherwise."""
         self.lib = hb.load_library()
         names = [n.encode() if isinstance(n, str) else bytes(n) for n in sample_names]
         arr = (C.c_char_p * max(len(names), 1))(*names)
@@ -52,6 +54,8 @@ class FastqSink(object):
         self._h = h
         if quiet:
             self.lib.qd_sink_set_quiet(self._h, 1)
+        if deflate_device is not None and deflate_device >= 0:
+            self._chk(self.lib.qd_sink_set_device_deflate(self._h, int(deflate_device)))
 
     def _chk(self, r):
         if r != hb.QD_OK:
@@ -86,6 +90,12 @@ class FastqSink(object):
         v = [C.c_int64(0) for _ in range(4)]
         self.lib.qd_sink_stats(self._h, *[C.byref(x) for x in v])
         return dict(zip(("members", "text_bytes", "gzip_bytes", "files"), (x.value for x in v)))
+
+    def device_members(self):
+        """Of stats()["members"]: how many the GPU made."""
+        v = C.c_int64(0)
+        self.lib.qd_sink_device_members(self._h, C.byref(v))
+        return v.value
 
     def close(self):
         if getattr(self, "_h", None):

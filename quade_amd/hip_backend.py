@@ -119,6 +119,13 @@ SYMBOLS = [
     ("qd_reader_gunzip_stats", C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("qd_gunzip_buffer", C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.POINTER(C.c_int64), _P]),
     ("qd_gunzip_last_error", C.c_char_p, []),
+    ("qd_deflater_create", C.c_int, [C.c_int, C.POINTER(_P)]),
+    ("qd_deflater_run", C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int64, _P]),
+    ("qd_huffman_member_bound", C.c_int64, [C.c_int64]),
+    ("qd_deflater_destroy", C.c_int, [_P]),
+    ("qd_deflater_last_error", C.c_char_p, [_P]),
+    ("qd_sink_set_device_deflate", C.c_int, [_P, C.c_int32]),
+    ("qd_sink_device_members", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("qd_reader_next", C.c_int, [_P, C.POINTER(qd_text_batch)]),
     ("qd_text_batch_free", C.c_int, [_P]),
     ("qd_reader_close", C.c_int, [_P]),

@@ -140,6 +140,8 @@ class Quade(object):
                 self.engines.append(eng)
             self.engine_groups.append(group)
         self.plan, self.layout = plan, self.engines[0].layout
+        # Huffman-only output members on the first device of this process ([gpu] device_deflate, gzip_level -1)
+        Sample.DEFLATE_DEVICE = self.engines[0].device_id if (cf.device_deflate and cf.gzip_level < 0) else -1
 
         # the communicator comes up before any chunk is touched: rank 0 clears stale part files, then
         # publishes the id the other ranks wait for, so nobody writes parts before the clean-up

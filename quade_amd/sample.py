@@ -31,10 +31,11 @@ class WriterSet(object):
     (quade_amd/fastq_writer.py).  Sample owns one for the run's output directory; chunk workers and
     the multi-process mode use one per chunk part directory."""
 
-    def __init__(self, outdir, gzip_level):
+    def __init__(self, outdir, gzip_level, deflate_device=None):
         self.outdir, self.gzip_level = outdir, gzip_level
         self._sink = FastqSink(outdir, [s.name for s in Sample.SAMPLE_LIST], gzip_level, Sample.WRITE_PASS,
-                               Sample.WRITE_FAIL, Sample.WRITE_UNDETERMINED)
+                               Sample.WRITE_FAIL, Sample.WRITE_UNDETERMINED,
+                               deflate_device=Sample.DEFLATE_DEVICE if deflate_device is None else deflate_device)
 
     def route(self, batch):
         """src/Sample.py:56-91 for every pair of the batch, counters excluded (they come from the
@@ -62,6 +63,7 @@ class Sample(object):
     DNA = ["A", "T", "C", "G", "N"]
     MIN_QUAL = 0
     OUTDIR = "."
+    DEFLATE_DEVICE = -1  # >= 0: Huffman-only output members ([gpu] gzip_level : -1) are made on that GPU
     GZIP_LEVEL = 6
     WRITERS = None  # WriterSet of the run's output directory
 
@@ -76,6 +78,7 @@ class Sample(object):
         if cls.WRITERS is not None:
             cls.WRITERS.close()
         cls.WRITERS = None
+        cls.DEFLATE_DEVICE = -1
 
     @classmethod
     def CLASS_INIT(cls, write_undetermined=False, write_pass=False, write_fail=False, min_qual=0,

@@ -1,0 +1,152 @@
+"""Huffman-only gzip members made on the GPU (quade_amd/csrc/quade_deflate.hip, qd_deflater_*): the gzip of the output
+files (src/FastqWriter.py:83-90) for the driver's `gzip_level : -1`.  The checker is zlib (any gunzip must read the
+members) and, for whole runs, the files the host's own Huffman-only coder writes."""
+import ctypes as C
+import gzip
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(lib, d, pieces, pinned):
+    from quade_amd import hip_backend as hb
+    n = len(pieces)
+    keep, ptrs = [], (C.c_void_p * max(n, 1))()
+    for i, t in enumerate(pieces):
+        if pinned and len(t):
+            p = lib.qd_pinned_alloc(len(t) + 16)
+            assert p
+            C.memmove(p, t, len(t))
+            keep.append(p)
+            ptrs[i] = p
+        else:
+            b = np.frombuffer(t, np.uint8) if len(t) else np.zeros(1, np.uint8)
+            keep.append(b)
+            ptrs[i] = b.ctypes.data
+    lens = np.array([len(t) for t in pieces], np.int64)
+    crc = np.array([zlib.crc32(t) for t in pieces], np.uint32)
+    stride = lib.qd_huffman_member_bound(int(lens.max()) if n else 0)
+    out = np.zeros(max(n, 1) * stride, np.uint8)
+    ml = np.zeros(max(n, 1), np.int64)
+    rc = lib.qd_deflater_run(d, n, ptrs, hb._ptr(lens), hb._ptr(crc), 1 if pinned else 0, hb._ptr(out), stride, hb._ptr(ml))
+    assert rc == 0, lib.qd_deflater_last_error(d)
+    members = [bytes(out[i * stride:i * stride + int(ml[i])]) for i in range(n)]
+    if pinned:
+        for p in keep:
+            if isinstance(p, int):
+                lib.qd_pinned_free(p)
+    return members
+
+
+def test_device_members_inflate_with_zlib_to_the_text():
+    """Every shape of symbol statistics the host coder is tested on (tests/test_host_sink.py), through the kernel: one
+    symbol, two, all 256, steep geometric tails that need the 15-bit repair, incompressible bytes, the empty piece,
+    pieces that are no multiple of a tile, a 5 MB piece; from page-locked and from ordinary memory."""
+    from quade_amd import hip_backend as hb
+    lib = hb.load_library()
+    rng = np.random.default_rng(21)
+    fastq = b"".join(b"@r%d 1:N:0:\n%s\n+\n%s\n" % (i, bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 150)),
+                                                  bytes(rng.integers(35, 74, 150).astype(np.uint8))) for i in range(16000))
+    fib = [1, 1]
+    while len(fib) < 34:
+        fib.append(fib[-1] + fib[-2])
+    pieces = [fastq[:2 << 20], fastq[:4097], fastq[:4096], fastq[:4095], fastq[:17], b"A" * 100000, bytes(range(256)) * 300,
+              bytes(rng.integers(0, 256, 300000).astype(np.uint8)), b"x", b"ab", b"",
+              b"".join(bytes([40 + i]) * f for i, f in enumerate(fib[1:])), fastq]
+    for k in (16, 18, 20, 24):
+        pieces.append(b"".join(bytes([65 + i]) * (1 << i) for i in range(k))[:6 << 20])
+    d = C.c_void_p()
+    assert lib.qd_deflater_create(0, C.byref(d)) == 0
+    try:
+        for pinned in (False, True):
+            members = _run(lib, d, pieces, pinned)
+            for t, m in zip(pieces, members):
+                assert len(m) > 18 and gzip.decompress(m) == t, (pinned, len(t))
+            assert len(members[0]) < 0.62 * len(pieces[0])  # near the entropy of the bytes, as the host coder
+        # a slot that is too small is reported, not overrun
+        t = pieces[0]
+        lens = np.array([len(t)], np.int64)
+        crc = np.array([zlib.crc32(t)], np.uint32)
+        buf = np.frombuffer(t, np.uint8)
+        ptrs = (C.c_void_p * 1)(buf.ctypes.data)
+        out = np.full(4096 + 64, 0xAB, np.uint8)
+        ml = np.full(1, -1, np.int64)
+        assert lib.qd_deflater_run(d, 1, ptrs, hb._ptr(lens), hb._ptr(crc), 0, hb._ptr(out), 4096, hb._ptr(ml)) == 0
+        assert ml[0] == 0 and (out[4096:] == 0xAB).all()
+    finally:
+        lib.qd_deflater_destroy(d)
+
+
+def _unzip_dir(d):
+    return {f: gzip.open(os.path.join(d, f)).read() for f in sorted(os.listdir(d)) if f.endswith(".fastq.gz")}
+
+
+@pytest.mark.parametrize("fail_after", [None, "1"])
+def test_cli_with_device_deflate_writes_the_same_files(tmp_path, monkeypatch, fail_after):
+    """`[gpu] gzip_level : -1` + `device_deflate : True` through the command line driver: same decompressed files and
+    report as with the host's coder, and the GPU really made members.  fail_after: the device "fails" after its
+    first batch (test hook) -- the pieces already queued and all later ones are coded by the host, nothing is lost."""
+    from quade_amd import synth
+    from quade_amd.quade import Quade
+    from quade_amd.sample import Sample
+    work = str(tmp_path)
+    paths, bcs = synth.write_fastq_dataset(work, 120_000, n_samples=24)
+    if fail_after:
+        monkeypatch.setenv("QUADE_TEST_DEFLATE_FAIL_AFTER", fail_after)
+    outs = {}
+    for mode in ("False", "True"):
+        conf = os.path.join(work, "conf_%s.txt" % mode)
+        synth.write_conf(conf, paths, bcs, 2, gpu="[gpu]\nbatch_pairs : 50000\ngzip_level : -1\ndevice_deflate : %s\n" % mode)
+        out = os.path.join(work, "out_" + mode)
+        os.mkdir(out)
+        cwd = os.getcwd()
+        os.chdir(out)
+        try:
+            assert Quade(conf_file=conf)() == 0
+        finally:
+            os.chdir(cwd)
+        outs[mode] = (_unzip_dir(out), Sample.COUNTS(), open(os.path.join(out, "Quade_report.csv")).read().split("\n")[1:])
+    assert outs["True"] == outs["False"]
+    assert outs["True"][1][0] == 240_000 and len(outs["True"][0]) > 20
+
+
+def test_sink_shares_pieces_between_device_and_host(tmp_path):
+    """The native sink with a deflate device: pieces go to the GPU while page-locked buffers last, to the pool's threads
+    otherwise; either way the files equal the host-only sink's after decompression, and device_members says how many
+    the GPU made."""
+    from quade_amd import synth
+    from quade_amd.fastq_reader import FastqStream
+    from quade_amd.fastq_writer import FastqSink
+    paths, bcs = synth.write_fastq_dataset(str(tmp_path), 200_000)
+    names = ["S%d" % i for i in range(len(bcs))]
+    rng = np.random.default_rng(5)
+    got = {}
+    for dev in (-1, 0):
+        o = tmp_path / ("out%d" % dev)
+        o.mkdir()
+        sink = FastqSink(str(o), names, -1, quiet=True, deflate_device=dev)
+        s1, s2 = FastqStream(paths["seq_R1"], 50_000), FastqStream(paths["seq_R2"], 50_000)
+        r = np.random.default_rng(6)
+        while True:
+            b1, b2 = s1.take(), s2.take()
+            n = min(b1.n, b2.n)
+            if n == 0:
+                break
+            codes = r.integers(0, 2 * len(bcs) + 10, n).astype(np.uint16)
+            codes[codes >= 2 * len(bcs)] = 0xFFFF
+            tags = np.zeros((n, 6), np.uint8)
+            tags[:] = np.frombuffer(b":ACGTA", np.uint8)
+            sink.route_batches(n, codes, b1, b2, tags, np.full(n, 6, np.uint8))
+        sink.flush()
+        st = sink.stats()
+        got[dev] = (_unzip_dir(str(o)), st["members"], sink.device_members())
+        sink.close()
+        s1.close()
+        s2.close()
+    assert got[0][0] == got[-1][0] and got[0][1] == got[-1][1]
+    assert got[-1][2] == 0 and got[0][2] > 0, got[0][1:]
+    del rng

@@ -135,3 +135,17 @@ int main() {
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0 and r.stdout.startswith("ok"), (r.returncode, r.stdout, r.stderr[-3000:])
+
+
+def test_write_through_stores_keep_their_hazard_pad():
+    """The fast kernels' 16-byte `sc1` stores are inline asm followed by `s_nop 1` (without the pad the
+    next instruction overwrote the store's data registers -- wrong codes in lanes 12-15).  The device listing is
+    producible without a GPU (make asm); tools/isa_check.py fails if any such store lost its pad."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "quade_amd", "csrc"), "asm"])
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import isa_check
+    n, bad = isa_check.check_store_pad(os.path.join(root, "quade_amd", "lib", "asm", "quade_kernels.s"))
+    assert n >= 20 and not bad, (n, bad[:3])

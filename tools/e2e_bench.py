@@ -3,7 +3,7 @@
 the CLI driver.  Host bound (gunzip, scan, format, gzip); printed as one JSON line.
 usage: python tools/e2e_bench.py [pairs] [gzip level] [chunks] [--single-member | --members] [--ranks N]
 input files: BGZF (bgzip layout) by default, --members = 8 MB gzip members, --single-member = one gzip member
-env: E2E_PARALLEL_GUNZIP (1; 0 = ordinary gzip files on one thread each), E2E_GUNZIP_CHUNK, E2E_GUNZIP_IN_FLIGHT, E2E_DEVICE_INFLATE (0; 1 = BGZF inflate on the GPU), E2E_WORKERS (chunk_workers), E2E_IO_THREADS, E2E_SAMPLES (96), E2E_BATCH (500000), QUADE_PROFILE=1 (stage timers)"""
+env: E2E_PARALLEL_GUNZIP (1; 0 = ordinary gzip files on one thread each), E2E_GUNZIP_CHUNK, E2E_GUNZIP_IN_FLIGHT, E2E_DEVICE_INFLATE (0; 1 = BGZF inflate on the GPU), E2E_DEVICE_DEFLATE (0; 1 = Huffman-only members made on the GPU, level -1), E2E_WORKERS (chunk_workers), E2E_IO_THREADS, E2E_SAMPLES (96), E2E_BATCH (500000), QUADE_PROFILE=1 (stage timers)"""
 import json
 import os
 import shutil
@@ -38,8 +38,9 @@ try:
     t_gen = time.perf_counter() - t0
     conf = os.path.join(work, "conf.txt")
     dev_inflate = os.environ.get("E2E_DEVICE_INFLATE", "0") not in ("0", "false", "False")
-    synth.write_conf(conf, paths, bcs, n_chunks, gpu="[gpu]\nbatch_pairs : %d\ngzip_level : %d\nchunk_workers : %d\nio_threads : %d\ndevice_inflate : %s\n"
-                     % (batch, level, workers, io_thr, dev_inflate))
+    dev_deflate = os.environ.get("E2E_DEVICE_DEFLATE", "0") not in ("0", "false", "False")  # gzip level -1 only
+    synth.write_conf(conf, paths, bcs, n_chunks, gpu="[gpu]\nbatch_pairs : %d\ngzip_level : %d\nchunk_workers : %d\nio_threads : %d\ndevice_inflate : %s\ndevice_deflate : %s\n"
+                     % (batch, level, workers, io_thr, dev_inflate, dev_deflate))
     out = os.path.join(work, "out")
     os.mkdir(out)
     os.chdir(out)
@@ -69,7 +70,7 @@ try:
     from quade_amd.fastq_writer import host_cores, io_backend, io_threads
     print(json.dumps({"mode": "end-to-end fastq.gz -> fastq.gz", "chunks": n_chunks, "pairs": n * n_chunks, "seconds": dt,
                       "pairs_per_s": n * n_chunks / dt, "gzip_level": level, "counts": counts, "chunk_workers": workers,
-                      "ranks": ranks, "device_inflate": dev_inflate, "parallel_gunzip": os.environ.get("E2E_PARALLEL_GUNZIP", "1") != "0", "samples": n_samples, "batch_pairs": batch, "input": {0: "single gzip member", "bgzf": "BGZF"}.get(fmt, "8 MB gzip members"), "gzip_backend": io_backend(),
+                      "ranks": ranks, "device_inflate": dev_inflate, "device_deflate": dev_deflate, "parallel_gunzip": os.environ.get("E2E_PARALLEL_GUNZIP", "1") != "0", "samples": n_samples, "batch_pairs": batch, "input": {0: "single gzip member", "bgzf": "BGZF"}.get(fmt, "8 MB gzip members"), "gzip_backend": io_backend(),
                       "io_threads": io_threads(), "host_cores": host_cores(), "host_logical_cpus": os.cpu_count(), "dataset_seconds": round(t_gen, 1),
                       "cpu_seconds": cpu_s, "cpu_user_sys": [round(cpu_user, 2), round(cpu_sys, 2)] if cpu_s else None, "cpu_seconds_per_M_pairs": cpu_s / (n * n_chunks / 1e6) if cpu_s else None,
                       "core_utilisation": cpu_s / (dt * host_cores()) if cpu_s else None}))
