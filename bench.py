@@ -542,9 +542,9 @@ def main():
         "unit": "read-pairs/s",
         "n_gpus": world,
         "steps": args.steps,
-        "warmup": untimed,              # untimed launches that ran before the timed region
-        "warmup_requested": args.warmup,  # --warmup W, topped up until the launch time settles (>= 50)
-        "untimed_launches": untimed,  # W topped up until the launch time settles (>= 50; outside the timed region)
+        "warmup": args.warmup,     # --warmup W as requested ...
+        "warmup_ran": untimed,     # ... and the untimed launches that really ran before the timed region: W topped up
+        "untimed_launches": untimed,  # until the launch time settles (>= 50; same number, kept for older readers)  # W topped up until the launch time settles (>= 50; outside the timed region)
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",

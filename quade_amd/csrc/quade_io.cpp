@@ -550,27 +550,24 @@ void finish_piece(qd_sink* s, OutFile* f, uint64_t seq, int64_t text_bytes, int6
 class DeflateService {
   public:
     static constexpr size_t BUF_BYTES = (size_t)JOB_BYTES + (JOB_BYTES >> 2) + (256u << 10);  // a piece, its tags, slack
-    static constexpr int MAX_BUFS = 192, MAX_BATCH = 32;
+    static constexpr int MAX_BUFS = 192, MAX_BATCH = 32;  // (192 = 4 slabs)
     explicit DeflateService(int device) : device_(device) {
         for (int i = 0; i < 2; ++i) lanes_.emplace_back([this] { lane(); });
     }
-    // a buffer of BUF_BYTES, or nullptr (none free and the budget is spent, or no page-locked memory to be had)
+    // a buffer of BUF_BYTES, or nullptr (none free right now: the caller codes its piece itself).  Buffers are made
+    // by the lanes, a slab at a time, off the pool threads' path (page-locking 120 MB takes tens of milliseconds).
     uint8_t* take_buffer() {
-        {
-            std::lock_guard<std::mutex> g(m_);
-            if (failed_) return nullptr;
-            if (!free_.empty()) {
-                uint8_t* p = free_.back();
-                free_.pop_back();
-                return p;
-            }
-            if (made_ >= MAX_BUFS) return nullptr;
-            ++made_;
+        std::lock_guard<std::mutex> g(m_);
+        if (failed_ || free_.empty()) {
+            want_slab_ = !failed_ && made_ < MAX_BUFS;
+            if (want_slab_) cv_.notify_one();
+            return nullptr;
         }
-        uint8_t* p = qd_pinned_alloc ? (uint8_t*)qd_pinned_alloc((int64_t)BUF_BYTES) : nullptr;
-        if (!p) {
-            std::lock_guard<std::mutex> g(m_);
-            --made_;
+        uint8_t* p = free_.back();
+        free_.pop_back();
+        if (free_.size() < 8 && made_ < MAX_BUFS) {
+            want_slab_ = true;
+            cv_.notify_one();
         }
         return p;
     }
@@ -594,16 +591,24 @@ class DeflateService {
         const int64_t fail_after = fa && *fa ? atoll(fa) : -1;
         int64_t batches = 0;
         std::vector<uint8_t> out;
+        if (usable) add_slab();
         for (;;) {
             std::vector<DevPiece> b;
+            bool slab = false;
             {
                 std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [this] { return !q_.empty(); });
+                cv_.wait(g, [this] { return !q_.empty() || want_slab_; });
                 while (!q_.empty() && (int)b.size() < MAX_BATCH) {
                     b.push_back(q_.front());
                     q_.pop_front();
                 }
+                if (b.empty() && want_slab_) {
+                    want_slab_ = false;
+                    slab = usable;
+                }
             }
+            if (slab) add_slab();
+            if (b.empty()) continue;
             std::vector<const uint8_t*> tp(b.size());
             std::vector<int64_t> tl(b.size()), ml(b.size(), 0);
             std::vector<uint32_t> crc(b.size());
@@ -642,13 +647,28 @@ class DeflateService {
             }
         }
     }
+    void add_slab() {  // SLAB more page-locked buffers, cut from one allocation (kept for the life of the process)
+        {
+            std::lock_guard<std::mutex> g(m_);
+            if (made_ >= MAX_BUFS) return;
+            made_ += SLAB;
+        }
+        uint8_t* p = qd_pinned_alloc ? (uint8_t*)qd_pinned_alloc((int64_t)(BUF_BYTES * SLAB)) : nullptr;
+        std::lock_guard<std::mutex> g(m_);
+        if (!p) {
+            made_ = MAX_BUFS;  // no more page-locked memory to be had: work with what there is
+            return;
+        }
+        for (int i = 0; i < SLAB; ++i) free_.push_back(p + (size_t)i * BUF_BYTES);
+    }
+    static constexpr int SLAB = 48;
     int device_;
     std::mutex m_;
     std::condition_variable cv_;
     std::deque<DevPiece> q_;
     std::vector<uint8_t*> free_;
     int made_ = 0;
-    bool failed_ = false;
+    bool failed_ = false, want_slab_ = false;
     std::vector<std::thread> lanes_;
 };
 
@@ -703,6 +723,7 @@ int qd_sink_set_device_deflate(qd_sink* s, int32_t device_id) {
     if (!s) return QD_ERR_INVALID;
     if (device_id >= 0 && !(qd_deflater_create && qd_deflater_run && qd_huffman_member_bound && qd_pinned_alloc)) return QD_ERR_NO_DEVICE;
     s->deflate_device = device_id;
+    if (device_id >= 0 && s->level < 0) (void)deflate_service(device_id);  // its lanes come up (deflaters, first buffers) while the readers start
     return QD_OK;
 }
 
