@@ -527,14 +527,14 @@ def main():
             tj = json.load(fh)
         if tj.get("n_pairs") == n:
             traffic = tj.get("hbm_bytes_per_launch")
+            traffic_source = "profiles/%s (earlier rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \
+                             "replayed, not measured in this run)" % tj.get("source", os.path.basename(tfile))
             traffic_commit = tj.get("commit")  # the kernel sources the PMC passes were taken at (tools/stamp_traffic.py)
             if tj.get("kernel_source_sha16"):
                 import hashlib
                 with open(os.path.join(ROOT, "quade_amd", "csrc", "quade_kernels.hip"), "rb") as kf:
                     same = hashlib.sha256(kf.read()).hexdigest()[:16] == tj["kernel_source_sha16"]
                 traffic_source += "; kernel source %s since" % ("unchanged" if same else "CHANGED")
-            traffic_source = "profiles/%s (earlier rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \
-                             "replayed, not measured in this run)" % tj.get("source", os.path.basename(tfile))
 
     out = {
         "metric": "read-pairs/sec demultiplexed (2x150 bp, dual 8 bp index)",
