@@ -1538,7 +1538,11 @@ hipError_t launch_fast_t(const DemuxParams& p_launch, QdKernelCache& cache, int 
     } else if (queued) {
         grid = (int64_t)cus * occ_blocks;  // the resident set: every wave draws its runs from the queue
     } else if (table_lds > 24 * 1024) {
-        grid = (int64_t)cus * (occ_blocks < 2 ? occ_blocks : 2);
+        // two rounds of the resident set: of two workgroups that share a CU the older one wins the arbitration and ends
+        // early (profiles/r03_wg_times_cfg3_persistent2.txt); a second round fills the slots it leaves, and restaging a
+        // large image twice per slot is still cheap (cfg5, 512-thread workgroups: 2 / 3 / 4 / 6 / 8 per CU = 0.750 /
+        // 0.766 / 0.744 / 0.752 / 0.758 ms, profiles/r03_cfg5_launch_forms.txt)
+        grid = (int64_t)cus * (occ_blocks < 2 ? occ_blocks : 2) * (BLOCK <= 512 && occ_blocks >= 2 ? 2 : 1);
     } else {
         const int64_t fill = (int64_t)cus * occ_blocks;  // workgroups resident at once
         const int64_t lo = (int64_t)cus * (occ_blocks < 2 ? occ_blocks : 2), hi = (int64_t)cus * 64;
@@ -1632,8 +1636,9 @@ hipError_t qd_launch_fast(const DemuxParams& p, QdKernelCache& cache, int cus, i
     // 1024-thread workgroups measured 12 % slower than 512-thread ones in every grid form, profiles/r03_cfg3_launch_forms.txt)
     const bool big = lds_bytes > QD_FAST_BIG_LDS;
     const bool two_fit = 2 * (lds_bytes + strip_bytes_per_wave * 8) <= 158 * 1024;
+    // (without the queue too: 512-thread workgroups, two per CU, whenever two images fit)
     int block = block_override ? block_override
-                               : (big ? ((QD_WORK_QUEUE && p.wq && two_fit) ? 512 : 1024)
+                               : (big ? (two_fit ? 512 : 1024)
                                       : ((p.n <= QD_FAST_SMALL_BATCH || p.wide) ? 256 : QD_FAST_BLOCK));
     if (block == 1024) return launch_fast_b<1024>(p, cache, cus, wg_per_cu, lds_bytes, strip_bytes_per_wave, st);
     if (block == 256) return launch_fast_b<256>(p, cache, cus, wg_per_cu, lds_bytes, strip_bytes_per_wave, st);

@@ -161,6 +161,8 @@ def load_library(path=None):
     _preload_shared_hip_runtime()
     lib = C.CDLL(path)
     for name, restype, argtypes in SYMBOLS:
+        if not default and not hasattr(lib, name):
+            continue  # an explicitly given build (A/B variants of older sources in tools/tune.py) may predate an entry point
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = restype
         fn.argtypes = argtypes

@@ -47,7 +47,8 @@ with torch.cuda.stream(st):
                 e.set_option("fast_block", b)
                 for wg, wq in [(a, b) for a in wgs for b in wqs]:
                     e.set_option("fast_workgroups_per_cu", wg)
-                    e.set_option("work_queue", wq)
+                    if wq or len(wqs) > 1:  # (older builds given through TUNE_LIBS do not know the option)
+                        e.set_option("work_queue", wq)
                     for i in range(reps + 1):
                         a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         a.record(st)
