@@ -20,6 +20,9 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else default_n[cfg]
 blocks = [int(x) for x in os.environ.get("TUNE_BLOCKS", "0,256,512,1024").split(",")]
 wgs = [int(x) for x in os.environ.get("TUNE_WG", "0,4,16,64").split(",")]
 wqs = [int(x) for x in os.environ.get("TUNE_WQ", "0").split(",")]  # work_queue option: 0 automatic, 1 always, 2 never
+# TUNE_OPT="name:v1,v2": one more option dimension (set on builds that know it), e.g. keys_global:0,1
+xopt = os.environ.get("TUNE_OPT", "")
+xname, xvals = (xopt.split(":")[0], [int(v) for v in xopt.split(":")[1].split(",")]) if xopt else (None, [0])
 libs = [LIB_PATH] + [p for p in os.environ.get("TUNE_LIBS", "").split(",") if p]
 rounds, reps = int(os.environ.get("TUNE_ROUNDS", "3")), 4
 
@@ -45,8 +48,15 @@ with torch.cuda.stream(st):
         for lp, e in zip(libs, engines):
             for b in blocks:
                 e.set_option("fast_block", b)
-                for wg, wq in [(a, b) for a in wgs for b in wqs]:
+                for wg, wq, xv in [(a, b, c) for a in wgs for b in wqs for c in xvals]:
                     e.set_option("fast_workgroups_per_cu", wg)
+                    if xname:
+                        try:
+                            e.set_option(xname, xv)
+                        except Exception:
+                            if xv:
+                                continue  # this build does not know the option: only its default arm runs
+                    wq = wq * 10 + xv if xname else wq  # (shown in the wq column as <wq><value>)
                     if wq or len(wqs) > 1:  # (older builds given through TUNE_LIBS do not know the option)
                         e.set_option("work_queue", wq)
                     for i in range(reps + 1):
