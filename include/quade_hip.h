@@ -357,7 +357,7 @@ const char* qd_reader_last_error(const qd_reader* reader); /* reader == NULL: wh
  *   "parallel_gunzip"        1 (default) / 0 = one thread per file (libdeflate per member, streaming zlib beyond 32 MB)
  *   "gunzip_chunk_bytes"     compressed bytes per chunk (default 4 MiB, at least 64 KiB)
  *   "gunzip_min_file_bytes"  smaller files are inflated by one thread (default 8 MiB)
- *   "gunzip_in_flight"       chunks in flight per file, 0 (default) = one per pool thread */
+ *   "gunzip_in_flight"       chunks in flight per file, 0 (default) = half the pool's threads, at least 4 */
 int qd_io_set_option(const char* name, int64_t value);
 /* Chunks of this reader's file that were inflated speculatively and proven / inflated by the coordinator itself. */
 int qd_reader_gunzip_stats(const qd_reader* reader, int64_t* parallel_chunks, int64_t* serial_chunks);

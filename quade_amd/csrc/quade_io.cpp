@@ -334,9 +334,9 @@ class Pool {
         {
             std::lock_guard<std::mutex> g(m_);
             if (urgent)
-                q_.push_front(std::move(fn));  // inflate jobs: everything downstream waits for their text
-            else
-                q_.push_back(std::move(fn));
+                uq_.push_back(std::move(fn));  // inflate jobs: everything downstream waits for their text.  Ahead of the
+            else                               // other work, but in order among themselves: a reader collects its chunks
+                q_.push_back(std::move(fn));   // oldest first, and a newest-first queue starved exactly the one it waited for
         }
         cv_.notify_one();
     }
@@ -348,16 +348,17 @@ class Pool {
             std::function<void()> fn;
             {
                 std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [this] { return stop_ || !q_.empty(); });
-                if (q_.empty()) return;  // stop_ and drained
-                fn = std::move(q_.front());
-                q_.pop_front();
+                cv_.wait(g, [this] { return stop_ || !q_.empty() || !uq_.empty(); });
+                if (q_.empty() && uq_.empty()) return;  // stop_ and drained
+                std::deque<std::function<void()>>& from = uq_.empty() ? q_ : uq_;
+                fn = std::move(from.front());
+                from.pop_front();
             }
             fn();
         }
     }
     std::vector<std::thread> threads_;
-    std::deque<std::function<void()>> q_;
+    std::deque<std::function<void()>> q_, uq_;  // ordinary jobs; urgent ones (served first, first in first out)
     std::mutex m_;
     std::condition_variable cv_;
     bool stop_ = false;
@@ -1528,13 +1529,13 @@ bool inflate_bgzf(qd_reader* r, Input& in, int& cur, bool& ok) {
 std::atomic<int64_t> g_pgz_enabled{1};
 std::atomic<int64_t> g_pgz_chunk_bytes{4 << 20};
 std::atomic<int64_t> g_pgz_min_file_bytes{8 << 20};  // smaller files: one thread is done before a second could help
-std::atomic<int64_t> g_pgz_in_flight{0};             // 0 = one chunk per pool thread
+std::atomic<int64_t> g_pgz_in_flight{0};             // 0 = half the pool's threads (at least 4) per file
 
 qdpgz::Options pgz_options() {
     qdpgz::Options o;
     o.chunk_bytes = (size_t)std::max<int64_t>(g_pgz_chunk_bytes.load(), 64 << 10);
     const int64_t f = g_pgz_in_flight.load();
-    o.in_flight = f > 0 ? (int)f : std::max(4, pool().size());
+    o.in_flight = f > 0 ? (int)f : std::max(4, pool().size() / 2);  // (5, 8 and 16 per file read the same end to end: profiles/r03_e2e_16m_single_*)
     return o;
 }
 
