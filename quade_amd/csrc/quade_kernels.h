@@ -37,6 +37,9 @@
 #ifndef QD_GENERIC_SPECIAL
 #define QD_GENERIC_SPECIAL 1 /* full-length batches on the generic path run its specialised forms (A/B: 0 = the catch-all) */
 #endif
+#ifndef QD_GENERIC_ALIGNED
+#define QD_GENERIC_ALIGNED 1 /* the specialised generic forms load 4- / 8-byte aligned slices without shifts (A/B: 0)       */
+#endif
 #ifndef QD_STRIPS_LDS_BUDGET
 #define QD_STRIPS_LDS_BUDGET 0 /* A/B: LDS a CU may spend on two workgroups incl. their code strips (0: small tables only) */
 #endif

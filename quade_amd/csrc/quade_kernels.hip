@@ -1304,7 +1304,37 @@ __device__ __forceinline__ uint32_t generic_pair(const DemuxParams& p, int64_t r
 // arrays have the size the plan needs (a 16-byte key is two words, not four), the slice widths are wave-uniform (no
 // per-lane clamping), and the stream loop has a constant bound -- the catch-all keeps ~160 scalars alive and spills
 // them through VGPR lanes (158 SGPR spills, 942 VALU per pair).
-template <int NS, int KW, int MWORDS>
+// A slice whose address is a multiple of ALIGN (4 or 8) for EVERY pair of the launch -- every stride and offset of the
+// plan is: no shift, no spare word, and 8-byte loads where the plan allows them (the one-pair-per-lane kernels are bound
+// by the number of vector memory instructions: three dword loads per 8-byte slice, each using half of the lines it
+// touches, against one).  nbytes (wave-uniform) <= 8 * NW; bytes beyond it read as zero.
+template <int NW, int ALIGN>
+__device__ __forceinline__ void load_aligned(const uint8_t* p, int nbytes, u64 (&w)[NW]) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int left = nbytes - 8 * i;  // wanted bytes of this word
+        u64 v = 0;
+        if (left > 0) {
+            if (ALIGN >= 8) {
+                v = *reinterpret_cast<const u64*>(p + 8 * i);  // (may read up to 7 bytes behind the slice, inside its aligned word)
+            } else {
+                v = *reinterpret_cast<const uint32_t*>(p + 8 * i);
+                if (left > 4) v |= (u64) * reinterpret_cast<const uint32_t*>(p + 8 * i + 4) << 32;
+            }
+            if (left < 8) v &= (1ull << (8 * left)) - 1;
+        }
+        w[i] = v;
+    }
+}
+template <int NW, int ALIGN>
+__device__ __forceinline__ void load_slice(const uint8_t* p, int nbytes, u64 (&w)[NW]) {
+    if (ALIGN >= 4)
+        load_aligned<NW, ALIGN>(p, nbytes, w);
+    else
+        load_bytes<NW>(p, nbytes, nbytes, w);
+}
+
+template <int NS, int KW, int MWORDS, int ALIGN>
 __device__ __forceinline__ uint32_t special_pair(const DemuxParams& p, int64_t r) {
     u64 w[KW];
 #pragma unroll
@@ -1315,8 +1345,8 @@ __device__ __forceinline__ uint32_t special_pair(const DemuxParams& p, int64_t r
     for (int k = 0; k < NS; ++k) {
         const int iw = p.idx_w[k];
         u64 v[KW], qv[KW];
-        load_bytes<KW>(p.seq[k] + r * p.seq_stride[k] + p.idx_off[k], iw, iw, v);
-        load_bytes<KW>(p.qual[k] + r * p.qual_stride[k], iw, iw, qv);
+        load_slice<KW, ALIGN>(p.seq[k] + r * p.seq_stride[k] + p.idx_off[k], iw, v);
+        load_slice<KW, ALIGN>(p.qual[k] + r * p.qual_stride[k], iw, qv);
 #pragma unroll
         for (int i = 0; i < KW; ++i) {
             v[i] = qd_fold8(v[i]);                                                    // a3
@@ -1363,7 +1393,7 @@ __device__ __forceinline__ uint32_t special_pair(const DemuxParams& p, int64_t r
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             u64 v[MW_];
-            load_bytes<MW_>(p.seq[k] + r * p.seq_stride[k] + p.mol_off[k], p.mol_w[k], p.mol_w[k], v);
+            load_slice<MW_, ALIGN>(p.seq[k] + r * p.seq_stride[k] + p.mol_off[k], p.mol_w[k], v);
             or_shifted<MW_>(m, v, mat);
             mat += p.mol_w[k];
         }
@@ -1381,7 +1411,7 @@ __device__ __forceinline__ uint32_t special_pair(const DemuxParams& p, int64_t r
     return code;
 }
 
-template <int NS, int KW, int MWORDS>
+template <int NS, int KW, int MWORDS, int ALIGN>
 __global__ __launch_bounds__(QD_GEN_BLOCK) void demux_special(const DemuxParams p, uint32_t hist_entries) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw);
@@ -1392,7 +1422,7 @@ __global__ __launch_bounds__(QD_GEN_BLOCK) void demux_special(const DemuxParams 
     if (hist_entries) __syncthreads();
     uint32_t undet = 0;
     for (int64_t r = (int64_t)blockIdx.x * QD_GEN_BLOCK + threadIdx.x; r < p.n; r += stride) {
-        const uint32_t code = special_pair<NS, KW, MWORDS>(p, r);
+        const uint32_t code = special_pair<NS, KW, MWORDS, ALIGN>(p, r);
         if (code == QD_CODE_UNDET)
             ++undet;
         else if (hist_entries)
@@ -1646,11 +1676,28 @@ hipError_t qd_launch_fast(const DemuxParams& p, QdKernelCache& cache, int cus, i
 }
 
 namespace {
+template <int NS, int KW, int ALIGN>
+void launch_special_a(const DemuxParams& p, int grid, size_t lds, uint32_t entries, hipStream_t st) {
+    if (p.M == 0) hipLaunchKernelGGL((demux_special<NS, KW, 0, ALIGN>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
+    else if (p.M <= 16) hipLaunchKernelGGL((demux_special<NS, KW, 2, ALIGN>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
+    else hipLaunchKernelGGL((demux_special<NS, KW, 4, ALIGN>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
+}
+// what every slice address of the launch is a multiple of: 8, 4 or nothing in particular (row arrays are 16-byte aligned)
+int slice_alignment(const DemuxParams& p) {
+    int a = 8;
+    for (int k = 0; k < p.n_streams; ++k) {
+        const int v[5] = {p.seq_stride[k], p.qual_stride[k], p.idx_w[k] ? p.idx_off[k] : 0, p.mol_w[k] ? p.mol_off[k] : 0, 0};
+        for (int x : v)
+            while (a > 1 && x % a) a >>= 1;
+    }
+    return a >= 4 ? a : 1;
+}
 template <int NS, int KW>
 void launch_special_m(const DemuxParams& p, int grid, size_t lds, uint32_t entries, hipStream_t st) {
-    if (p.M == 0) hipLaunchKernelGGL((demux_special<NS, KW, 0>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
-    else if (p.M <= 16) hipLaunchKernelGGL((demux_special<NS, KW, 2>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
-    else hipLaunchKernelGGL((demux_special<NS, KW, 4>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
+    const int a = QD_GENERIC_ALIGNED ? slice_alignment(p) : 1;
+    if (a == 8) launch_special_a<NS, KW, 8>(p, grid, lds, entries, st);
+    else if (a == 4) launch_special_a<NS, KW, 4>(p, grid, lds, entries, st);
+    else launch_special_a<NS, KW, 1>(p, grid, lds, entries, st);
 }
 }  // namespace
 
