@@ -1580,10 +1580,11 @@ hipError_t launch_fast_t(const DemuxParams& p_launch, QdKernelCache& cache, int 
         // (a batch that fills the device about once must not leave one workgroup with an extra super-tile)
         constexpr int64_t R = OPS::RUNS > 0 ? OPS::RUNS : 1;
         const int64_t nunits = ntiles / R > 0 ? ntiles / R : 1;
-        // about 8 tiles per workgroup; 16 with more than 128 samples: every workgroup ends with one atomic per
-        // non-zero counter, and with a few hundred samples twice as many workgroups put ~0.3 % more bytes on
-        // the fabric for no time gained (profiles/r02_cfg4_grid_with_runs.txt: 3840 .. 7680 workgroups within 0.7 %)
-        int64_t per = (p.n_samples > 128 ? 16 : 8) / R;
+        // about 8 tiles per workgroup
+        // (r02 gave tables of more than 128 samples 16 tiles per workgroup to halve the flush; with r03's cfg4 form -- run
+        // strips, single buffer -- 8 is 2 % faster: 24 / 32 workgroups per CU 0.6591 / 0.6578 ms against 14 per CU 0.6710,
+        // profiles/r03_cfg4_grid_r03_form.txt)
+        int64_t per = 8 / R;
         if (per < 1) per = 1;
         if ((nunits + per - 1) / per > hi) per = (nunits + hi - 1) / hi;
         while (per > 1 && (nunits + per - 1) / per < lo) --per;
