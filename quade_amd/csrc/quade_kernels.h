@@ -47,7 +47,7 @@
 #define QD_SLOT_FACTOR 4 /* open-addressing slots per barcode, before rounding up to a power of two (load <= 1/4) */
 #endif
 #ifndef QD_STATIC80_ALWAYS
-#define QD_STATIC80_ALWAYS 0 /* A/B: the static 8+0 shape for small tables too                              */
+#define QD_STATIC80_ALWAYS 1 /* the static 8+0 shape for small tables too (0: large tables only, r02's choice)     */
 #endif
 #ifndef QD_FAST_CODE_STRIPS
 #define QD_FAST_CODE_STRIPS 1 /* with runs: codes leave through the wave's LDS strip, 16 B per lane          */

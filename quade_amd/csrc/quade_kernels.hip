@@ -1620,9 +1620,11 @@ hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, in
                       (!dual || (p.seq_stride[1] == 8 && p.qual_stride[1] == 8));
     if (all8) {
 #ifndef QD_NO_STATIC_SHAPES
-        // dual 8 + 8 bp index, no molecular index (BASELINE cfg3, cfg5): measured +2.6 % for the large-table
-        // launch form (cfg5), -1.4 % for the small-table one (cfg3) -> used where it pays
-        // (profiles/r02_static_vs_dynamic_shape_cfg{3,5}.txt)
+        // dual 8 + 8 bp index, no molecular index (BASELINE cfg3, cfg5): r02 measured +2.6 % for the large-table launch
+        // form (cfg5) and -1.4 % for the small-table one (cfg3) and used it for large tables only
+        // (profiles/r02_static_vs_dynamic_shape_cfg{3,5}.txt); since r03 the dynamic-shape kernel carries more
+        // parameters (128 VGPRs, 76 SGPR spills) and the static one wins on cfg3 too: 0.5444 vs 0.5505 ms, r02's library
+        // 0.5487 (profiles/r03_cfg3_static80_triple_buffer.txt; a third register tile on top of it: 0.5475, not kept)
         if (StaticShape<8, 0>::matches(p) && (table_lds > 24 * 1024 || QD_STATIC80_ALWAYS))
             return launch_fast_t<Rows8<BLOCK, true, U, StaticShape<8, 0>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
 #endif
