@@ -533,6 +533,28 @@ struct StaticShape {
     }
 };
 
+template <int IW>  // single index read, IW-base barcode at column 0, no molecular index, 8-byte rows (BASELINE cfg2: IW = 8)
+struct StaticSingle {
+    static constexpr bool STATIC = true;
+    static constexpr int MOLW = 0;
+    static_assert(IW >= 1 && IW <= 8, "single static shapes: 8-byte rows");
+    static __device__ __forceinline__ void apply(DemuxParams& p) {
+        p.n_streams = 1;
+        p.K = IW;
+        p.M = 0;
+        p.seq_stride[0] = p.qual_stride[0] = 8;
+        p.idx_off[0] = 0;
+        p.idx_w[0] = IW;
+        p.mol_off[0] = p.mol_w[0] = 0;
+        p.idx_mask[0] = IW >= 8 ? ~0ull : ((1ull << (8 * IW)) - 1);
+        p.mol_mask[0] = 0;
+    }
+    static bool matches(const DemuxParams& p) {
+        return p.n_streams == 1 && p.K == IW && p.M == 0 && p.seq_stride[0] == 8 && p.qual_stride[0] == 8 && p.idx_off[0] == 0 &&
+               p.idx_w[0] == IW && p.mol_w[0] == 0;
+    }
+};
+
 // ---- Rows8: all strides 8 ------------------------------------------------------------------------
 template <int BLOCK_, bool DUAL, int UNITS, class SH = DynShape>
 struct Rows8 {
@@ -1630,6 +1652,10 @@ hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, in
 #endif
         if (dual) return launch_fast_t<Rows8<BLOCK, true, U>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
 #ifndef QD_SWEEP_BUILD  // tuning builds instantiate the dual 8+8 kernel only
+#ifndef QD_NO_STATIC_SHAPES
+        if (StaticSingle<8>::matches(p))  // single 8 bp index (BASELINE cfg2)
+            return launch_fast_t<Rows8<BLOCK, false, U, StaticSingle<8>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+#endif
         return launch_fast_t<Rows8<BLOCK, false, U>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
 #endif
     }
