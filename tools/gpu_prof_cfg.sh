@@ -14,7 +14,9 @@ echo "[prof $C] bench"
 python bench.py --config $C --no-cpu-baseline --no-extras > $D/bench.json 2> $D/bench.err || { tail -5 $D/bench.err; exit 1; }
 echo "[prof $C] kernel trace"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$C/trace -- $BENCH > $D/trace.log 2>&1 || tail -5 $D/trace.log
-for f in $(find /tmp/prof_$C/trace -name "*_kernel_stats.csv" -o -name "*_kernel_trace.csv"); do cp $f $D/; done
+# fixed names: rocprofv3 prefixes its files with the process id, which repeats from box to box, and merged sessions piled up
+for f in $(find /tmp/prof_$C/trace -name "*_kernel_stats.csv"); do cp $f $D/run_kernel_stats.csv; done
+for f in $(find /tmp/prof_$C/trace -name "*_kernel_trace.csv"); do cp $f $D/run_kernel_trace.csv; done
 for ctr in FETCH_SIZE WRITE_SIZE; do
   echo "[prof $C] pmc $ctr"
   timeout -k 10 200 rocprofv3 --pmc $ctr --output-format csv -d /tmp/prof_$C/pmc_$ctr -- python3 tools/pmc_run.py $C 6 > $D/pmc_$ctr.log 2>&1 || tail -5 $D/pmc_$ctr.log

@@ -31,7 +31,7 @@ samples, stop = [], False
 def watch():
     while not stop:
         try:
-            out = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--csv"], capture_output=True, text=True, timeout=10).stdout
+            out = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showtemp", "--csv"], capture_output=True, text=True, timeout=10).stdout
             samples.append(out.strip().split("\n")[-1])
         except Exception as ex:
             samples.append("rocm-smi failed: %r" % ex)
@@ -42,16 +42,21 @@ def watch():
 th = threading.Thread(target=watch)
 th.start()
 t0, k = time.time(), 0
+rates = []  # (seconds since start, ms per launch of this group of 50)
 while time.time() - t0 < secs:
+    g0 = time.time()
     for _ in range(50):
         e.demux_device(n, [t.data_ptr() for t in w.seq], [t.data_ptr() for t in w.qual], codes.data_ptr(), mol.data_ptr() if M else None)
     e.synchronize()
     k += 50
+    rates.append((time.time() - t0, (time.time() - g0) / 50 * 1e3))
 dt = time.time() - t0
 stop = True
 th.join()
 print("%s work_queue=%d: %d launches in %.2f s = %.4f ms per launch" % (cfg, wq, k, dt, dt / k * 1e3))
-hdr = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--csv"], capture_output=True, text=True).stdout.strip().split("\n")
+step = max(1, len(rates) // 24)
+print("ms per launch over time (s: ms):", "  ".join("%.1f: %.4f" % r for r in rates[::step]))
+hdr = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showtemp", "--csv"], capture_output=True, text=True).stdout.strip().split("\n")
 print(hdr[0] if hdr else "")
-for sline in samples[:3] + samples[-6:]:
+for sline in samples[::max(1, len(samples) // 16)]:
     print(sline)

@@ -25,6 +25,7 @@ xopt = os.environ.get("TUNE_OPT", "")
 xname, xvals = (xopt.split(":")[0], [int(v) for v in xopt.split(":")[1].split(",")]) if xopt else (None, [0])
 libs = [LIB_PATH] + [p for p in os.environ.get("TUNE_LIBS", "").split(",") if p]
 rounds, reps = int(os.environ.get("TUNE_ROUNDS", "3")), 4
+burst = int(os.environ.get("TUNE_BURST", "1"))  # launches per timed sample, back to back (1: every launch timed alone)
 
 engines, loads = [], {}
 for lp in libs:
@@ -63,12 +64,13 @@ with torch.cuda.stream(st):
                         a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         a.record(st)
                         w = e.workload
-                        e.demux_device(n, [t.data_ptr() for t in w.seq], [t.data_ptr() for t in w.qual],
-                                       codes.data_ptr(), mol.data_ptr() if M else None, stream=st.cuda_stream)
+                        for _ in range(burst):
+                            e.demux_device(n, [t.data_ptr() for t in w.seq], [t.data_ptr() for t in w.qual],
+                                           codes.data_ptr(), mol.data_ptr() if M else None, stream=st.cuda_stream)
                         z.record(st)
                         z.synchronize()
                         if i:
-                            res.setdefault((os.path.basename(lp), b, wg, wq), []).append(a.elapsed_time(z))
+                            res.setdefault((os.path.basename(lp), b, wg, wq), []).append(a.elapsed_time(z) / burst)
                     assert torch.equal(codes.view(torch.int16).to(torch.int32) & 0xFFFF, w.expected) or os.environ.get("TUNE_NOCHECK")
                     if M and not os.environ.get("TUNE_NOCHECK"):  # molecular bytes: the columns behind the barcode in both index reads
                         iw, L = synth.CONFIGS[cfg].get("iw", 8), synth.CONFIGS[cfg]["read_len"]
