@@ -28,8 +28,11 @@ def cpu():
     return r.ru_utime + r.ru_stime
 
 
+DEV = int(os.environ.get("READER_DEVICE_INFLATE", "-1"))  # >= 0: BGZF runs are inflated on that GPU (qd_reader_open_on)
+
+
 def read_all(path, res, i):
-    st = FastqStream(path, 250_000)
+    st = FastqStream(path, 250_000, inflate_device=DEV)
     nb, t0 = 0, time.perf_counter()
     while True:
         b = st.take()
@@ -44,7 +47,7 @@ def read_all(path, res, i):
 
 try:
     print("usable cores", host_cores(), "io pool", io_threads(), "pairs", n, "gzip level", level)
-    for fmt, member in (("BGZF", "bgzf"), ("one member", 0), ("8 MB members", 8 << 20)):
+    for fmt, member in ((("BGZF", "bgzf"),) if os.environ.get("READER_ONLY_BGZF") else (("BGZF", "bgzf"), ("one member", 0), ("8 MB members", 8 << 20))):
         d = os.path.join(work, fmt.replace(" ", "_"))
         os.mkdir(d)
         paths, _ = synth.write_fastq_dataset(d, n, gz_level=level, member_bytes=member)
