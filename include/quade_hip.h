@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 3
+#define QD_ABI_VERSION 4
 
 #define QD_OK 0
 #define QD_ERR_INVALID (-1)     /* bad argument (NULL pointer, misaligned buffer, size out of range)   */
@@ -407,12 +407,18 @@ int qd_reader_inflate_stats(const qd_reader* reader, int64_t* device_runs, int64
  * member_len[i]; member_len[i] == 0: that member did not fit out_stride (make it on the host).  Blocking.
  * qd_sink_set_device_deflate: the sink's Huffman-only members are made on `device_id` while the process has
  * page-locked buffers to spare (192 x 2.5 MB); a piece that finds none is coded on its pool thread as before, so the
- * host and the device share the work; device_id < 0: host only (the default).  Only gzip_level -1 is affected. */
+ * host and the device share the work; device_id < 0: host only (the default).  gzip_level -1 and 1 are affected (the levels
+ * the device implements, qd_deflater_set_level); sinks at other levels ignore the device. */
 typedef struct qd_deflater qd_deflater;
 int qd_deflater_create(int device_id, qd_deflater** out);
 int qd_deflater_run(qd_deflater* deflater, int32_t n_pieces, const uint8_t* const* text, const int64_t* text_len,
                     const uint32_t* crc32, int32_t text_pinned, uint8_t* out, int64_t out_stride, int64_t* member_len);
 int64_t qd_huffman_member_bound(int64_t text_len);
+/* ABI v4.  Which members the deflater makes: -1 (the default) = Huffman only, as above; 1 = LZ77 + dynamic Huffman, the
+ * driver's `gzip_level : 1` (greedy parse, 4-byte hash of last positions + runs, 32 KiB window; the piece is coded as 64 KiB
+ * dynamic-Huffman blocks joined by empty stored blocks in ONE member).  Same slots, same bound, same fallback rule
+ * (member_len 0); other levels stay with the host's libdeflate / zlib: QD_ERR_INVALID. */
+int qd_deflater_set_level(qd_deflater* deflater, int32_t level);
 int qd_deflater_destroy(qd_deflater* deflater);
 const char* qd_deflater_last_error(const qd_deflater* deflater);
 int qd_sink_set_device_deflate(qd_sink* sink, int32_t device_id);

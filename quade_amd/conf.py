@@ -26,9 +26,9 @@ Optional [gpu] section (not in Quade 0.3.2; a conf file without it runs with the
                          speed of level 1, files ~25 % larger on real data)
   chunk_workers : 1      chunks processed concurrently by host threads (outputs identical)
   io_threads : 0         threads of the native gunzip / gzip pool (0 = one per core)
-  device_deflate : True  with gzip_level -1: the output members are made on the GPU (one workgroup per ~2 MB piece of
-                         formatted text) while page-locked buffers last, on the host's pool otherwise (+24 % end to end
-                         on a 16-core host); no effect at the other levels
+  device_deflate : True  with gzip_level -1 or 1: the output members are made on the GPU (-1: one workgroup per ~2 MB piece of
+                         formatted text, Huffman coding only; 1: LZ77 + Huffman, one workgroup per 64 KiB of it) while
+                         page-locked buffers last, on the host's pool otherwise; no effect at the other levels
   device_inflate : False BGZF (bgzip) input files are inflated on the GPU, one block per wave (default: on host threads --
                          on a 16-core host both ways run at the same rate; the GPU way uses 5-10 % less CPU)
 """

@@ -1279,6 +1279,14 @@ struct qd_deflater {
     qd_deflate_piece *h_pc = nullptr, *d_pc = nullptr;
     uint32_t *h_len = nullptr, *d_len = nullptr;
     size_t cap_pc = 0, cap_len = 0;
+    // level 1 (LZ77 + dynamic Huffman, quade_deflate.hip): sub-block table, piece -> first sub-block, device scratch
+    int level = -1;
+    qd_lz_sub *h_sub = nullptr, *d_sub = nullptr;
+    uint32_t *h_first = nullptr, *d_first = nullptr;
+    size_t cap_sub = 0, cap_first = 0;
+    uint32_t *d_tokens = nullptr, *d_sub_bytes = nullptr;
+    uint8_t* d_sub_out = nullptr;
+    size_t cap_scratch = 0;  // sub-blocks the three scratch arrays hold
 };
 
 namespace {
@@ -1337,7 +1345,20 @@ int qd_deflater_destroy(qd_deflater* f) {
     if (f->d_pc) (void)hipFree(f->d_pc);
     if (f->h_len) (void)hipHostFree(f->h_len);
     if (f->d_len) (void)hipFree(f->d_len);
+    if (f->h_sub) (void)hipHostFree(f->h_sub);
+    if (f->d_sub) (void)hipFree(f->d_sub);
+    if (f->h_first) (void)hipHostFree(f->h_first);
+    if (f->d_first) (void)hipFree(f->d_first);
+    if (f->d_tokens) (void)hipFree(f->d_tokens);
+    if (f->d_sub_bytes) (void)hipFree(f->d_sub_bytes);
+    if (f->d_sub_out) (void)hipFree(f->d_sub_out);
     delete f;
+    return QD_OK;
+}
+
+int qd_deflater_set_level(qd_deflater* f, int32_t level) {
+    if (!f || (level != -1 && level != 1)) return def_fail(f, QD_ERR_INVALID, "the device makes members at gzip_level -1 (Huffman only) and 1 (LZ77 + Huffman)");
+    f->level = level;
     return QD_OK;
 }
 
@@ -1379,7 +1400,40 @@ int qd_deflater_run(qd_deflater* f, int32_t n_pieces, const uint8_t* const* text
         at += ((size_t)text_len[i] + 15) & ~(size_t)15;
     }
     DEFCHK(f, hipMemcpyAsync(f->d_pc, f->h_pc, (size_t)n_pieces * sizeof(qd_deflate_piece), hipMemcpyHostToDevice, f->stream));
-    DEFCHK(f, qd_launch_huffman(f->d_text, f->d_pc, (uint32_t)n_pieces, f->d_out, out_stride, f->d_len, f->stream));
+    if (f->level == 1) {  // LZ77 + dynamic Huffman: one workgroup per 64 KiB sub-block, then the members are strung together
+        size_t n_subs = 0;
+        for (int i = 0; i < n_pieces; ++i) n_subs += ((size_t)text_len[i] + QD_LZ_SUB - 1) / QD_LZ_SUB;
+        const int64_t sub_stride = qd_huffman_member_bound(QD_LZ_SUB);
+        DEFCHK(f, grow_pair(f->h_sub, f->d_sub, f->cap_sub, n_subs + 1));
+        DEFCHK(f, grow_pair(f->h_first, f->d_first, f->cap_first, (size_t)n_pieces + 1));
+        if (n_subs > f->cap_scratch) {
+            if (f->d_tokens) (void)hipFree(f->d_tokens);
+            if (f->d_sub_bytes) (void)hipFree(f->d_sub_bytes);
+            if (f->d_sub_out) (void)hipFree(f->d_sub_out);
+            f->d_tokens = f->d_sub_bytes = nullptr;
+            f->d_sub_out = nullptr;
+            f->cap_scratch = 0;
+            const size_t n = n_subs + n_subs / 4 + 16;
+            DEFCHK(f, hipMalloc((void**)&f->d_tokens, n * (size_t)QD_LZ_SUB * 4));
+            DEFCHK(f, hipMalloc((void**)&f->d_sub_bytes, n * 4));
+            DEFCHK(f, hipMalloc((void**)&f->d_sub_out, n * (size_t)sub_stride));
+            f->cap_scratch = n;
+        }
+        size_t js = 0, off = 0;
+        for (int i = 0; i < n_pieces; ++i) {
+            f->h_first[i] = (uint32_t)js;
+            for (int64_t a = 0; a < text_len[i]; a += QD_LZ_SUB)
+                f->h_sub[js++] = qd_lz_sub{(uint64_t)(off + (size_t)a), (uint32_t)std::min<int64_t>(QD_LZ_SUB, text_len[i] - a), (uint32_t)i};
+            off += ((size_t)text_len[i] + 15) & ~(size_t)15;
+        }
+        f->h_first[n_pieces] = (uint32_t)js;
+        if (js) DEFCHK(f, hipMemcpyAsync(f->d_sub, f->h_sub, js * sizeof(qd_lz_sub), hipMemcpyHostToDevice, f->stream));
+        DEFCHK(f, hipMemcpyAsync(f->d_first, f->h_first, ((size_t)n_pieces + 1) * 4, hipMemcpyHostToDevice, f->stream));
+        DEFCHK(f, qd_launch_lz(f->d_text, f->d_pc, (uint32_t)n_pieces, f->d_sub, f->d_first, (uint32_t)js, f->d_tokens, f->d_sub_out, sub_stride,
+                               f->d_sub_bytes, f->d_out, out_stride, f->d_len, f->stream));
+    } else {
+        DEFCHK(f, qd_launch_huffman(f->d_text, f->d_pc, (uint32_t)n_pieces, f->d_out, out_stride, f->d_len, f->stream));
+    }
     DEFCHK(f, hipMemcpyAsync(f->h_len, f->d_len, (size_t)n_pieces * 4, hipMemcpyDeviceToHost, f->stream));
     DEFCHK(f, hipEventRecord(f->done, f->stream));
     DEFCHK(f, hipEventSynchronize(f->done));

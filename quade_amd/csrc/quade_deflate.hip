@@ -27,14 +27,14 @@ constexpr uint32_t HEADER_BITS = 80 + 3 + 14 + 19 * 3 + 259 * 4;  // gzip header
 
 __device__ uint32_t rev_bits(uint32_t v, int n) { return __brev(v) >> (32 - n); }
 
-// lengths (<= 15) of a Huffman code for the used ones of 257 symbols; same construction as huffman_lengths()
-__device__ void code_lengths(const uint32_t* freq, uint8_t* len, uint16_t* order /*257*/, uint32_t* w /*513*/, int16_t* parent /*513*/) {
+// lengths (<= 15) of a Huffman code for the used ones of n symbols; same construction as huffman_lengths()
+__device__ void code_lengths(const uint32_t* freq, int n, uint8_t* len, uint16_t* order /*n*/, uint32_t* w /*2n*/, int16_t* parent /*2n*/) {
     int m = 0;
-    for (int s = 0; s < 257; ++s) {
+    for (int s = 0; s < n; ++s) {
         len[s] = 0;
         if (freq[s]) order[m++] = (uint16_t)s;
     }
-    for (int s = 0; m < 2 && s < 257; ++s) {
+    for (int s = 0; m < 2 && s < n; ++s) {
         bool used = false;
         for (int i = 0; i < m; ++i) used |= order[i] == s;
         if (!used) order[m++] = (uint16_t)s;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(BLOCK) void huff_pieces(const uint8_t* text, const 
     __syncthreads();
     // 2. the code
     if (tid == 0) {
-        code_lengths(freq, len, order, wtmp, parent);
+        code_lengths(freq, 257, len, order, wtmp, parent);
         int blc[16] = {0}, nxt[16] = {0};
         for (int s = 0; s < 257; ++s) ++blc[len[s]];
         blc[0] = 0;
@@ -266,5 +266,490 @@ hipError_t qd_launch_huffman(const uint8_t* text, const qd_deflate_piece* pieces
                              uint32_t* out_bytes, hipStream_t st) {
     if (n_pieces == 0) return hipSuccess;
     hipLaunchKernelGGL(huff_pieces, dim3(n_pieces), dim3(BLOCK), 0, st, text, pieces, out, out_stride, out_bytes);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// LZ77 + dynamic Huffman on the device: gzip members for the driver's `gzip_level : 1` and above (r03).  What it replaces is
+// the same seam (src/FastqWriter.py:83-90: gzip members appended to the destination files), at the levels where matching
+// earns its keep on fastq text: the read names (a record's name repeats most of its predecessor's) and the quality lines
+// (runs, and stretches shared with earlier lines).
+//
+// A piece (~2 MB of formatted records) is cut into sub-blocks of 64 KiB; ONE WAVE per sub-block (a workgroup of 64 lanes:
+// the parse is sequential in the text, and what a wave does for it in parallel is a stretch of 64 positions) makes one
+// dynamic-Huffman block that ends on a byte boundary (an empty stored block behind it, as pigz joins the work of its
+// threads); a second kernel strings a piece's sub-blocks together behind the gzip header and closes the member with an
+// empty final block, CRC-32 (made on the host) and ISIZE.
+//
+//  1. the sub-block's text is staged in LDS and walked 64 positions at a time.  Candidates: each lane hashes the 4 bytes
+//     at its position into a table of 4 096 buckets x the 4 last positions with that hash (16 bit each; an entry is only
+//     a guess), compares each candidate with its own next 32 bytes, keeps the longest (the nearest on a tie), tries
+//     distance 1 (runs) if none matched, and enters its own position.  A match that covers only bases (ACGTN: literals of
+//     ~2 bits) must be 12 bytes long to be taken, any other 4 -- short matches inside the sequence lines cost more than
+//     their literals (tools/lz_model.cpp: 31.8 % -> 27.3 % of the text on binned-quality records).
+//  2. the parse is a scalar walk over the 64 positions: a position with a match is deferred by one literal when its
+//     successor's match is longer (lazy evaluation on the lanes' 32-byte views); a 32-byte match is extended by all 64
+//     lanes comparing 4 bytes each (256 bytes in one step: ballot + count of trailing zeros = the length); the walk jumps
+//     behind the match; positions without a match are literals and are skipped in one step up to the next candidate.
+//     Tokens (literal | length, distance) go to a scratch array in text order, their symbols into two LDS histograms.
+//  3. the two length-limited codes: symbols ranked by (count, symbol) by all lanes, the two-queue merge and the Kraft repair
+//     of the Huffman-only kernel by one; the header carries the code lengths as plain 4-bit numbers.
+//  4. 64 tokens per step are coded in parallel: bits and bit count per lane, wave scan, OR into an LDS word buffer, whole
+//     words leave coalesced.
+// Against zlib on 2 MB of fastq text (tools/lz_model.cpp, the sizes the device's members have: tests/test_gpu_deflate.py):
+// binned qualities 19.5 % of the text (zlib level 1: 22.5 %, level 6: 19.0 %), uniform random qualities 50.0 % (52.2 / 47.8).
+// Nothing is read or written outside the piece's text, the scratch slots and the output slots; a sub-block or member
+// that would not fit its slot is reported with length 0 and the host makes that member itself.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int LZ_SUB = QD_LZ_SUB, LZ_HASH_BITS = 12, LZ_NICE = 32, LZ_DNA_MIN = 12, LZ_MAXLEN = 256;
+constexpr int LZ_TEXT_WORDS = (LZ_SUB + 320) / 4;  // the text and what the widest compare may read behind it
+constexpr int LZ_NL = 286, LZ_ND = 30;
+static_assert(LZ_SUB == 65536, "table entries are 16-bit positions inside the sub-block");
+
+__device__ __forceinline__ uint32_t rd32(const uint32_t* tw, uint32_t p) {  // 4 bytes at any byte position of the LDS text
+    const uint32_t i = p >> 2;
+    return __builtin_amdgcn_alignbyte(tw[i + 1], tw[i], p & 3u);
+}
+// bytes [p, p + 32) of the LDS text as 8 dwords
+__device__ __forceinline__ void rd256(const uint32_t* tw, uint32_t p, uint32_t (&a)[8]) {
+    const uint32_t i = p >> 2, sh = p & 3u;
+    uint32_t w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = tw[i + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh);
+}
+// how many of the 32 bytes in a[] equal the text at c (0..32)
+__device__ __forceinline__ uint32_t same32(const uint32_t* tw, const uint32_t (&a)[8], uint32_t c) {
+    uint32_t b[8];
+    rd256(tw, c, b);
+    uint32_t n = 32;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+        const uint32_t x = a[k] ^ b[k];
+        if (x) n = 4u * (uint32_t)k + ((uint32_t)__builtin_ctz(x) >> 3);
+    }
+    return n;
+}
+// every byte of v is one of A C G T N
+__device__ __forceinline__ bool bases4(uint32_t v) {
+    // (byte >> 1) & 7 tells the five letters apart (A 0, C 1, T 2, G 3, N 7): look the letter up, compare with the byte
+    return __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, (v >> 1) & 0x07070707u) == v;
+}
+// length - 3 (0..255) -> literal/length symbol, extra bits, extra value
+__device__ __forceinline__ void len_symbol(uint32_t l, uint32_t& sym, uint32_t& eb, uint32_t& ev) {
+    if (l < 8) {
+        sym = 257 + l;
+        eb = ev = 0;
+    } else if (l == 255) {
+        sym = 285;
+        eb = ev = 0;
+    } else {
+        const uint32_t n = 31u - (uint32_t)__clz(l);
+        eb = n - 2;
+        sym = 257 + 4 * (n - 1) + ((l >> eb) & 3u);
+        ev = l & ((1u << eb) - 1);
+    }
+}
+// distance - 1 (0..32767) -> distance symbol, extra bits, extra value
+__device__ __forceinline__ void dist_symbol(uint32_t d, uint32_t& sym, uint32_t& eb, uint32_t& ev) {
+    if (d < 4) {
+        sym = d;
+        eb = ev = 0;
+    } else {
+        const uint32_t n = 31u - (uint32_t)__clz(d);
+        eb = n - 1;
+        sym = 2 * n + ((d >> eb) & 1u);
+        ev = d & ((1u << eb) - 1);
+    }
+}
+__device__ __forceinline__ uint32_t len_extra_bits(uint32_t sym) {  // of literal/length symbol 257..285
+    return (sym < 265 || sym == 285) ? 0u : (sym - 261) >> 2;
+}
+__device__ __forceinline__ uint32_t dist_extra_bits(uint32_t sym) { return sym < 4 ? 0u : (sym >> 1) - 1; }
+
+// Lengths (<= 15) of a Huffman code for the used ones of n symbols, by one wave: the construction of code_lengths() with the
+// sort done by all lanes (rank = how many used symbols come before this one by (count, symbol)).  fx, order, w, parent: LDS
+// scratch of n, n, 2n, 2n entries.  Every lane calls it; len[] is complete when it returns.
+__device__ void wave_code_lengths(const uint32_t* freq, int n, uint8_t* len, uint32_t* fx, uint16_t* order, uint32_t* w, int16_t* parent,
+                                  uint32_t* m_out) {
+    const int lane = threadIdx.x & 63;
+    for (int s = lane; s < n; s += 64) {
+        fx[s] = freq[s];
+        len[s] = 0;
+    }
+    __syncthreads();
+    if (lane == 0) {  // a prefix code needs two codes: lend one to an unused symbol
+        int used = 0;
+        for (int s = 0; s < n; ++s) used += fx[s] != 0;
+        for (int s = 0; used < 2 && s < n; ++s)
+            if (!fx[s]) {
+                fx[s] = 1;
+                ++used;
+            }
+        *m_out = (uint32_t)used;
+    }
+    __syncthreads();
+    const int m = (int)*m_out;
+    for (int s = lane; s < n; s += 64) {
+        const uint32_t f = fx[s];
+        if (!f) continue;
+        int rank = 0;
+        for (int t = 0; t < n; ++t) {
+            const uint32_t g = fx[t];
+            rank += (g != 0 && (g < f || (g == f && t < s))) ? 1 : 0;
+        }
+        order[rank] = (uint16_t)s;
+        w[rank] = f;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        for (int i = 0; i < 2 * m - 1; ++i) parent[i] = -1;
+        int leaf = 0, inner = m, next = m;
+        while (next < 2 * m - 1) {
+            int pick[2];
+            for (int k = 0; k < 2; ++k) pick[k] = (leaf < m && (inner >= next || w[leaf] <= w[inner])) ? leaf++ : inner++;
+            w[next] = w[pick[0]] + w[pick[1]];
+            parent[pick[0]] = parent[pick[1]] = (int16_t)next;
+            ++next;
+        }
+        int bl[16] = {0};
+        w[2 * m - 2] = 0;  // depth of every node from the root down (w is reused for the depths)
+        for (int k = 2 * m - 3; k >= 0; --k) w[k] = w[parent[k]] + 1;
+        for (int i = 0; i < m; ++i) ++bl[w[i] < 15 ? w[i] : 15];
+        uint32_t kraft = 0;
+        for (int d = 1; d <= 15; ++d) kraft += (uint32_t)bl[d] << (15 - d);
+        for (uint32_t excess = kraft - (1u << 15); excess > 0; --excess) {
+            int bits = 14;
+            while (bl[bits] == 0) --bits;
+            --bl[bits];
+            bl[bits + 1] += 2;
+            --bl[15];
+        }
+        int at = 0;
+        for (int bits = 15; bits >= 1; --bits)
+            for (int c = 0; c < bl[bits]; ++c) len[order[at++]] = (uint8_t)bits;
+    }
+    __syncthreads();
+}
+
+// canonical codes, bit-reversed, of n symbols with the lengths len[] -> lut[s] = len | code << 8
+__device__ void canonical_lut(const uint8_t* len, int n, uint32_t* lut) {
+    int blc[16] = {0}, nxt[16] = {0};
+    for (int s = 0; s < n; ++s) ++blc[len[s]];
+    blc[0] = 0;
+    for (int b = 1, c = 0; b <= 15; ++b) {
+        c = (c + blc[b - 1]) << 1;
+        nxt[b] = c;
+    }
+    for (int s = 0; s < n; ++s) lut[s] = len[s] ? ((uint32_t)len[s] | (rev_bits((uint32_t)nxt[len[s]]++, len[s]) << 8)) : 0;
+}
+
+__global__ __launch_bounds__(64) void lz_subblocks(const uint8_t* text, const qd_lz_sub* subs, uint32_t* tokens, uint8_t* sub_out,
+                                                   int64_t sub_stride, uint32_t* sub_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lz_lds[];
+    uint32_t* tw = reinterpret_cast<uint32_t*>(lz_lds);                                          // LZ_TEXT_WORDS
+    unsigned long long* table = reinterpret_cast<unsigned long long*>(lz_lds + (size_t)LZ_TEXT_WORDS * 4);  // 1 << LZ_HASH_BITS buckets
+    __shared__ uint32_t lfreq[288], dfreq[32], llut[288], dlut[32];
+    __shared__ uint8_t llen[288], dlen[32];
+    __shared__ uint32_t ctl[4];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t L = subs[blockIdx.x].text_len;  // 1 .. LZ_SUB
+    const uint8_t* src = text + subs[blockIdx.x].text_off;  // 16-byte aligned
+    uint32_t* dst = reinterpret_cast<uint32_t*>(sub_out + (int64_t)blockIdx.x * sub_stride);
+    uint32_t* tok = tokens + (size_t)blockIdx.x * LZ_SUB;
+
+    // 0. stage the text (zero behind it), empty table and histograms
+    for (uint32_t i = lane; i < (uint32_t)LZ_TEXT_WORDS / 4; i += 64) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const uint32_t b = i * 16;
+        if (b + 16 <= L) {
+            v = *reinterpret_cast<const uint4*>(src + b);
+        } else if (b < L) {
+            uint32_t q[4] = {0, 0, 0, 0};
+            for (uint32_t k = b; k < L; ++k) q[(k - b) >> 2] |= (uint32_t)src[k] << (8 * ((k - b) & 3));
+            v = make_uint4(q[0], q[1], q[2], q[3]);
+        }
+        reinterpret_cast<uint4*>(tw)[i] = v;
+    }
+    for (uint32_t i = lane; i < (1u << LZ_HASH_BITS); i += 64) table[i] = 0;
+    for (uint32_t i = lane; i < 288; i += 64) lfreq[i] = 0;
+    if (lane < 32) dfreq[lane] = 0;
+    __syncthreads();
+
+    // 1 + 2. candidates and parse, 64 positions at a time
+    uint32_t ntok = 0;
+    {
+        int carry = 0;  // positions of the next stretch that the last match already covers
+        for (uint32_t base = 0; base < L; base += 64) {
+            const uint32_t p = base + lane;
+            const int limit = (int)min(64u, L - base);
+            uint32_t a[8];
+            rd256(tw, p, a);
+            uint32_t eff = 0, dist = 0;  // this position's match as the lane sees it (<= 32 bytes), 0: none worth taking
+            if (p + 4 <= L) {
+                const uint32_t h = (a[0] * 2654435761u) >> (32 - LZ_HASH_BITS);
+                const unsigned long long bucket = table[h];
+                uint32_t best = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {  // nearest first: a later candidate must be longer to win
+                    const uint32_t c = (uint32_t)(bucket >> (16 * k)) & 0xFFFFu;
+                    const uint32_t n = same32(tw, a, c);  // (any entry is a position inside the text: only a guess until compared)
+                    if (c < p && p - c <= 32768u && n > best) {
+                        best = n;
+                        dist = p - c;
+                    }
+                }
+                if (best < 4 && p >= 1) {  // a run
+                    const uint32_t n = same32(tw, a, p - 1);
+                    if (n >= 4) {
+                        best = n;
+                        dist = 1;
+                    }
+                }
+                best = min(best, L - p);
+                const uint32_t need = (bases4(a[0]) && bases4(a[1])) ? (uint32_t)LZ_DNA_MIN : 4u;
+                eff = best >= need ? best : 0u;
+                table[h] = (bucket << 16) | (unsigned long long)p;
+            }
+            const uint64_t cm = __ballot(eff != 0);
+            uint32_t tlen = 0, tdist = 0;
+            uint64_t starts = 0;
+            int s = carry;
+            while (s < limit) {
+                bool matched = false;
+                if ((cm >> s) & 1ull) {
+                    const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)eff, s);
+                    bool defer = false;
+                    if (s + 1 < limit && ((cm >> (s + 1)) & 1ull) && e0 < (uint32_t)LZ_NICE)
+                        defer = (uint32_t)__builtin_amdgcn_readlane((int)eff, s + 1) > e0;  // a literal now, the longer match next
+                    if (!defer) {
+                        const uint32_t D = (uint32_t)__builtin_amdgcn_readlane((int)dist, s);
+                        uint32_t len = e0;
+                        if (e0 >= (uint32_t)LZ_NICE) {  // the lane's view ended at 32 bytes: all lanes extend it, 4 bytes each
+                            const uint32_t ps = base + (uint32_t)s;
+                            const uint32_t x = rd32(tw, ps + 4 * lane) ^ rd32(tw, ps - D + 4 * lane);
+                            const uint64_t nz = __ballot(x != 0);
+                            len = LZ_MAXLEN;
+                            if (nz) {
+                                const int fl = __builtin_ctzll(nz);
+                                const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, fl);
+                                len = 4u * (uint32_t)fl + ((uint32_t)__builtin_ctz(xf) >> 3);
+                            }
+                            len = min(len, L - ps);
+                        }
+                        if ((int)lane == s) {
+                            tlen = len;
+                            tdist = D;
+                        }
+                        starts |= 1ull << s;
+                        s += (int)len;
+                        matched = true;
+                    }
+                }
+                if (!matched) {  // literals up to the next candidate
+                    const uint64_t rest = s + 1 < 64 ? (cm >> (s + 1)) << (s + 1) : 0ull;
+                    int nxt = rest ? __builtin_ctzll(rest) : 64;
+                    if (nxt > limit) nxt = limit;
+                    const uint64_t upto = nxt >= 64 ? ~0ull : ((1ull << nxt) - 1);
+                    starts |= upto & ~((1ull << s) - 1);
+                    s = nxt;
+                }
+            }
+            carry = s - 64;
+            if ((starts >> lane) & 1ull) {
+                uint32_t t;
+                if (tlen) {
+                    t = (tlen - 3) | ((tdist - 1) << 8);
+                    uint32_t sym, eb, ev;
+                    len_symbol(tlen - 3, sym, eb, ev);
+                    atomicAdd(&lfreq[sym], 1u);
+                    dist_symbol(tdist - 1, sym, eb, ev);
+                    atomicAdd(&dfreq[sym], 1u);
+                } else {
+                    t = 0x80000000u | (a[0] & 0xFFu);
+                    atomicAdd(&lfreq[a[0] & 0xFFu], 1u);
+                }
+                tok[ntok + (uint32_t)__popcll(starts & ((1ull << lane) - 1))] = t;
+            }
+            ntok += (uint32_t)__popcll(starts);
+        }
+    }
+    if (lane == 0) lfreq[256] = 1;  // end of block
+    __syncthreads();
+
+    // 3. the two codes (the text in LDS is not needed any more: its space holds the builders' scratch)
+    {
+        uint32_t* fx = tw;                                            // 288
+        uint16_t* order = reinterpret_cast<uint16_t*>(tw + 288);       // 288 x 16 bit
+        uint32_t* w = tw + 288 + 144;                                  // 576
+        int16_t* parent = reinterpret_cast<int16_t*>(tw + 288 + 144 + 576);  // 576 x 16 bit
+        wave_code_lengths(lfreq, LZ_NL, llen, fx, order, w, parent, &ctl[2]);
+        wave_code_lengths(dfreq, LZ_ND, dlen, fx, order, w, parent, &ctl[2]);
+    }
+    uint32_t* words = tw + 2048;  // 64 tokens x <= 48 bits, + the carried word
+    if (lane == 0) {
+        canonical_lut(llen, LZ_NL, llut);
+        canonical_lut(dlen, LZ_ND, dlut);
+        int nl = LZ_NL, nd = LZ_ND;
+        while (nl > 257 && llen[nl - 1] == 0) --nl;
+        while (nd > 1 && dlen[nd - 1] == 0) --nd;
+        uint64_t acc = 0;
+        int cnt = 0, wi = 0;
+        auto put = [&](uint32_t v, int n) {
+            acc |= (uint64_t)v << cnt;
+            cnt += n;
+            if (cnt >= 32) {
+                dst[wi++] = (uint32_t)acc;
+                acc >>= 32;
+                cnt -= 32;
+            }
+        };
+        put(0, 1);  // not the member's last block
+        put(2, 2);  // dynamic Huffman
+        put((uint32_t)(nl - 257), 5);
+        put((uint32_t)(nd - 1), 5);
+        put(15, 4);
+        const uint8_t ord[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        for (int k = 0; k < 19; ++k) put(ord[k] < 16 ? 4 : 0, 3);  // lengths 0..15 as 4-bit codes, no run-length symbols
+        for (int s = 0; s < nl; ++s) put(rev_bits(llen[s], 4), 4);
+        for (int s = 0; s < nd; ++s) put(rev_bits(dlen[s], 4), 4);
+        // the block must fit its slot: header, symbols + extra bits, end of block, the empty stored block
+        uint64_t bits = 3 + 14 + 19 * 3 + 4 * (uint64_t)(nl + nd);
+        for (int s = 0; s < LZ_NL; ++s) bits += (uint64_t)lfreq[s] * (llen[s] + (s > 256 ? len_extra_bits((uint32_t)s) : 0u));
+        for (int s = 0; s < LZ_ND; ++s) bits += (uint64_t)dfreq[s] * (dlen[s] + dist_extra_bits((uint32_t)s));
+        ctl[0] = (uint32_t)wi;
+        ctl[1] = ((bits + 7) / 8 + 3 + 4 + 8 <= (uint64_t)sub_stride) ? 1u : 0u;
+        ctl[2] = (uint32_t)acc;  // the partial word carried into the encode loop
+        ctl[3] = (uint32_t)cnt;
+    }
+    __syncthreads();
+    uint32_t out_word = ctl[0];
+    if (ctl[1] == 0) {
+        if (lane == 0) sub_bytes[blockIdx.x] = 0;
+        return;
+    }
+    // 4. encode, 64 tokens per step (carry: the bits of the last, partial word -- wave-uniform registers)
+    uint32_t cw = ctl[2], cb = ctl[3];
+    for (uint32_t g0 = 0; g0 < ntok; g0 += 64) {
+        const uint32_t g = g0 + lane;
+        uint64_t b = 0;
+        uint32_t nb = 0;
+        if (g < ntok) {
+            const uint32_t t = tok[g];
+            if (t & 0x80000000u) {
+                const uint32_t e = llut[t & 0xFFu];
+                b = e >> 8;
+                nb = e & 0xFFu;
+            } else {
+                uint32_t sym, eb, ev;
+                len_symbol(t & 0xFFu, sym, eb, ev);
+                uint32_t e = llut[sym];
+                b = (uint64_t)(e >> 8) | ((uint64_t)ev << (e & 0xFFu));
+                nb = (e & 0xFFu) + eb;
+                dist_symbol((t >> 8) & 0x7FFFu, sym, eb, ev);
+                e = dlut[sym];
+                b |= ((uint64_t)(e >> 8) | ((uint64_t)ev << (e & 0xFFu))) << nb;
+                nb += (e & 0xFFu) + eb;
+            }
+        }
+        uint32_t x = nb;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= (uint32_t)d) x += y;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+        const uint32_t nwords = (cb + total + 31) >> 5;
+        for (uint32_t i = lane; i <= nwords + 2; i += 64) words[i] = i == 0 ? cw : 0;
+        __syncthreads();
+        if (nb) {
+            const uint32_t pos = cb + x - nb, w0 = pos >> 5, sh = pos & 31u;
+            const uint64_t lo = b << sh;
+            const uint32_t hi = sh ? (uint32_t)(b >> (64 - sh)) : 0u;
+            if ((uint32_t)lo) atomicOr(&words[w0], (uint32_t)lo);
+            if ((uint32_t)(lo >> 32)) atomicOr(&words[w0 + 1], (uint32_t)(lo >> 32));
+            if (hi) atomicOr(&words[w0 + 2], hi);
+        }
+        __syncthreads();
+        const uint32_t full = (cb + total) >> 5;
+        for (uint32_t i = lane; i < full; i += 64) dst[out_word + i] = words[i];
+        cw = words[full];
+        cb = (cb + total) & 31u;
+        out_word += full;
+        __syncthreads();
+    }
+    // end of block; then an empty stored block puts the next sub-block on a byte boundary
+    if (lane == 0) {
+        uint64_t acc = cw;
+        int cnt = (int)cb;
+        const uint32_t e = llut[256];
+        acc |= (uint64_t)(e >> 8) << cnt;
+        cnt += (int)(e & 0xFFu);
+        cnt += 3;  // BFINAL 0, BTYPE 00
+        uint8_t* bytes = reinterpret_cast<uint8_t*>(dst) + (size_t)out_word * 4;
+        int nby = 0;
+        while (cnt > 0) {
+            bytes[nby++] = (uint8_t)acc;
+            acc >>= 8;
+            cnt -= 8;
+        }
+        bytes[nby++] = 0;
+        bytes[nby++] = 0;
+        bytes[nby++] = 0xFF;
+        bytes[nby++] = 0xFF;
+        sub_bytes[blockIdx.x] = out_word * 4 + (uint32_t)nby;
+    }
+}
+
+// member i = gzip header | the piece's sub-blocks first_sub[i] .. first_sub[i + 1] | an empty final block | CRC-32, ISIZE
+__global__ __launch_bounds__(256) void lz_members(const qd_deflate_piece* pieces, const uint32_t* first_sub, const uint8_t* sub_out,
+                                                  int64_t sub_stride, const uint32_t* sub_bytes, uint8_t* out, int64_t out_stride,
+                                                  uint32_t* out_bytes) {
+    const uint32_t j0 = first_sub[blockIdx.x], j1 = first_sub[blockIdx.x + 1];
+    uint64_t total = 10 + 2 + 8;
+    bool ok = true;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const uint32_t n = sub_bytes[j];
+        ok = ok && n > 0;
+        total += n;
+    }
+    if (!ok || total > (uint64_t)out_stride) {
+        if (threadIdx.x == 0) out_bytes[blockIdx.x] = 0;
+        return;
+    }
+    uint8_t* dst = out + (int64_t)blockIdx.x * out_stride;
+    uint64_t off = 10;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const uint32_t n = sub_bytes[j];
+        const uint8_t* s = sub_out + (int64_t)j * sub_stride;
+        for (uint32_t k = threadIdx.x; k < n; k += 256) dst[off + k] = s[k];
+        off += n;
+    }
+    if (threadIdx.x == 0) {
+        const uint8_t head[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff};
+        for (int i = 0; i < 10; ++i) dst[i] = head[i];
+        dst[off++] = 0x03;  // BFINAL 1, fixed Huffman, end of block
+        dst[off++] = 0x00;
+        const uint32_t c = pieces[blockIdx.x].crc32, isz = pieces[blockIdx.x].text_len;
+        for (int i = 0; i < 4; ++i) dst[off++] = (uint8_t)(c >> (8 * i));
+        for (int i = 0; i < 4; ++i) dst[off++] = (uint8_t)(isz >> (8 * i));
+        out_bytes[blockIdx.x] = (uint32_t)off;
+    }
+}
+}  // namespace
+
+hipError_t qd_launch_lz(const uint8_t* text, const qd_deflate_piece* pieces, uint32_t n_pieces, const qd_lz_sub* subs, const uint32_t* first_sub,
+                        uint32_t n_subs, uint32_t* tokens, uint8_t* sub_out, int64_t sub_stride, uint32_t* sub_bytes, uint8_t* out,
+                        int64_t out_stride, uint32_t* out_bytes, hipStream_t st) {
+    if (n_pieces == 0) return hipSuccess;
+    constexpr size_t lds = (size_t)LZ_TEXT_WORDS * 4 + (8u << LZ_HASH_BITS);
+    static_assert(LZ_TEXT_WORDS % 4 == 0, "the text is staged 16 bytes at a time");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lz_subblocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (n_subs) hipLaunchKernelGGL(lz_subblocks, dim3(n_subs), dim3(64), lds, st, text, subs, tokens, sub_out, sub_stride, sub_bytes);
+    hipLaunchKernelGGL(lz_members, dim3(n_pieces), dim3(256), 0, st, pieces, first_sub, sub_out, sub_stride, sub_bytes, out, out_stride,
+                       out_bytes);
     return hipGetLastError();
 }

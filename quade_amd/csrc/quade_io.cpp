@@ -511,6 +511,7 @@ extern "C" {
 int qd_deflater_create(int device_id, qd_deflater** out) __attribute__((weak));
 int qd_deflater_run(qd_deflater* deflater, int32_t n_pieces, const uint8_t* const* text, const int64_t* text_len, const uint32_t* crc32,
                     int32_t text_pinned, uint8_t* out, int64_t out_stride, int64_t* member_len) __attribute__((weak));
+int qd_deflater_set_level(qd_deflater* deflater, int32_t level) __attribute__((weak));
 int qd_deflater_destroy(qd_deflater* deflater) __attribute__((weak));
 int64_t qd_huffman_member_bound(int64_t text_len) __attribute__((weak));
 void* qd_pinned_alloc(int64_t bytes) __attribute__((weak));
@@ -529,7 +530,11 @@ struct DevPiece {
     size_t cap;
     int64_t len;
     uint32_t crc;
+    int level;  // of its sink: -1 (Huffman only) or 1 (LZ77 + Huffman), the two the device implements
 };
+
+// the levels whose members a deflate device makes (qd_deflater_set_level)
+inline bool device_level(int level) { return level == -1 || level == 1; }
 
 void finish_piece(qd_sink* s, OutFile* f, uint64_t seq, int64_t text_bytes, int64_t w, Bytes&& member, bool on_device) {
     const int64_t out_bytes = (int64_t)member.size();
@@ -599,7 +604,7 @@ class DeflateService {
             {
                 std::unique_lock<std::mutex> g(m_);
                 cv_.wait(g, [this] { return !q_.empty() || want_slab_; });
-                while (!q_.empty() && (int)b.size() < MAX_BATCH) {
+                while (!q_.empty() && (int)b.size() < MAX_BATCH && (b.empty() || q_.front().level == b[0].level)) {  // one level per launch
                     b.push_back(q_.front());
                     q_.pop_front();
                 }
@@ -622,6 +627,8 @@ class DeflateService {
             }
             bool ok = usable && !(fail_after >= 0 && batches >= fail_after);
             int64_t stride = 0;
+            if (ok && b[0].level != -1) ok = qd_deflater_set_level && qd_deflater_set_level(def, b[0].level) == QD_OK;
+            else if (ok && qd_deflater_set_level) (void)qd_deflater_set_level(def, -1);
             if (ok) {
                 stride = qd_huffman_member_bound(longest);
                 out.resize((size_t)stride * b.size());
@@ -639,7 +646,7 @@ class DeflateService {
                 if (dev) {
                     member.resize((size_t)ml[i]);
                     memcpy(member.data(), out.data() + (size_t)stride * i, (size_t)ml[i]);
-                } else if (!huffman_member(b[i].text, (size_t)b[i].len, member)) {
+                } else if (!gzip_member(b[i].text, (size_t)b[i].len, b[i].level, member)) {
                     sink_error(b[i].s, "gzip compression failed");
                     member.clear();
                 }
@@ -724,7 +731,7 @@ int qd_sink_set_device_deflate(qd_sink* s, int32_t device_id) {
     if (!s) return QD_ERR_INVALID;
     if (device_id >= 0 && !(qd_deflater_create && qd_deflater_run && qd_huffman_member_bound && qd_pinned_alloc)) return QD_ERR_NO_DEVICE;
     s->deflate_device = device_id;
-    if (device_id >= 0 && s->level < 0) (void)deflate_service(device_id);  // its lanes come up (deflaters, first buffers) while the readers start
+    if (device_id >= 0 && device_level(s->level)) (void)deflate_service(device_id);  // its lanes come up (deflaters, first buffers) while the readers start
     return QD_OK;
 }
 
@@ -856,7 +863,7 @@ static int route_impl(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_
         P.submit([s, p, tag_rows, tag_stride, tag_len, res]() mutable {
             // Huffman-only members with a deflate device: format straight into a page-locked buffer and hand the piece
             // to the device lanes (which deliver it); no buffer free = this core codes the piece itself, as below
-            if (s->level < 0 && s->deflate_device >= 0) {
+            if (device_level(s->level) && s->deflate_device >= 0) {
                 DeflateService* sv = deflate_service(s->deflate_device);
                 const size_t need = (size_t)p.text_bytes + 8 * (size_t)p.n_sel + 16;
                 uint8_t* buf = need <= DeflateService::BUF_BYTES ? sv->take_buffer() : nullptr;
@@ -866,7 +873,7 @@ static int route_impl(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_
                     res->formatted.done();
                     res.reset();
                     if (w >= 0) {
-                        sv->submit(DevPiece{s, p.f, p.seq, p.text_bytes, buf, DeflateService::BUF_BYTES, w, qd_io_crc32(buf, (size_t)w)});
+                        sv->submit(DevPiece{s, p.f, p.seq, p.text_bytes, buf, DeflateService::BUF_BYTES, w, qd_io_crc32(buf, (size_t)w), s->level});
                     } else {
                         sv->give_buffer(buf);
                         sink_error(s, "qd_format_records failed (malformed record text)");

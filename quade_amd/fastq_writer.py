@@ -41,7 +41,7 @@ class FastqSink(object):
 
     def __init__(self, outdir, sample_names, gzip_level=6, write_pass=True, write_fail=True, write_undetermined=True,
                  quiet=False, deflate_device=-1):
-        """deflate_device >= 0: with gzip_level -1 the members are made on that GPU (quade_deflate.hip) while the
+        """deflate_device >= 0: with gzip_level -1 or 1 the members are made on that GPU (quade_deflate.hip) while the
         process has page-locked buffers to spare, on the pool's threads otherwise."""
         self.lib = hb.load_library()
         names = [n.encode() if isinstance(n, str) else bytes(n) for n in sample_names]

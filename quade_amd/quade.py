@@ -140,8 +140,9 @@ class Quade(object):
                 self.engines.append(eng)
             self.engine_groups.append(group)
         self.plan, self.layout = plan, self.engines[0].layout
-        # Huffman-only output members on the first device of this process ([gpu] device_deflate, gzip_level -1)
-        Sample.DEFLATE_DEVICE = self.engines[0].device_id if (cf.device_deflate and cf.gzip_level < 0) else -1
+        # output members made on the first device of this process ([gpu] device_deflate): gzip_level -1 (Huffman only) and
+        # 1 (LZ77 + Huffman) are the levels the device implements, the others stay with the host's pool
+        Sample.DEFLATE_DEVICE = self.engines[0].device_id if (cf.device_deflate and cf.gzip_level in (-1, 1)) else -1
 
         # the communicator comes up before any chunk is touched: rank 0 clears stale part files, then
         # publishes the id the other ranks wait for, so nobody writes parts before the clean-up

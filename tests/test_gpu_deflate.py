@@ -1,6 +1,6 @@
-"""Huffman-only gzip members made on the GPU (quade_amd/csrc/quade_deflate.hip, qd_deflater_*): the gzip of the output
-files (src/FastqWriter.py:83-90) for the driver's `gzip_level : -1`.  The checker is zlib (any gunzip must read the
-members) and, for whole runs, the files the host's own Huffman-only coder writes."""
+"""gzip members made on the GPU (quade_amd/csrc/quade_deflate.hip, qd_deflater_*): the gzip of the output files
+(src/FastqWriter.py:83-90) for the driver's `gzip_level : -1` (Huffman coding only) and `gzip_level : 1` (LZ77 + Huffman).
+The checker is zlib (any gunzip must read the members) and, for whole runs, the files the host's own coders write."""
 import ctypes as C
 import gzip
 import os
@@ -12,8 +12,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run(lib, d, pieces, pinned):
+def _run(lib, d, pieces, pinned, level=-1):
     from quade_amd import hip_backend as hb
+    assert lib.qd_deflater_set_level(d, level) == 0
     n = len(pieces)
     keep, ptrs = [], (C.c_void_p * max(n, 1))()
     for i, t in enumerate(pieces):
@@ -77,6 +78,60 @@ def test_device_members_inflate_with_zlib_to_the_text():
         ml = np.full(1, -1, np.int64)
         assert lib.qd_deflater_run(d, 1, ptrs, hb._ptr(lens), hb._ptr(crc), 0, hb._ptr(out), 4096, hb._ptr(ml)) == 0
         assert ml[0] == 0 and (out[4096:] == 0xAB).all()
+    finally:
+        lib.qd_deflater_destroy(d)
+
+
+def _fastq_like(rng, n_records, binned):
+    """records with names that repeat most of their predecessor's, and (binned) qualities in long runs: what matching earns on"""
+    out = []
+    for i in range(n_records):
+        seq = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 150))
+        if binned:
+            q = np.full(150, ord("F"), np.uint8)
+            for _ in range(int(rng.integers(0, 6))):
+                a = int(rng.integers(0, 150))
+                q[a:a + int(rng.integers(1, 12))] = rng.choice(np.frombuffer(b":,#", np.uint8))
+            qual = bytes(q)
+        else:
+            qual = bytes(rng.integers(35, 74, 150).astype(np.uint8))
+        out.append(b"@A00123:45:HXXXXXXXX:1:%d:%d:%d 1:N:0:ACGTACGT+TTGCAATC\n%s\n+\n%s\n" % (1101 + i // 3000, 1000 + (i * 37) % 30000,
+                                                                                            1000 + (i * 101) % 35000, seq, qual))
+    return b"".join(out)
+
+
+def test_device_lz_members_inflate_with_zlib_to_the_text():
+    """`gzip_level : 1` on the device (LZ77 + dynamic Huffman, 64 KiB sub-blocks joined in one member): every member must
+    inflate to its piece with zlib -- fastq text, runs far longer than the longest match, periodic text (overlapping
+    matches), incompressible bytes, pieces around the sub-block boundaries, one byte, nothing -- and the matching must earn
+    what it does on the host: below the Huffman-only size and below zlib's level 1 (tools/lz_model.cpp: between zlib's
+    levels 1 and 6 on both kinds of text)."""
+    from quade_amd import hip_backend as hb
+    lib = hb.load_library()
+    rng = np.random.default_rng(22)
+    fq = _fastq_like(rng, 9000, False)
+    fqb = _fastq_like(rng, 9000, True)
+    SUB = 65536
+    pieces = [fqb[:2 << 20], fq[:2 << 20], fqb[:SUB], fqb[:SUB + 1], fqb[:SUB - 1], fqb[:16384], fqb[:16385], fqb[:16383], fqb[:3 * SUB + 77],
+              fqb[:70], fqb[:3], b"A" * 100000, b"AB" * 40000, b"ABC" * 30000, b"ABCDEFGHIJKLMNOPQ" * 9000, bytes(range(256)) * 600,
+              bytes(rng.integers(0, 256, 200000).astype(np.uint8)), b"x", b"ab", b"abcd", b"", fqb, fq[:5 << 20],
+              bytes(rng.integers(65, 69, 300000).astype(np.uint8))]
+    d = C.c_void_p()
+    assert lib.qd_deflater_create(0, C.byref(d)) == 0
+    try:
+        assert lib.qd_deflater_set_level(d, 6) != 0  # only -1 and 1 are the device's
+        for pinned in (False, True):
+            members = _run(lib, d, pieces, pinned, level=1)
+            for k, (t, m) in enumerate(zip(pieces, members)):
+                assert len(m) >= 20 and gzip.decompress(m) == t, (pinned, k, len(t), len(m))
+            huff = _run(lib, d, pieces[:2], pinned, level=-1)
+            for t, m, h in zip(pieces[:2], members[:2], huff):
+                z1 = len(zlib.compress(t, 1))
+                assert len(m) < 0.97 * len(h) and len(m) < z1, (len(t), len(m), len(h), z1)  # smaller than zlib's level 1
+            assert len(members[11]) < 2000 and len(members[12]) < 2000  # runs: one match per 256 bytes
+        # the two levels alternate on one deflater
+        assert gzip.decompress(_run(lib, d, [fqb[:100000]], False, level=-1)[0]) == fqb[:100000]
+        assert gzip.decompress(_run(lib, d, [fqb[:100000]], False, level=1)[0]) == fqb[:100000]
     finally:
         lib.qd_deflater_destroy(d)
 
