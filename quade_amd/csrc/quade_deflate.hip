@@ -270,39 +270,44 @@ hipError_t qd_launch_huffman(const uint8_t* text, const qd_deflate_piece* pieces
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// LZ77 + dynamic Huffman on the device: gzip members for the driver's `gzip_level : 1` and above (r03).  What it replaces is
-// the same seam (src/FastqWriter.py:83-90: gzip members appended to the destination files), at the levels where matching
-// earns its keep on fastq text: the read names (a record's name repeats most of its predecessor's) and the quality lines
-// (runs, and stretches shared with earlier lines).
+// LZ77 + dynamic Huffman on the device: gzip members for the driver's `gzip_level : 1` (r03).  What it replaces is the same
+// seam (src/FastqWriter.py:83-90: gzip members appended to the destination files), at a level where matching earns its keep
+// on fastq text: the read names (a record's name repeats most of its predecessor's) and the quality lines (runs, and
+// stretches shared with earlier lines).
 //
-// A piece (~2 MB of formatted records) is cut into sub-blocks of 64 KiB; ONE WAVE per sub-block (a workgroup of 64 lanes:
-// the parse is sequential in the text, and what a wave does for it in parallel is a stretch of 64 positions) makes one
+// A piece (~2 MB of formatted records) is cut into sub-blocks of 64 KiB; one workgroup (4 waves) per sub-block makes one
 // dynamic-Huffman block that ends on a byte boundary (an empty stored block behind it, as pigz joins the work of its
 // threads); a second kernel strings a piece's sub-blocks together behind the gzip header and closes the member with an
 // empty final block, CRC-32 (made on the host) and ISIZE.
 //
-//  1. the sub-block's text is staged in LDS and walked 64 positions at a time.  Candidates: each lane hashes the 4 bytes
-//     at its position into a table of 4 096 buckets x the 4 last positions with that hash (16 bit each; an entry is only
-//     a guess), compares each candidate with its own next 32 bytes, keeps the longest (the nearest on a tie), tries
-//     distance 1 (runs) if none matched, and enters its own position.  A match that covers only bases (ACGTN: literals of
-//     ~2 bits) must be 12 bytes long to be taken, any other 4 -- short matches inside the sequence lines cost more than
-//     their literals (tools/lz_model.cpp: 31.8 % -> 27.3 % of the text on binned-quality records).
-//  2. the parse is a scalar walk over the 64 positions: a position with a match is deferred by one literal when its
-//     successor's match is longer (lazy evaluation on the lanes' 32-byte views); a 32-byte match is extended by all 64
-//     lanes comparing 4 bytes each (256 bytes in one step: ballot + count of trailing zeros = the length); the walk jumps
-//     behind the match; positions without a match are literals and are skipped in one step up to the next candidate.
-//     Tokens (literal | length, distance) go to a scratch array in text order, their symbols into two LDS histograms.
-//  3. the two length-limited codes: symbols ranked by (count, symbol) by all lanes, the two-queue merge and the Kraft repair
-//     of the Huffman-only kernel by one; the header carries the code lengths as plain 4-bit numbers.
-//  4. 64 tokens per step are coded in parallel: bits and bit count per lane, wave scan, OR into an LDS word buffer, whole
-//     words leave coalesced.
-// Against zlib on 2 MB of fastq text (tools/lz_model.cpp, the sizes the device's members have: tests/test_gpu_deflate.py):
-// binned qualities 19.5 % of the text (zlib level 1: 22.5 %, level 6: 19.0 %), uniform random qualities 50.0 % (52.2 / 47.8).
+//  1. candidates, for every position of the sub-block (text staged in LDS): rounds of 256 positions, a stretch of 64 per
+//     wave, one barrier per round (so a look-up sees every position up to the round before its own -- what the parse
+//     needs is the NEAREST earlier occurrence; four waves on four quarters of the sub-block, the first form, made files
+//     60 % larger).  Each lane hashes the 4 bytes at its position into a table of 2 048 buckets x the 2 last positions with
+//     that hash (16 bit each; an entry is only a guess), compares both candidates and the position before its own
+//     (distance 1: runs) with its own next 32 bytes, keeps the longest (the nearest on a tie), and enters its own
+//     position.  A match that covers only bases (ACGTN: literals of ~2 bits) must be 12 bytes long to be kept, any other
+//     4 -- short matches inside the sequence lines cost more than their literals.  (length <= 32, distance) per
+//     position goes to the sub-block's scratch.
+//  2. the parse: every wave walks a quarter of the sub-block (a match never crosses into the next quarter), 64
+//     positions at a time, as a scalar loop: a position with a match is deferred by one literal when its successor's
+//     match is longer (lazy evaluation on the 32-byte views); a 32-byte match is extended by all 64 lanes comparing 4
+//     bytes each (256 bytes in one step: ballot + count of trailing zeros = the length); the walk jumps behind the
+//     match; positions without a match are literals and are skipped in one step up to the next candidate.  Tokens
+//     (literal | length, distance) replace the candidates in the scratch, in text order; their symbols go into two LDS
+//     histograms.
+//  3. the two length-limited codes: symbols ranked by (count, symbol) by all threads, the two-queue merge and the Kraft
+//     repair of the Huffman-only kernel by one; the header carries the code lengths as plain 4-bit numbers.
+//  4. 256 tokens per step are coded in parallel: bits and bit count per lane, workgroup scan, OR into an LDS word buffer,
+//     whole words leave coalesced.
+// Against the host's coders on 2 MB of fastq text (tools/lz_model.cpp is the parse on the CPU; tools/lz_bench.py the device):
+// binned qualities 18.8 % of the text (zlib level 1: 22.5 %, level 6: 19.0 %), uniform random qualities 50.0 % (52.2 / 47.8).
 // Nothing is read or written outside the piece's text, the scratch slots and the output slots; a sub-block or member
 // that would not fit its slot is reported with length 0 and the host makes that member itself.
 // ------------------------------------------------------------------------------------------------------------------------
 namespace {
-constexpr int LZ_SUB = QD_LZ_SUB, LZ_HASH_BITS = 12, LZ_NICE = 32, LZ_DNA_MIN = 12, LZ_MAXLEN = 256;
+constexpr int LZ_SUB = QD_LZ_SUB, LZ_WAVES = 4, LZ_BLOCK = 64 * LZ_WAVES, LZ_REG = LZ_SUB / LZ_WAVES;
+constexpr int LZ_HASH_BITS = 11, LZ_NICE = 32, LZ_DNA_MIN = 12, LZ_MAXLEN = 256;
 constexpr int LZ_TEXT_WORDS = (LZ_SUB + 320) / 4;  // the text and what the widest compare may read behind it
 constexpr int LZ_NL = 286, LZ_ND = 30;
 static_assert(LZ_SUB == 65536, "table entries are 16-bit positions inside the sub-block");
@@ -369,18 +374,18 @@ __device__ __forceinline__ uint32_t len_extra_bits(uint32_t sym) {  // of litera
 }
 __device__ __forceinline__ uint32_t dist_extra_bits(uint32_t sym) { return sym < 4 ? 0u : (sym >> 1) - 1; }
 
-// Lengths (<= 15) of a Huffman code for the used ones of n symbols, by one wave: the construction of code_lengths() with the
-// sort done by all lanes (rank = how many used symbols come before this one by (count, symbol)).  fx, order, w, parent: LDS
-// scratch of n, n, 2n, 2n entries.  Every lane calls it; len[] is complete when it returns.
-__device__ void wave_code_lengths(const uint32_t* freq, int n, uint8_t* len, uint32_t* fx, uint16_t* order, uint32_t* w, int16_t* parent,
-                                  uint32_t* m_out) {
-    const int lane = threadIdx.x & 63;
-    for (int s = lane; s < n; s += 64) {
+// Lengths (<= 15) of a Huffman code for the used ones of n symbols, by one workgroup: the construction of code_lengths()
+// with the sort done by all threads (rank = how many used symbols come before this one by (count, symbol)).  fx, order, w,
+// parent: LDS scratch of n, n, 2n, 2n entries.  Every thread calls it; len[] is complete when it returns.
+__device__ void block_code_lengths(const uint32_t* freq, int n, uint8_t* len, uint32_t* fx, uint16_t* order, uint32_t* w, int16_t* parent,
+                                   uint32_t* m_out) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    for (int s = tid; s < n; s += nthr) {
         fx[s] = freq[s];
         len[s] = 0;
     }
     __syncthreads();
-    if (lane == 0) {  // a prefix code needs two codes: lend one to an unused symbol
+    if (tid == 0) {  // a prefix code needs two codes: lend one to an unused symbol
         int used = 0;
         for (int s = 0; s < n; ++s) used += fx[s] != 0;
         for (int s = 0; used < 2 && s < n; ++s)
@@ -392,7 +397,7 @@ __device__ void wave_code_lengths(const uint32_t* freq, int n, uint8_t* len, uin
     }
     __syncthreads();
     const int m = (int)*m_out;
-    for (int s = lane; s < n; s += 64) {
+    for (int s = tid; s < n; s += nthr) {
         const uint32_t f = fx[s];
         if (!f) continue;
         int rank = 0;
@@ -404,7 +409,7 @@ __device__ void wave_code_lengths(const uint32_t* freq, int n, uint8_t* len, uin
         w[rank] = f;
     }
     __syncthreads();
-    if (lane == 0) {
+    if (tid == 0) {
         for (int i = 0; i < 2 * m - 1; ++i) parent[i] = -1;
         int leaf = 0, inner = m, next = m;
         while (next < 2 * m - 1) {
@@ -446,22 +451,23 @@ __device__ void canonical_lut(const uint8_t* len, int n, uint32_t* lut) {
     for (int s = 0; s < n; ++s) lut[s] = len[s] ? ((uint32_t)len[s] | (rev_bits((uint32_t)nxt[len[s]]++, len[s]) << 8)) : 0;
 }
 
-__global__ __launch_bounds__(64) void lz_subblocks(const uint8_t* text, const qd_lz_sub* subs, uint32_t* tokens, uint8_t* sub_out,
-                                                   int64_t sub_stride, uint32_t* sub_bytes) {
+__global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, const qd_lz_sub* subs, uint32_t* tokens, uint8_t* sub_out,
+                                                         int64_t sub_stride, uint32_t* sub_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lz_lds[];
-    uint32_t* tw = reinterpret_cast<uint32_t*>(lz_lds);                                          // LZ_TEXT_WORDS
-    unsigned long long* table = reinterpret_cast<unsigned long long*>(lz_lds + (size_t)LZ_TEXT_WORDS * 4);  // 1 << LZ_HASH_BITS buckets
+    uint32_t* tw = reinterpret_cast<uint32_t*>(lz_lds);                                   // LZ_TEXT_WORDS
+    uint32_t* table = reinterpret_cast<uint32_t*>(lz_lds + (size_t)LZ_TEXT_WORDS * 4);     // 1 << LZ_HASH_BITS buckets of 2 x 16 bit
     __shared__ uint32_t lfreq[288], dfreq[32], llut[288], dlut[32];
     __shared__ uint8_t llen[288], dlen[32];
-    __shared__ uint32_t ctl[4];
-    const uint32_t lane = threadIdx.x;
+    __shared__ uint32_t wave_ntok[LZ_WAVES], scan[LZ_WAVES], ctl[4];
+    __shared__ uint32_t carry_word, carry_bits;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t L = subs[blockIdx.x].text_len;  // 1 .. LZ_SUB
     const uint8_t* src = text + subs[blockIdx.x].text_off;  // 16-byte aligned
     uint32_t* dst = reinterpret_cast<uint32_t*>(sub_out + (int64_t)blockIdx.x * sub_stride);
-    uint32_t* tok = tokens + (size_t)blockIdx.x * LZ_SUB;
+    uint32_t* tok0 = tokens + (size_t)blockIdx.x * LZ_SUB;  // candidates per position, then the waves' token lists
 
     // 0. stage the text (zero behind it), empty table and histograms
-    for (uint32_t i = lane; i < (uint32_t)LZ_TEXT_WORDS / 4; i += 64) {
+    for (uint32_t i = tid; i < (uint32_t)LZ_TEXT_WORDS / 4; i += LZ_BLOCK) {
         uint4 v = make_uint4(0, 0, 0, 0);
         const uint32_t b = i * 16;
         if (b + 16 <= L) {
@@ -473,46 +479,61 @@ __global__ __launch_bounds__(64) void lz_subblocks(const uint8_t* text, const qd
         }
         reinterpret_cast<uint4*>(tw)[i] = v;
     }
-    for (uint32_t i = lane; i < (1u << LZ_HASH_BITS); i += 64) table[i] = 0;
-    for (uint32_t i = lane; i < 288; i += 64) lfreq[i] = 0;
-    if (lane < 32) dfreq[lane] = 0;
+    for (uint32_t i = tid; i < (1u << LZ_HASH_BITS); i += LZ_BLOCK) table[i] = 0;
+    for (uint32_t i = tid; i < 288; i += LZ_BLOCK) lfreq[i] = 0;
+    if (tid < 32) dfreq[tid] = 0;
     __syncthreads();
 
-    // 1 + 2. candidates and parse, 64 positions at a time
-    uint32_t ntok = 0;
-    {
-        int carry = 0;  // positions of the next stretch that the last match already covers
-        for (uint32_t base = 0; base < L; base += 64) {
-            const uint32_t p = base + lane;
-            const int limit = (int)min(64u, L - base);
+    // 1. candidates: rounds of 256 positions, one barrier per round
+    for (uint32_t r0 = 0; r0 < L; r0 += LZ_BLOCK) {
+        const uint32_t p = r0 + tid;
+        if (p < L) {
             uint32_t a[8];
             rd256(tw, p, a);
-            uint32_t eff = 0, dist = 0;  // this position's match as the lane sees it (<= 32 bytes), 0: none worth taking
+            uint32_t best = 0, dist = 0;
             if (p + 4 <= L) {
                 const uint32_t h = (a[0] * 2654435761u) >> (32 - LZ_HASH_BITS);
-                const unsigned long long bucket = table[h];
-                uint32_t best = 0;
+                const uint32_t bucket = table[h];
+                if (p >= 1) {  // a run (the nearest candidate there is)
+                    best = same32(tw, a, p - 1);
+                    dist = 1;
+                }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {  // nearest first: a later candidate must be longer to win
-                    const uint32_t c = (uint32_t)(bucket >> (16 * k)) & 0xFFFFu;
+                for (int k = 0; k < 2; ++k) {  // nearest first: a later candidate must be longer to win
+                    const uint32_t c = (bucket >> (16 * k)) & 0xFFFFu;
                     const uint32_t n = same32(tw, a, c);  // (any entry is a position inside the text: only a guess until compared)
                     if (c < p && p - c <= 32768u && n > best) {
                         best = n;
                         dist = p - c;
                     }
                 }
-                if (best < 4 && p >= 1) {  // a run
-                    const uint32_t n = same32(tw, a, p - 1);
-                    if (n >= 4) {
-                        best = n;
-                        dist = 1;
-                    }
-                }
                 best = min(best, L - p);
                 const uint32_t need = (bases4(a[0]) && bases4(a[1])) ? (uint32_t)LZ_DNA_MIN : 4u;
-                eff = best >= need ? best : 0u;
-                table[h] = (bucket << 16) | (unsigned long long)p;
+                if (best < need) best = 0;
+                table[h] = (bucket << 16) | p;
             }
+            tok0[p] = best | (dist << 8);
+        }
+        __syncthreads();
+    }
+
+    // 2. parse: this wave's quarter of the sub-block, 64 positions at a time
+    {
+        const uint32_t rbeg = wave * LZ_REG, rend = min(rbeg + (uint32_t)LZ_REG, L);
+        uint32_t* tok = tok0 + rbeg;
+        uint32_t ntok = 0;
+        int carry = 0;  // positions of the next stretch that the last match already covers
+        for (uint32_t base = rbeg; base < rend; base += 64) {
+            const uint32_t p = base + lane;
+            const int limit = (int)min(64u, rend - base);
+            uint32_t eff = 0, dist = 0;
+            if ((int)lane < limit) {
+                const uint32_t cd = tok0[p];
+                eff = min(cd & 0xFFu, rend - p);  // (a match ends with the quarter)
+                dist = cd >> 8;
+                if (eff < 4) eff = 0;
+            }
+            const uint32_t lit = (tw[p >> 2] >> (8 * (p & 3u))) & 0xFFu;
             const uint64_t cm = __ballot(eff != 0);
             uint32_t tlen = 0, tdist = 0;
             uint64_t starts = 0;
@@ -537,7 +558,7 @@ __global__ __launch_bounds__(64) void lz_subblocks(const uint8_t* text, const qd
                                 const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, fl);
                                 len = 4u * (uint32_t)fl + ((uint32_t)__builtin_ctz(xf) >> 3);
                             }
-                            len = min(len, L - ps);
+                            len = min(len, rend - ps);
                         }
                         if ((int)lane == s) {
                             tlen = len;
@@ -568,15 +589,16 @@ __global__ __launch_bounds__(64) void lz_subblocks(const uint8_t* text, const qd
                     dist_symbol(tdist - 1, sym, eb, ev);
                     atomicAdd(&dfreq[sym], 1u);
                 } else {
-                    t = 0x80000000u | (a[0] & 0xFFu);
-                    atomicAdd(&lfreq[a[0] & 0xFFu], 1u);
+                    t = 0x80000000u | lit;
+                    atomicAdd(&lfreq[lit], 1u);
                 }
-                tok[ntok + (uint32_t)__popcll(starts & ((1ull << lane) - 1))] = t;
+                tok[ntok + (uint32_t)__popcll(starts & ((1ull << lane) - 1))] = t;  // (index <= this position: its candidate was read above)
             }
             ntok += (uint32_t)__popcll(starts);
         }
+        if (lane == 0) wave_ntok[wave] = ntok;
     }
-    if (lane == 0) lfreq[256] = 1;  // end of block
+    if (tid == 0) lfreq[256] = 1;  // end of block
     __syncthreads();
 
     // 3. the two codes (the text in LDS is not needed any more: its space holds the builders' scratch)
@@ -585,11 +607,11 @@ __global__ __launch_bounds__(64) void lz_subblocks(const uint8_t* text, const qd
         uint16_t* order = reinterpret_cast<uint16_t*>(tw + 288);       // 288 x 16 bit
         uint32_t* w = tw + 288 + 144;                                  // 576
         int16_t* parent = reinterpret_cast<int16_t*>(tw + 288 + 144 + 576);  // 576 x 16 bit
-        wave_code_lengths(lfreq, LZ_NL, llen, fx, order, w, parent, &ctl[2]);
-        wave_code_lengths(dfreq, LZ_ND, dlen, fx, order, w, parent, &ctl[2]);
+        block_code_lengths(lfreq, LZ_NL, llen, fx, order, w, parent, &ctl[2]);
+        block_code_lengths(dfreq, LZ_ND, dlen, fx, order, w, parent, &ctl[2]);
     }
-    uint32_t* words = tw + 2048;  // 64 tokens x <= 48 bits, + the carried word
-    if (lane == 0) {
+    uint32_t* words = tw + 2048;  // 256 tokens x <= 48 bits, + the carried word
+    if (tid == 0) {
         canonical_lut(llen, LZ_NL, llut);
         canonical_lut(dlen, LZ_ND, dlut);
         int nl = LZ_NL, nd = LZ_ND;
@@ -615,29 +637,36 @@ __global__ __launch_bounds__(64) void lz_subblocks(const uint8_t* text, const qd
         for (int k = 0; k < 19; ++k) put(ord[k] < 16 ? 4 : 0, 3);  // lengths 0..15 as 4-bit codes, no run-length symbols
         for (int s = 0; s < nl; ++s) put(rev_bits(llen[s], 4), 4);
         for (int s = 0; s < nd; ++s) put(rev_bits(dlen[s], 4), 4);
+        carry_word = (uint32_t)acc;
+        carry_bits = (uint32_t)cnt;
         // the block must fit its slot: header, symbols + extra bits, end of block, the empty stored block
         uint64_t bits = 3 + 14 + 19 * 3 + 4 * (uint64_t)(nl + nd);
         for (int s = 0; s < LZ_NL; ++s) bits += (uint64_t)lfreq[s] * (llen[s] + (s > 256 ? len_extra_bits((uint32_t)s) : 0u));
         for (int s = 0; s < LZ_ND; ++s) bits += (uint64_t)dfreq[s] * (dlen[s] + dist_extra_bits((uint32_t)s));
         ctl[0] = (uint32_t)wi;
         ctl[1] = ((bits + 7) / 8 + 3 + 4 + 8 <= (uint64_t)sub_stride) ? 1u : 0u;
-        ctl[2] = (uint32_t)acc;  // the partial word carried into the encode loop
-        ctl[3] = (uint32_t)cnt;
     }
     __syncthreads();
     uint32_t out_word = ctl[0];
     if (ctl[1] == 0) {
-        if (lane == 0) sub_bytes[blockIdx.x] = 0;
+        if (tid == 0) sub_bytes[blockIdx.x] = 0;
         return;
     }
-    // 4. encode, 64 tokens per step (carry: the bits of the last, partial word -- wave-uniform registers)
-    uint32_t cw = ctl[2], cb = ctl[3];
-    for (uint32_t g0 = 0; g0 < ntok; g0 += 64) {
-        const uint32_t g = g0 + lane;
+    // 4. encode: the waves' token lists one after the other, 256 tokens per step
+    uint32_t pre[LZ_WAVES + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int i = 0; i < LZ_WAVES; ++i) pre[i + 1] = pre[i] + wave_ntok[i];
+    const uint32_t T = pre[LZ_WAVES];
+    for (uint32_t g0 = 0; g0 < T; g0 += LZ_BLOCK) {
+        const uint32_t g = g0 + tid;
         uint64_t b = 0;
         uint32_t nb = 0;
-        if (g < ntok) {
-            const uint32_t t = tok[g];
+        if (g < T) {
+            uint32_t wv = 0;
+#pragma unroll
+            for (int i = 1; i < LZ_WAVES; ++i) wv += g >= pre[i] ? 1u : 0u;
+            const uint32_t t = tok0[(size_t)wv * LZ_REG + (g - pre[wv])];
             if (t & 0x80000000u) {
                 const uint32_t e = llut[t & 0xFFu];
                 b = e >> 8;
@@ -660,12 +689,21 @@ __global__ __launch_bounds__(64) void lz_subblocks(const uint8_t* text, const qd
             const uint32_t y = __shfl_up(x, d, 64);
             if (lane >= (uint32_t)d) x += y;
         }
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+        if (lane == 63) scan[wave] = x;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < LZ_WAVES; ++i) {
+            const uint32_t v = scan[i];
+            if ((uint32_t)i < wave) before += v;
+            total += v;
+        }
+        const uint32_t cb = carry_bits, cw = carry_word;
         const uint32_t nwords = (cb + total + 31) >> 5;
-        for (uint32_t i = lane; i <= nwords + 2; i += 64) words[i] = i == 0 ? cw : 0;
+        for (uint32_t i = tid; i <= nwords + 2; i += LZ_BLOCK) words[i] = i == 0 ? cw : 0;
         __syncthreads();
         if (nb) {
-            const uint32_t pos = cb + x - nb, w0 = pos >> 5, sh = pos & 31u;
+            const uint32_t pos = cb + before + x - nb, w0 = pos >> 5, sh = pos & 31u;
             const uint64_t lo = b << sh;
             const uint32_t hi = sh ? (uint32_t)(b >> (64 - sh)) : 0u;
             if ((uint32_t)lo) atomicOr(&words[w0], (uint32_t)lo);
@@ -674,16 +712,19 @@ __global__ __launch_bounds__(64) void lz_subblocks(const uint8_t* text, const qd
         }
         __syncthreads();
         const uint32_t full = (cb + total) >> 5;
-        for (uint32_t i = lane; i < full; i += 64) dst[out_word + i] = words[i];
-        cw = words[full];
-        cb = (cb + total) & 31u;
+        for (uint32_t i = tid; i < full; i += LZ_BLOCK) dst[out_word + i] = words[i];
+        __syncthreads();
+        if (tid == 0) {
+            carry_word = words[full];
+            carry_bits = (cb + total) & 31u;
+        }
         out_word += full;
         __syncthreads();
     }
     // end of block; then an empty stored block puts the next sub-block on a byte boundary
-    if (lane == 0) {
-        uint64_t acc = cw;
-        int cnt = (int)cb;
+    if (tid == 0) {
+        uint64_t acc = carry_word;
+        int cnt = (int)carry_bits;
         const uint32_t e = llut[256];
         acc |= (uint64_t)(e >> 8) << cnt;
         cnt += (int)(e & 0xFFu);
@@ -703,39 +744,49 @@ __global__ __launch_bounds__(64) void lz_subblocks(const uint8_t* text, const qd
     }
 }
 
-// member i = gzip header | the piece's sub-blocks first_sub[i] .. first_sub[i + 1] | an empty final block | CRC-32, ISIZE
-__global__ __launch_bounds__(256) void lz_members(const qd_deflate_piece* pieces, const uint32_t* first_sub, const uint8_t* sub_out,
-                                                  int64_t sub_stride, const uint32_t* sub_bytes, uint8_t* out, int64_t out_stride,
-                                                  uint32_t* out_bytes) {
-    const uint32_t j0 = first_sub[blockIdx.x], j1 = first_sub[blockIdx.x + 1];
-    uint64_t total = 10 + 2 + 8;
+// member i = gzip header | the piece's sub-blocks first_sub[i] .. first_sub[i + 1] | an empty final block | CRC-32, ISIZE.
+// One workgroup per sub-block copies it to its place (the sum of its predecessors' lengths); a piece without text has none:
+// its member is made by the workgroups behind the sub-blocks (blockIdx - n_subs = the piece).
+__global__ __launch_bounds__(256) void lz_members(const qd_deflate_piece* pieces, const qd_lz_sub* subs, const uint32_t* first_sub, uint32_t n_subs,
+                                                  const uint8_t* sub_out, int64_t sub_stride, const uint32_t* sub_bytes, uint8_t* out,
+                                                  int64_t out_stride, uint32_t* out_bytes) {
+    const bool empty = blockIdx.x >= n_subs;
+    const uint32_t piece = empty ? blockIdx.x - n_subs : subs[blockIdx.x].piece;
+    const uint32_t j0 = first_sub[piece], j1 = first_sub[piece + 1], j = blockIdx.x;
+    if (empty && j1 != j0) return;
+    uint64_t total = 10 + 2 + 8, off = 10;
     bool ok = true;
-    for (uint32_t j = j0; j < j1; ++j) {
-        const uint32_t n = sub_bytes[j];
+    for (uint32_t k = j0; k < j1; ++k) {
+        const uint32_t n = sub_bytes[k];
         ok = ok && n > 0;
         total += n;
+        if (k < j) off += n;
     }
+    const bool first = empty || j == j0, last = empty || j + 1 == j1;
     if (!ok || total > (uint64_t)out_stride) {
-        if (threadIdx.x == 0) out_bytes[blockIdx.x] = 0;
+        if (first && threadIdx.x == 0) out_bytes[piece] = 0;
         return;
     }
-    uint8_t* dst = out + (int64_t)blockIdx.x * out_stride;
-    uint64_t off = 10;
-    for (uint32_t j = j0; j < j1; ++j) {
+    uint8_t* dst = out + (int64_t)piece * out_stride;
+    if (!empty) {
         const uint32_t n = sub_bytes[j];
         const uint8_t* s = sub_out + (int64_t)j * sub_stride;
         for (uint32_t k = threadIdx.x; k < n; k += 256) dst[off + k] = s[k];
         off += n;
     }
     if (threadIdx.x == 0) {
-        const uint8_t head[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff};
-        for (int i = 0; i < 10; ++i) dst[i] = head[i];
-        dst[off++] = 0x03;  // BFINAL 1, fixed Huffman, end of block
-        dst[off++] = 0x00;
-        const uint32_t c = pieces[blockIdx.x].crc32, isz = pieces[blockIdx.x].text_len;
-        for (int i = 0; i < 4; ++i) dst[off++] = (uint8_t)(c >> (8 * i));
-        for (int i = 0; i < 4; ++i) dst[off++] = (uint8_t)(isz >> (8 * i));
-        out_bytes[blockIdx.x] = (uint32_t)off;
+        if (first) {
+            const uint8_t head[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff};
+            for (int i = 0; i < 10; ++i) dst[i] = head[i];
+        }
+        if (last) {
+            dst[off++] = 0x03;  // BFINAL 1, fixed Huffman, end of block
+            dst[off++] = 0x00;
+            const uint32_t c = pieces[piece].crc32, isz = pieces[piece].text_len;
+            for (int i = 0; i < 4; ++i) dst[off++] = (uint8_t)(c >> (8 * i));
+            for (int i = 0; i < 4; ++i) dst[off++] = (uint8_t)(isz >> (8 * i));
+            out_bytes[piece] = (uint32_t)off;
+        }
     }
 }
 }  // namespace
@@ -744,12 +795,12 @@ hipError_t qd_launch_lz(const uint8_t* text, const qd_deflate_piece* pieces, uin
                         uint32_t n_subs, uint32_t* tokens, uint8_t* sub_out, int64_t sub_stride, uint32_t* sub_bytes, uint8_t* out,
                         int64_t out_stride, uint32_t* out_bytes, hipStream_t st) {
     if (n_pieces == 0) return hipSuccess;
-    constexpr size_t lds = (size_t)LZ_TEXT_WORDS * 4 + (8u << LZ_HASH_BITS);
+    constexpr size_t lds = (size_t)LZ_TEXT_WORDS * 4 + (4u << LZ_HASH_BITS);
     static_assert(LZ_TEXT_WORDS % 4 == 0, "the text is staged 16 bytes at a time");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lz_subblocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (n_subs) hipLaunchKernelGGL(lz_subblocks, dim3(n_subs), dim3(64), lds, st, text, subs, tokens, sub_out, sub_stride, sub_bytes);
-    hipLaunchKernelGGL(lz_members, dim3(n_pieces), dim3(256), 0, st, pieces, first_sub, sub_out, sub_stride, sub_bytes, out, out_stride,
-                       out_bytes);
+    if (n_subs) hipLaunchKernelGGL(lz_subblocks, dim3(n_subs), dim3(LZ_BLOCK), lds, st, text, subs, tokens, sub_out, sub_stride, sub_bytes);
+    hipLaunchKernelGGL(lz_members, dim3(n_subs + n_pieces), dim3(256), 0, st, pieces, subs, first_sub, n_subs, sub_out, sub_stride, sub_bytes,
+                       out, out_stride, out_bytes);
     return hipGetLastError();
 }

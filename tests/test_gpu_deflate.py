@@ -140,9 +140,9 @@ def _unzip_dir(d):
     return {f: gzip.open(os.path.join(d, f)).read() for f in sorted(os.listdir(d)) if f.endswith(".fastq.gz")}
 
 
-@pytest.mark.parametrize("fail_after", [None, "1"])
-def test_cli_with_device_deflate_writes_the_same_files(tmp_path, monkeypatch, fail_after):
-    """`[gpu] gzip_level : -1` + `device_deflate : True` through the command line driver: same decompressed files and
+@pytest.mark.parametrize("fail_after,level", [(None, -1), ("1", -1), (None, 1), ("1", 1)])
+def test_cli_with_device_deflate_writes_the_same_files(tmp_path, monkeypatch, fail_after, level):
+    """`[gpu] gzip_level : -1` (or 1) + `device_deflate : True` through the command line driver: same decompressed files and
     report as with the host's coder, and the GPU really made members.  fail_after: the device "fails" after its
     first batch (test hook) -- the pieces already queued and all later ones are coded by the host, nothing is lost."""
     from quade_amd import synth
@@ -155,7 +155,7 @@ def test_cli_with_device_deflate_writes_the_same_files(tmp_path, monkeypatch, fa
     outs = {}
     for mode in ("False", "True"):
         conf = os.path.join(work, "conf_%s.txt" % mode)
-        synth.write_conf(conf, paths, bcs, 2, gpu="[gpu]\nbatch_pairs : 50000\ngzip_level : -1\ndevice_deflate : %s\n" % mode)
+        synth.write_conf(conf, paths, bcs, 2, gpu="[gpu]\nbatch_pairs : 50000\ngzip_level : %d\ndevice_deflate : %s\n" % (level, mode))
         out = os.path.join(work, "out_" + mode)
         os.mkdir(out)
         cwd = os.getcwd()
@@ -169,7 +169,8 @@ def test_cli_with_device_deflate_writes_the_same_files(tmp_path, monkeypatch, fa
     assert outs["True"][1][0] == 240_000 and len(outs["True"][0]) > 20
 
 
-def test_sink_shares_pieces_between_device_and_host(tmp_path):
+@pytest.mark.parametrize("level", [-1, 1])
+def test_sink_shares_pieces_between_device_and_host(tmp_path, level):
     """The native sink with a deflate device: pieces go to the GPU while page-locked buffers last, to the pool's threads
     otherwise; either way the files equal the host-only sink's after decompression, and device_members says how many
     the GPU made."""
@@ -183,7 +184,7 @@ def test_sink_shares_pieces_between_device_and_host(tmp_path):
     for dev in (-1, 0):
         o = tmp_path / ("out%d" % dev)
         o.mkdir()
-        sink = FastqSink(str(o), names, -1, quiet=True, deflate_device=dev)
+        sink = FastqSink(str(o), names, level, quiet=True, deflate_device=dev)
         s1, s2 = FastqStream(paths["seq_R1"], 50_000), FastqStream(paths["seq_R2"], 50_000)
         r = np.random.default_rng(6)
         while True:

@@ -1,14 +1,19 @@
-// CPU model of the parse of quade_deflate.hip's lz_subblocks (the device's `gzip_level : 1`): same sub-blocks, 64-position
-// stretches (look-ups before inserts), buckets of last positions, run candidate, 32-byte views, the rule for matches inside
-// the sequence lines, lazy walk -- and the size the two Huffman codes would give it.  For tuning the parse's choices without
-// a GPU (the defaults are the kernel's; the first version of the kernel was waves=4 ways=1 hash=14 nice=0 lazy=0 dna=0: four
-// waves on quarters of a sub-block, 31.8 % of the text on binned-quality records where this form makes 19.5 %); the device's
-// members are checked with zlib by tests/test_gpu_deflate.py.
+// CPU model of the parse of quade_deflate.hip's lz_subblocks (the device's `gzip_level : 1`): same sub-blocks, rounds of
+// look-ups (a position sees what was entered up to the round before its own), buckets of last positions, run candidate, 32-byte
+// views, the rule for matches inside the sequence lines, lazy walk cut into quarters -- and the size the two Huffman codes
+// would give it.  For tuning the parse's choices without a GPU; the defaults are the kernel's.  Its history on 2 MB of
+// binned-quality records (zlib level 1: 22.5 % of the text, level 6: 19.0 %):
+//   waves=4 look=64 cut=0 ways=1 hash=14 nice=0 lazy=0 dna=0 run=0   31.8 %  four waves on quarters of a sub-block, side by side
+//   waves=1 look=64 cut=0 ways=4 hash=12 run=0                         19.5 %  one wave per sub-block (complete history): 10 ms per 64 MB
+//   (defaults)                                                           18.8 %  the run candidate always compared, rounds of 256
+// The device's members are checked with zlib by tests/test_gpu_deflate.py.
 //   g++ -O2 -o /tmp/lz_model tools/lz_model.cpp && /tmp/lz_model text [key=value ...]
-//   keys: sub (65536) waves (1: regions of a sub-block parsed side by side) hash (12) ways (4) minlen (4) nice (32) lazy (1)
-//         dna (12: least length of a match that covers only ACGTN) hist (0: bytes of history before the sub-block)
-//         far (0: a match of < far_len bytes farther than `far` is dropped) far_len (0)
+//   keys: sub (65536) look (256: positions looked up before any of them is entered) cut (16384: the walk's regions)
+//         hash (11) ways (2) run (1: distance 1 always compared) minlen (4) nice (32) lazy (1)
+//         dna (12: least length of a match that covers only ACGTN) waves (1: > 1 = regions looked up side by side, the first form)
+//         hist (0: bytes of history before the sub-block) far (0: a match of < far_len bytes farther than `far` is dropped) far_len (0)
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -19,9 +24,9 @@
 #include <string>
 #include <vector>
 
-static std::map<std::string, long> opt = {{"sub", 65536}, {"waves", 1},  {"hash", 12},   {"minlen", 4}, {"ways", 4},
+static std::map<std::string, long> opt = {{"sub", 65536}, {"waves", 1},  {"hash", 11},   {"minlen", 4}, {"ways", 2},
                                           {"hist", 0},    {"lazy", 1},   {"far", 0},     {"far_len", 0}, {"maxlen", 256},
-                                          {"dna", 12},    {"nice", 32}};
+                                          {"dna", 12},    {"nice", 32},  {"look", 256}, {"cut", 16384}, {"run", 1}};
 
 static double huff_bits(const std::vector<uint64_t>& f) {  // total bits of an (unlimited) Huffman code for these counts
     std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> q;
@@ -70,7 +75,7 @@ int main(int argc, char** argv) {
     while ((r = fread(buf, 1, sizeof buf, f)) > 0) text.insert(text.end(), buf, buf + r);
     fclose(f);
     const long SUB = opt["sub"], W = opt["waves"], HB = opt["hash"], MINLEN = opt["minlen"], WAYS = opt["ways"], HIST = opt["hist"],
-               MAXLEN = opt["maxlen"], LAZY = opt["lazy"], FAR = opt["far"], FAR_LEN = opt["far_len"], DNA = opt["dna"], NICE = opt["nice"];
+               MAXLEN = opt["maxlen"], LAZY = opt["lazy"], FAR = opt["far"], FAR_LEN = opt["far_len"], DNA = opt["dna"], NICE = opt["nice"], LOOK = opt["look"], CUT = opt["cut"], RUN = opt["run"];
     const size_t N = text.size();
     text.resize(N + 512, 0);
     double total_bits = 0;
@@ -103,18 +108,50 @@ int main(int argc, char** argv) {
             while (n < maxlen && t[p + n] == t[c + n]) ++n;
             return n;
         };
+        // look > 64: the candidates of `look` positions are looked up before any of them is entered (the kernel's rounds of
+        // several waves); cut > 0: the walk is cut every `cut` bytes (regions walked side by side after the look-ups)
+        std::vector<std::array<long, 8>> pre;
+        if (LOOK > 64) {
+            pre.assign((size_t)L + 64, std::array<long, 8>{-1, -1, -1, -1, -1, -1, -1, -1});
+            for (long r0 = 0; r0 < L; r0 += LOOK) {
+                for (long p = r0; p < std::min(r0 + LOOK, L); ++p) {
+                    if (p + 4 > L) continue;
+                    const int32_t* bk = &table[(size_t)hash(p) * WAYS];
+                    long nc = 0;
+                    for (long k = 0; k < WAYS; ++k) {
+                        const long c = bk[k];
+                        if (c < p && p - c <= 32768 && c >= -H && memcmp(t + c, t + p, 4) == 0) pre[p][nc++] = c;
+                    }
+                    if ((nc == 0 || (RUN && nc < 8)) && p - 1 >= -H && memcmp(t + p - 1, t + p, 4) == 0) {
+                        if (RUN) {  // the nearest candidate: first
+                            for (long k = nc; k > 0; --k) pre[p][k] = pre[p][k - 1];
+                            pre[p][0] = p - 1;
+                            ++nc;
+                        } else
+                            pre[p][nc++] = p - 1;
+                    }
+                }
+                for (long p = r0; p < std::min(r0 + LOOK, L); ++p)
+                    if (p + 4 <= L) insert(p);
+            }
+        }
         bool any = true;
         while (any) {
             any = false;
             for (long w = 0; w < W; ++w) {  // the waves advance in lockstep, one stretch each
-                const long rend = std::min((w + 1) * REG, L);
+                long rend = std::min((w + 1) * REG, L);
+                if (CUT) rend = std::min(rend, (base[w] / CUT + 1) * CUT);  // (with waves=1: regions of `cut` bytes one after the other)
                 if (base[w] >= rend) continue;
                 any = true;
                 const long b0 = base[w], limit = std::min<long>(64, rend - b0);
-                long cand[64][4];
+                long cand[64][8];
                 for (long i = 0; i < 64; ++i) {  // look-ups of the whole stretch first
                     const long p = b0 + i;
-                    for (long k = 0; k < 4; ++k) cand[i][k] = -1;
+                    for (long k = 0; k < 8; ++k) cand[i][k] = -1;
+                    if (LOOK > 64) {
+                        if (p < L) for (long k = 0; k < 8; ++k) cand[i][k] = pre[p][k];
+                        continue;
+                    }
                     if (p + 4 > L) continue;
                     const int32_t* bk = &table[(size_t)hash(p) * WAYS];
                     long nc = 0;
@@ -122,9 +159,16 @@ int main(int argc, char** argv) {
                         const long c = bk[k];
                         if (c < p && p - c <= 32768 && c >= -H && memcmp(t + c, t + p, 4) == 0) cand[i][nc++] = c;
                     }
-                    if (nc == 0 && p - 1 >= -H && memcmp(t + p - 1, t + p, 4) == 0) cand[i][nc++] = p - 1;
+                    if ((nc == 0 || (RUN && nc < 8)) && p - 1 >= -H && memcmp(t + p - 1, t + p, 4) == 0) {
+                        if (RUN) {
+                            for (long k = nc; k > 0; --k) cand[i][k] = cand[i][k - 1];
+                            cand[i][0] = p - 1;
+                            ++nc;
+                        } else
+                            cand[i][nc++] = p - 1;
+                    }
                 }
-                for (long i = 0; i < 64; ++i)
+                for (long i = 0; i < 64 && LOOK <= 64; ++i)
                     if (b0 + i + 4 <= L) insert(b0 + i);
                 // capped: the lane's own view (candidates compared up to `nice` bytes); the walk extends the chosen one fully
                 auto best_at = [&](long s, long& blen, long& bdist, bool capped) {
@@ -133,7 +177,7 @@ int main(int argc, char** argv) {
                     if (s >= 64) return;
                     const long ps = b0 + s, maxlen = std::min<long>(MAXLEN, rend - ps);
                     long bcap = 0;
-                    for (long k = 0; k < 4 && cand[s][k] != -1; ++k) {
+                    for (long k = 0; k < 8 && cand[s][k] != -1; ++k) {
                         const long n = match_len(ps, cand[s][k], NICE ? std::min(NICE, maxlen) : maxlen);
                         if (n > bcap) bcap = n, bdist = ps - cand[s][k];
                     }
