@@ -202,11 +202,12 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
             shutil.rmtree(out, ignore_errors=True)
             return dt, cpu_s, counts, out_bytes
 
-        dt, cpu_s, counts, out_bytes = run(gzip_level, "lvl")
+        dt, cpu_s, counts, out_bytes = run(gzip_level, "lvl")  # (level 1: its members are made on the GPU -- LZ77 + Huffman, quade_deflate.hip)
+        dt_1h, cpu_1h, counts_1h, out_bytes_1h = run(gzip_level, "lvlhost", "device_deflate : False\n")  # ... and by the host's pool alone
         # the same job with gzip_level -1: output members are one dynamic-Huffman block of literals (no string matching)
         dt_h, cpu_h, counts_h, out_bytes_h = run(-1, "huff")  # (its members are made on the GPU: [gpu] device_deflate, the default)
         dt_hh, cpu_hh, counts_hh, _ = run(-1, "huffhost", "device_deflate : False\n")  # ... and by the host's pool alone
-        # ... at the driver's own default output level (conf.py: gzip_level 6; the reference's gzip.open default is 9)
+        # ... at gzip level 6 on the host's pool (the driver's default was 6 until the device coded level 1; the reference's gzip.open default is 9)
         dt_6, cpu_6, counts_6, out_bytes_6 = run(6, "lvl6")
         in_bytes = sum(os.path.getsize(p) for p in paths.values()) * n_chunks
         # ... and on the reference's real input format: every input file ONE ordinary gzip member (src/Quade.py:203-206
@@ -237,9 +238,13 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
                      "same records, every input file ONE gzip member (the reference's input format), inflated by the "
                      "parallel gunzip (speculative chunks over a marker window, proven by the chain)",
                      input_gz_bytes=in_bytes_s, output_gz_bytes=out_bytes_s, vs_bgzf_input=(n / dt_s) / (n / dt))
-        lvl6 = sub(dt_6, cpu_6, counts_6, 6, "same BGZF input, [gpu] gzip_level : 6 (the driver's default output level)",
+        lvl6 = sub(dt_6, cpu_6, counts_6, 6, "same BGZF input, [gpu] gzip_level : 6 (libdeflate on the host's pool; the driver's default is 1 = the level the device codes)",
                    output_gz_bytes=out_bytes_6)
-        return {"value": n / dt, "huffman_only": huff, "single_member_gzip": single, "default_level": lvl6, "unit": "read-pairs/s", "pairs": n, "chunks": n_chunks, "seconds": dt, "gzip_level": gzip_level,
+        host1 = sub(dt_1h, cpu_1h, counts_1h, gzip_level, "same input and level, [gpu] device_deflate : False (libdeflate on the pool's threads)",
+                    output_gz_bytes=out_bytes_1h)
+        return {"value": n / dt, "host_pool_only": host1,
+                "members_made_by": "the GPU (quade_deflate.hip: LZ77 + dynamic Huffman) while page-locked buffers last, the host's pool otherwise",
+                "huffman_only": huff, "single_member_gzip": single, "host_level6": lvl6, "default_level": gzip_level, "unit": "read-pairs/s", "pairs": n, "chunks": n_chunks, "seconds": dt, "gzip_level": gzip_level,
                 "samples": len(bcs), "gzip_backend": io_backend(), "io_threads": io_threads(), "host_cores": host_cores(),
                 "input_gz_bytes": in_bytes, "output_gz_bytes": out_bytes, "counts_total_pass_fail_undetermined": counts,
                 "dataset_seconds": t_gen,

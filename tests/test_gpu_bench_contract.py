@@ -50,13 +50,14 @@ def test_single_gpu_line():
     assert e["pairs"] == 30000 and e["value"] > 0 and e["gzip_level"] == 1 and e["gzip_backend"] in ("libdeflate", "zlib")
     assert e["counts_total_pass_fail_undetermined"][0] == 30000 == sum(e["counts_total_pass_fail_undetermined"][1:])
     assert e["cpu_seconds"] > 0 and 0 < e["core_utilisation"] <= 1.05
+    assert e["host_pool_only"]["value"] > 0 and e["host_pool_only"]["counts_equal"] is True and e["host_pool_only"]["gzip_level"] == 1
     h = e["huffman_only"]
     assert h["gzip_level"] == -1 and h["value"] > 0 and h["counts_equal"] is True and h["output_gz_bytes"] > 0
     assert h["host_pool_only"]["value"] > 0 and h["host_pool_only"]["counts_equal"] is True
     # the reference's real input format (one gzip member per file) and the driver's default output level, same line
     sm1 = e["single_member_gzip"]
     assert sm1["value"] > 0 and sm1["counts_equal"] is True and sm1["gzip_level"] == 1 and sm1["vs_bgzf_input"] > 0
-    assert e["default_level"]["gzip_level"] == 6 and e["default_level"]["counts_equal"] is True
+    assert e["host_level6"]["gzip_level"] == 6 and e["host_level6"]["counts_equal"] is True and e["default_level"] == 1
     # hygiene: what ran as warm-up, the step-based fraction beside the event-based one
     assert j["warmup_ran"] == j["untimed_launches"] and 0 < r["frac_by_step"] <= r["frac"] * 1.001
     assert "traffic_age_commit" in r
