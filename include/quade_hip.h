@@ -322,6 +322,10 @@ int qd_sink_close(qd_sink* sink); /* flush + destroy */
  * text, 0 = one member, -1 = BGZF blocks (bgzip / htslib layout: 64 KiB members that carry their size in a
  * 'BC' extra subfield, closed by the empty end-of-file block).  Tooling (synthetic inputs); no reference
  * counterpart. */
+/* Where the host's CPU time goes (measurement): thread-CPU seconds per stage of the reader, the sink and the pool since the
+ * process started or since the last call with reset != 0, summed over all threads of the library.  names[i] (static strings)
+ * and seconds[i] for i < the return value (<= cap); either array may be NULL. */
+int qd_io_stage_seconds(const char** names, double* seconds, int32_t cap, int32_t reset);
 int qd_write_gzip_file(const char* path, const uint8_t* data, int64_t n_bytes, int32_t level, int64_t member_bytes);
 
 /* ---- host I/O: fastq(.gz) file -> batches of whole records ----------------------------------------------

@@ -86,6 +86,41 @@ LibDeflate& deflate_lib() {
     return L;
 }
 
+// ---- where the host's CPU time goes: thread-CPU seconds per stage, summed over all threads of the library -----------
+// (qd_io_stage_seconds; two clock reads per job or per 4 MB piece -- nothing per record)
+enum Stage { ST_INFLATE, ST_READ, ST_SCAN_COPY, ST_SCAN_LINES, ST_SCAN_RECORDS, ST_SCATTER, ST_FORMAT, ST_CRC, ST_DEFLATE, ST_LANE, ST_APPEND,
+             ST_COUNT };
+const char* const STAGE_NAMES[ST_COUNT] = {"inflate (pool jobs)", "read + cut input (reader threads)", "scanner: copy into the batch",
+                                           "scanner: newlines", "scanner: records + batch hand-over", "sink: scatter by code",
+                                           "sink: format records", "sink: CRC-32", "sink: deflate on the host",
+                                           "device lanes: launch, wait, copy members", "file appends"};
+std::atomic<int64_t> g_stage_ns[ST_COUNT];
+inline int64_t thread_cpu_ns() {
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (int64_t)ts.tv_sec * 1000000000 + ts.tv_nsec;
+}
+thread_local int g_stage_depth = 0;
+struct StageTimer {  // the outermost timer of a thread counts; one opened inside it is part of it
+    Stage st;
+    int64_t t0 = 0;
+    bool active;
+    explicit StageTimer(Stage s) : st(s), active(g_stage_depth++ == 0) {
+        if (active) t0 = thread_cpu_ns();
+    }
+    void next(Stage s) {  // closes the running stage, opens another
+        if (!active) return;
+        const int64_t t = thread_cpu_ns();
+        g_stage_ns[st].fetch_add(t - t0, std::memory_order_relaxed);
+        st = s;
+        t0 = t;
+    }
+    ~StageTimer() {
+        --g_stage_depth;
+        if (active) g_stage_ns[st].fetch_add(thread_cpu_ns() - t0, std::memory_order_relaxed);
+    }
+};
+
 }  // namespace
 
 // CRC-32 of a buffer (gzip's): libdeflate's slice-by-N when loaded, zlib's otherwise.  Used by the device inflater
@@ -460,6 +495,7 @@ void sink_error(qd_sink* s, const std::string& msg) {
 }
 
 bool append_file(const std::string& path, const Bytes& data, std::string& why) {
+    StageTimer timer(ST_APPEND);
     const int fd = open(path.c_str(), O_WRONLY | O_APPEND | O_CREAT | O_CLOEXEC, 0644);
     if (fd < 0) {
         why = path + ": " + strerror(errno);
@@ -627,6 +663,7 @@ class DeflateService {
             }
             bool ok = usable && !(fail_after >= 0 && batches >= fail_after);
             int64_t stride = 0;
+            StageTimer lane_timer(ST_LANE);
             if (ok && b[0].level != -1) ok = qd_deflater_set_level && qd_deflater_set_level(def, b[0].level) == QD_OK;
             else if (ok && qd_deflater_set_level) (void)qd_deflater_set_level(def, -1);
             if (ok) {
@@ -646,12 +683,17 @@ class DeflateService {
                 if (dev) {
                     member.resize((size_t)ml[i]);
                     memcpy(member.data(), out.data() + (size_t)stride * i, (size_t)ml[i]);
-                } else if (!gzip_member(b[i].text, (size_t)b[i].len, b[i].level, member)) {
-                    sink_error(b[i].s, "gzip compression failed");
-                    member.clear();
+                } else {
+                    lane_timer.next(ST_DEFLATE);
+                    if (!gzip_member(b[i].text, (size_t)b[i].len, b[i].level, member)) {
+                        sink_error(b[i].s, "gzip compression failed");
+                        member.clear();
+                    }
                 }
+                lane_timer.next(ST_APPEND);  // (finish_piece delivers: the appends open their own timer, this one only idles)
                 give_buffer(b[i].text);
                 finish_piece(b[i].s, b[i].f, b[i].seq, b[i].text_bytes, b[i].len, std::move(member), dev);
+                lane_timer.next(ST_LANE);
             }
         }
     }
@@ -692,6 +734,19 @@ DeflateService* deflate_service(int device) {
 }  // namespace
 
 extern "C" {
+
+/* Thread-CPU seconds per stage of the host I/O since the process started (or since the last call with reset != 0), summed over
+ * all threads of the library: names[i] -> seconds[i], i < the return value (<= cap). */
+int qd_io_stage_seconds(const char** names, double* seconds, int32_t cap, int32_t reset) {
+    int n = 0;
+    for (; n < ST_COUNT && n < cap; ++n) {
+        if (names) names[n] = STAGE_NAMES[n];
+        if (seconds) seconds[n] = (double)g_stage_ns[n].load(std::memory_order_relaxed) * 1e-9;
+    }
+    if (reset)
+        for (int i = 0; i < ST_COUNT; ++i) g_stage_ns[i].store(0, std::memory_order_relaxed);
+    return n;
+}
 
 int qd_io_threads(int32_t n_threads) {
     std::lock_guard<std::mutex> g(g_pool_mutex);
@@ -783,6 +838,7 @@ static int route_impl(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_
         tag_len = res->tag_len.data();
     }
     // 1. counting scatter by routing code (src/Sample.py:74-91 decides per pair; here per batch), stable
+    std::unique_ptr<StageTimer> scatter_timer(new StageTimer(ST_SCATTER));
     const uint32_t S = (uint32_t)s->names.size(), nb = 2 * S + 1;
     std::vector<int64_t> start(nb + 1, 0);
     for (int64_t i = 0; i < n; ++i) {
@@ -846,6 +902,7 @@ static int route_impl(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_
             }
         }
     }
+    scatter_timer.reset();
     if (pieces.empty()) return QD_OK;
     // 3. back-pressure, then one job per piece: format (until then `order`, the texts and the tags
     //    are needed: this call waits for that), compress, deliver in order
@@ -868,12 +925,21 @@ static int route_impl(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_
                 const size_t need = (size_t)p.text_bytes + 8 * (size_t)p.n_sel + 16;
                 uint8_t* buf = need <= DeflateService::BUF_BYTES ? sv->take_buffer() : nullptr;
                 if (buf) {
-                    const int64_t w = qd_format_records(p.text, p.rec_off, p.sel, p.n_sel, tag_rows, tag_stride, tag_len, buf,
-                                                        (int64_t)DeflateService::BUF_BYTES);
+                    int64_t w;
+                    {
+                        StageTimer timer(ST_FORMAT);
+                        w = qd_format_records(p.text, p.rec_off, p.sel, p.n_sel, tag_rows, tag_stride, tag_len, buf,
+                                              (int64_t)DeflateService::BUF_BYTES);
+                    }
                     res->formatted.done();
                     res.reset();
                     if (w >= 0) {
-                        sv->submit(DevPiece{s, p.f, p.seq, p.text_bytes, buf, DeflateService::BUF_BYTES, w, qd_io_crc32(buf, (size_t)w), s->level});
+                        uint32_t crc;
+                        {
+                            StageTimer timer(ST_CRC);
+                            crc = qd_io_crc32(buf, (size_t)w);
+                        }
+                        sv->submit(DevPiece{s, p.f, p.seq, p.text_bytes, buf, DeflateService::BUF_BYTES, w, crc, s->level});
                     } else {
                         sv->give_buffer(buf);
                         sink_error(s, "qd_format_records failed (malformed record text)");
@@ -886,15 +952,21 @@ static int route_impl(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_
             Bytes member;
             text.clear();
             text.resize((size_t)p.text_bytes + 8 * (size_t)p.n_sel + 16);
-            const int64_t w = qd_format_records(p.text, p.rec_off, p.sel, p.n_sel, tag_rows, tag_stride, tag_len, text.data(),
-                                                (int64_t)text.size());
+            int64_t w;
+            {
+                StageTimer timer(ST_FORMAT);
+                w = qd_format_records(p.text, p.rec_off, p.sel, p.n_sel, tag_rows, tag_stride, tag_len, text.data(), (int64_t)text.size());
+            }
             res->formatted.done();
             res.reset();  // nothing of the batch is touched after this line: the last job to get here frees it
             bool ok = w >= 0;
             if (!ok) sink_error(s, "qd_format_records failed (malformed record text)");
-            if (ok && !gzip_member(text.data(), (size_t)w, s->level, member)) {
-                sink_error(s, "gzip compression failed");
-                ok = false;
+            if (ok) {
+                StageTimer timer(ST_DEFLATE);
+                if (!gzip_member(text.data(), (size_t)w, s->level, member)) {
+                    sink_error(s, "gzip compression failed");
+                    ok = false;
+                }
             }
             if (!ok) member.clear();  // keep the file's sequence moving
             finish_piece(s, p.f, p.seq, p.text_bytes, w, std::move(member), false);
@@ -1139,9 +1211,11 @@ bool scan_records(qd_reader* r) {
         // every newline of the text fed so far, then records four lines at a time (same rules as next_record():
         // a record whose sequence and quality lengths differ is dropped, a trailing '\r' is not part of a line)
         if (r->nl_from < r->fill) {
+            StageTimer timer(ST_SCAN_LINES);
             newlines(b->text, r->nl_from, r->fill, r->nls);
             r->nl_from = r->fill;
         }
+        StageTimer timer(ST_SCAN_RECORDS);
         const uint8_t* t = b->text;
         while (b->n < r->B && r->nl_at + 4 <= r->nls.size()) {
             const int64_t* e = &r->nls[r->nl_at];
@@ -1203,7 +1277,10 @@ bool feed(qd_reader* r, const uint8_t* d, size_t len) {
             b->text = grown;
             b->cap = cap;
         }
-        memcpy(b->text + r->fill, d, piece);
+        {
+            StageTimer timer(ST_SCAN_COPY);
+            memcpy(b->text + r->fill, d, piece);
+        }
         r->fill += (int64_t)piece;
         r->last = d[piece - 1];
         d += piece;
@@ -1231,6 +1308,7 @@ struct Input {
     // the moves stay a fraction of the bytes consumed.  false on a read error.
     bool refill(size_t want) {
         if (avail() >= want || eof) return true;
+        StageTimer timer(ST_READ);
         if (pos) {
             memmove(buf.data(), buf.data() + pos, avail());
             fill -= pos;
@@ -1304,6 +1382,7 @@ constexpr size_t BGZF_DEVICE_LANES = 3;              // launches in flight per r
 
 // the blocks of a run, one after the other, on this thread
 void host_inflate_run(BgzfRun& run, LibDeflate& L) {
+    StageTimer timer(ST_INFLATE);
     thread_local void* dec = nullptr;
     if (!dec) dec = L.alloc_decompressor();
     size_t ip = 0, op = 0;
@@ -1557,7 +1636,12 @@ bool inflate_parallel(qd_reader* r, int& cur, bool& ok) {
     if (map == MAP_FAILED) return false;
     (void)madvise(map, size, MADV_SEQUENTIAL);
     {
-        qdpgz::Gunzip gz((const uint8_t*)map, size, pgz_options(), [](std::function<void()> fn) { pool().submit(std::move(fn), true); });
+        qdpgz::Gunzip gz((const uint8_t*)map, size, pgz_options(), [](std::function<void()> fn) {
+            pool().submit([fn = std::move(fn)] {
+                StageTimer timer(ST_INFLATE);
+                fn();
+            }, true);
+        });
         while (ok) {
             std::shared_ptr<qdpgz::Text> t;
             const int rc = gz.next(&t);

@@ -104,6 +104,7 @@ SYMBOLS = [
     ("qd_reduce_counts", C.c_int, [_P, _P, C.c_int32]),
     ("qd_comm_destroy", C.c_int, [_P]),
     ("qd_comm_last_error", C.c_char_p, []),
+    ("qd_io_stage_seconds", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     ("qd_write_gzip_file", C.c_int, [C.c_char_p, _P, C.c_int64, C.c_int32, C.c_int64]),
     ("qd_reader_open", C.c_int, [C.c_char_p, C.c_int64, C.c_int32, C.POINTER(_P)]),
     ("qd_reader_open_on", C.c_int, [C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(_P)]),

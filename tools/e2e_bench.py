@@ -59,11 +59,22 @@ try:
     else:
         from quade_amd.quade import Quade
         from quade_amd.sample import Sample
+        import ctypes as _C
+        _lib = _hb.load_library()
+        _names, _secs = (_C.c_char_p * 32)(), (_C.c_double * 32)()
+        _lib.qd_io_stage_seconds(None, None, 0, 1)  # reset: the dataset was written through the same pool
         c0 = os.times()
         t0 = time.perf_counter()
         Quade(conf_file=conf)()
         dt = time.perf_counter() - t0
         c1 = os.times()
+        if os.environ.get("QUADE_PROFILE"):  # thread-CPU seconds of the library's stages (all threads)
+            k = _lib.qd_io_stage_seconds(_names, _secs, 32, 0)
+            tot = (c1.user - c0.user) + (c1.system - c0.system)
+            for i in range(k):
+                print("\t[cpu] %-44s %7.2f s  %5.2f core-s per M pairs" % (_names[i].decode(), _secs[i], _secs[i] / (n * n_chunks / 1e6)))
+            print("\t[cpu] %-44s %7.2f s  %5.2f core-s per M pairs (python main thread, index packing, tags, unaccounted)"
+                  % ("everything else", tot - sum(_secs[:k]), (tot - sum(_secs[:k])) / (n * n_chunks / 1e6)))
         cpu_s = (c1.user - c0.user) + (c1.system - c0.system)  # every thread of this process (readers, pool, main)
         cpu_user, cpu_sys = c1.user - c0.user, c1.system - c0.system
         counts = Sample.COUNTS()[:4]
