@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>  // types only: the library is bound at run time (dlopen), single-GPU users never load it
 
 #include <algorithm>
+#include <unistd.h>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -1131,6 +1132,21 @@ hipError_t grow_pair(T*& h, T*& d, size_t& cap, size_t need) {
     return hipSuccess;
 }
 thread_local std::string g_inflater_error;
+
+// Waits for an event without holding a core: hipEventSynchronize spins on this runtime even for events made with
+// hipEventBlockingSync (measured: the reader's device lanes burnt 0.95 core-seconds per M pairs waiting for their kernels,
+// profiles/r03_e2e_16m_level1_stages_device_inflate.txt).  A few immediate polls (short kernels), then naps of 100 us.
+hipError_t wait_event_napping(hipEvent_t ev) {
+    for (int i = 0; i < 64; ++i) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+    }
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        usleep(100);
+    }
+}
 }  // namespace
 
 extern "C" {
@@ -1248,7 +1264,7 @@ static int inflater_run(qd_inflater* f, const uint8_t* comp, int64_t comp_len, u
     INFCHK(f, hipMemcpyAsync(f->h_st, f->d_st, blk.size() * 4, hipMemcpyDeviceToHost, f->stream));
     if (out_len) INFCHK(f, hipMemcpyAsync(text, f->d_out, (size_t)out_len, hipMemcpyDeviceToHost, f->stream));
     INFCHK(f, hipEventRecord(f->done, f->stream));
-    INFCHK(f, hipEventSynchronize(f->done));
+    INFCHK(f, wait_event_napping(f->done));
     // 3. every block: decoder status, then the CRC32 of its text
     for (size_t i = 0; i < blk.size(); ++i) {
         if (f->h_st[i] != 0 || qd_io_crc32(text + blk[i].out_off, blk[i].out_len) != f->crc[i]) {
@@ -1436,7 +1452,7 @@ int qd_deflater_run(qd_deflater* f, int32_t n_pieces, const uint8_t* const* text
     }
     DEFCHK(f, hipMemcpyAsync(f->h_len, f->d_len, (size_t)n_pieces * 4, hipMemcpyDeviceToHost, f->stream));
     DEFCHK(f, hipEventRecord(f->done, f->stream));
-    DEFCHK(f, hipEventSynchronize(f->done));
+    DEFCHK(f, wait_event_napping(f->done));
     for (int i = 0; i < n_pieces; ++i) {  // the used bytes of every member
         if (f->h_len[i] > (uint64_t)out_stride) return def_fail(f, QD_ERR_HIP, "member longer than its slot");
         if (f->h_len[i])
@@ -1444,7 +1460,7 @@ int qd_deflater_run(qd_deflater* f, int32_t n_pieces, const uint8_t* const* text
                                      hipMemcpyDeviceToHost, f->stream));
     }
     DEFCHK(f, hipEventRecord(f->done, f->stream));
-    DEFCHK(f, hipEventSynchronize(f->done));
+    DEFCHK(f, wait_event_napping(f->done));
     for (int i = 0; i < n_pieces; ++i) {
         member_len[i] = f->h_len[i];  // 0: this member did not fit out_stride (the caller makes it itself)
         if (f->h_len[i]) memcpy(out + (size_t)i * (size_t)out_stride, f->h_out + (size_t)i * (size_t)out_stride, f->h_len[i]);

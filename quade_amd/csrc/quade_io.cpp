@@ -88,9 +88,9 @@ LibDeflate& deflate_lib() {
 
 // ---- where the host's CPU time goes: thread-CPU seconds per stage, summed over all threads of the library -----------
 // (qd_io_stage_seconds; two clock reads per job or per 4 MB piece -- nothing per record)
-enum Stage { ST_INFLATE, ST_READ, ST_SCAN_COPY, ST_SCAN_LINES, ST_SCAN_RECORDS, ST_SCATTER, ST_FORMAT, ST_CRC, ST_DEFLATE, ST_LANE, ST_APPEND,
+enum Stage { ST_INFLATE, ST_DEV_INFLATE, ST_READ, ST_SCAN_COPY, ST_SCAN_LINES, ST_SCAN_RECORDS, ST_SCATTER, ST_FORMAT, ST_CRC, ST_DEFLATE, ST_LANE, ST_APPEND,
              ST_COUNT };
-const char* const STAGE_NAMES[ST_COUNT] = {"inflate (pool jobs)", "read + cut input (reader threads)", "scanner: copy into the batch",
+const char* const STAGE_NAMES[ST_COUNT] = {"inflate (pool jobs)", "reader device lanes: stage, launch, wait, CRC-32", "read + cut input (reader threads)", "scanner: copy into the batch",
                                            "scanner: newlines", "scanner: records + batch hand-over", "sink: scatter by code",
                                            "sink: format records", "sink: CRC-32", "sink: deflate on the host",
                                            "device lanes: launch, wait, copy members", "file appends"};
@@ -594,7 +594,7 @@ class DeflateService {
     static constexpr size_t BUF_BYTES = (size_t)JOB_BYTES + (JOB_BYTES >> 2) + (256u << 10);  // a piece, its tags, slack
     static constexpr int MAX_BUFS = 192, MAX_BATCH = 32;  // (192 = 4 slabs)
     explicit DeflateService(int device) : device_(device) {
-        for (int i = 0; i < 2; ++i) lanes_.emplace_back([this] { lane(); });
+        for (int i = 0; i < LANES; ++i) lanes_.emplace_back([this] { lane(); });
     }
     // a buffer of BUF_BYTES, or nullptr (none free right now: the caller codes its piece itself).  Buffers are made
     // by the lanes, a slab at a time, off the pool threads' path (page-locking 120 MB takes tens of milliseconds).
@@ -632,7 +632,6 @@ class DeflateService {
         const char* fa = getenv("QUADE_TEST_DEFLATE_FAIL_AFTER");  // test hook: the device "fails" after this many batches
         const int64_t fail_after = fa && *fa ? atoll(fa) : -1;
         int64_t batches = 0;
-        std::vector<uint8_t> out;
         if (usable) add_slab();
         for (;;) {
             std::vector<DevPiece> b;
@@ -666,10 +665,11 @@ class DeflateService {
             StageTimer lane_timer(ST_LANE);
             if (ok && b[0].level != -1) ok = qd_deflater_set_level && qd_deflater_set_level(def, b[0].level) == QD_OK;
             else if (ok && qd_deflater_set_level) (void)qd_deflater_set_level(def, -1);
+            std::shared_ptr<MemberBlock> out;
             if (ok) {
                 stride = qd_huffman_member_bound(longest);
-                out.resize((size_t)stride * b.size());
-                ok = qd_deflater_run(def, (int32_t)b.size(), tp.data(), tl.data(), crc.data(), 1, out.data(), stride, ml.data()) == QD_OK;
+                out = take_block((size_t)stride * b.size());
+                ok = out->p && qd_deflater_run(def, (int32_t)b.size(), tp.data(), tl.data(), crc.data(), 1, out->p, stride, ml.data()) == QD_OK;
                 ++batches;
                 if (!ok) {  // a HIP error: the host takes over from here (pool jobs stop asking for buffers)
                     usable = false;
@@ -677,26 +677,67 @@ class DeflateService {
                     failed_ = true;
                 }
             }
+            // The members go to their files on the pool's threads (a copy out of the batch's block, the appends in file
+            // order): a lane that delivered its 32 members itself spent more of a batch's ~27 ms in write() than waiting
+            // for the device, two lanes made 4.8 GB/s of text, and the pieces that found no buffer meanwhile were coded by
+            // the host (profiles/r03_e2e_16m_level1_stages.txt: 0.17-0.29 core-s per M pairs of fallback).
             for (size_t i = 0; i < b.size(); ++i) {
-                Bytes member;
-                bool dev = ok && ml[i] > 0;
-                if (dev) {
-                    member.resize((size_t)ml[i]);
-                    memcpy(member.data(), out.data() + (size_t)stride * i, (size_t)ml[i]);
-                } else {
-                    lane_timer.next(ST_DEFLATE);
-                    if (!gzip_member(b[i].text, (size_t)b[i].len, b[i].level, member)) {
-                        sink_error(b[i].s, "gzip compression failed");
-                        member.clear();
-                    }
+                const DevPiece pc = b[i];
+                if (ok && ml[i] > 0) {
+                    give_buffer(pc.text);
+                    const size_t at = (size_t)stride * i, len = (size_t)ml[i];
+                    pool().submit([out, at, len, pc] {
+                        StageTimer timer(ST_APPEND);
+                        Bytes member;
+                        member.resize(len);
+                        memcpy(member.data(), out->p + at, len);
+                        finish_piece(pc.s, pc.f, pc.seq, pc.text_bytes, pc.len, std::move(member), true);
+                    });
+                } else {  // the device failed, or this member did not fit its slot: the host's coder
+                    pool().submit([this, pc] {
+                        Bytes member;
+                        {
+                            StageTimer timer(ST_DEFLATE);
+                            if (!gzip_member(pc.text, (size_t)pc.len, pc.level, member)) {
+                                sink_error(pc.s, "gzip compression failed");
+                                member.clear();
+                            }
+                        }
+                        give_buffer(pc.text);
+                        finish_piece(pc.s, pc.f, pc.seq, pc.text_bytes, pc.len, std::move(member), false);
+                    });
                 }
-                lane_timer.next(ST_APPEND);  // (finish_piece delivers: the appends open their own timer, this one only idles)
-                give_buffer(b[i].text);
-                finish_piece(b[i].s, b[i].f, b[i].seq, b[i].text_bytes, b[i].len, std::move(member), dev);
-                lane_timer.next(ST_LANE);
             }
         }
     }
+    // blocks of members (one per batch), recycled: a fresh 75 MB allocation per batch is 18 000 page faults
+    struct MemberBlock {
+        uint8_t* p = nullptr;
+        size_t cap = 0;
+        ~MemberBlock() { free(p); }
+    };
+    std::shared_ptr<MemberBlock> take_block(size_t need) {
+        MemberBlock* mb = nullptr;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            if (!blocks_.empty()) {
+                mb = blocks_.back();
+                blocks_.pop_back();
+            }
+        }
+        if (!mb) mb = new MemberBlock();
+        if (mb->cap < need) {
+            free(mb->p);
+            mb->p = (uint8_t*)malloc(need);
+            mb->cap = mb->p ? need : 0;
+        }
+        return std::shared_ptr<MemberBlock>(mb, [this](MemberBlock* x) {
+            std::lock_guard<std::mutex> g(m_);
+            if (blocks_.size() < 8) blocks_.push_back(x);
+            else delete x;
+        });
+    }
+    std::vector<MemberBlock*> blocks_;
     void add_slab() {  // SLAB more page-locked buffers, cut from one allocation (kept for the life of the process)
         {
             std::lock_guard<std::mutex> g(m_);
@@ -711,7 +752,7 @@ class DeflateService {
         }
         for (int i = 0; i < SLAB; ++i) free_.push_back(p + (size_t)i * BUF_BYTES);
     }
-    static constexpr int SLAB = 48;
+    static constexpr int SLAB = 48, LANES = 3;
     int device_;
     std::mutex m_;
     std::condition_variable cv_;
@@ -1376,7 +1417,7 @@ struct BgzfRun {  // consecutive blocks inflated by one pool job
 };
 
 constexpr size_t BGZF_RUN_BYTES = 2u << 20;  // compressed bytes per job
-constexpr size_t BGZF_RUNS_IN_FLIGHT = 6;
+std::atomic<int64_t> g_bgzf_in_flight{6};  // runs of blocks a reader keeps with the pool (qd_io_set_option "bgzf_in_flight")
 constexpr size_t BGZF_DEVICE_RUN_BYTES = 16u << 20;  // per device launch: ~500 blocks (a launch takes ~16 ms whether it holds 500 blocks or 8 000)
 constexpr size_t BGZF_DEVICE_LANES = 3;              // launches in flight per reader
 
@@ -1455,6 +1496,7 @@ void device_lane(qd_reader* r) {
         }
         bool taken = false;
         if (usable) {
+            StageTimer timer(ST_DEV_INFLATE);
             int32_t bad = -1;
             const int rc = (fail_after >= 0 && r->device_runs >= fail_after) ? QD_ERR_HIP : run->pin ? qd_inflater_run_pinned(inf, run->in.data(), (int64_t)run->in.size(), run->pin, (int64_t)run->out_len, &bad)
                                     : qd_inflater_run(inf, run->in.data(), (int64_t)run->in.size(), run->out.data(), (int64_t)run->out.size(), &bad);
@@ -1595,7 +1637,7 @@ bool inflate_bgzf(qd_reader* r, Input& in, int& cur, bool& ok) {
                 pool().submit([run, &L] { host_inflate_run(*run, L); }, true);
             }
         }
-        while (ok && !flight.empty() && (flight.size() >= (on_device ? BGZF_DEVICE_LANES + 1 : BGZF_RUNS_IN_FLIGHT) || !more)) collect_one();
+        while (ok && !flight.empty() && (flight.size() >= (on_device ? BGZF_DEVICE_LANES + 1 : (size_t)g_bgzf_in_flight.load()) || !more)) collect_one();
     }
     while (!flight.empty()) {  // stopping early (close / error): the jobs still reference their runs; just wait them out
         std::shared_ptr<BgzfRun> run = flight.front();
@@ -1932,6 +1974,7 @@ int qd_io_set_option(const char* name, int64_t value) {
     else if (n == "gunzip_chunk_bytes" && value >= (64 << 10)) g_pgz_chunk_bytes = value;
     else if (n == "gunzip_min_file_bytes" && value >= 0) g_pgz_min_file_bytes = value;
     else if (n == "gunzip_in_flight" && value >= 0 && value <= 256) g_pgz_in_flight = value;
+    else if (n == "bgzf_in_flight" && value >= 1 && value <= 256) g_bgzf_in_flight = value;
     else return QD_ERR_INVALID;
     return QD_OK;
 }
