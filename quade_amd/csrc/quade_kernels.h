@@ -40,6 +40,12 @@
 #ifndef QD_GENERIC_ALIGNED
 #define QD_GENERIC_ALIGNED 1 /* the specialised generic forms load 4- / 8-byte aligned slices without shifts (A/B: 0)       */
 #endif
+#ifndef QD_WIDE_CONFIRM_GLOBAL
+#define QD_WIDE_CONFIRM_GLOBAL 0 /* A/B: wide plans confirm a packed hit against the barcode's bytes in global memory (r02) instead of checking the key's alphabet in registers */
+#endif
+#ifndef QD_WIDE_PREFETCH
+#define QD_WIDE_PREFETCH 0 /* A/B: register double buffering for the static wide shapes */
+#endif
 #ifndef QD_STRIPS_LDS_BUDGET
 #define QD_STRIPS_LDS_BUDGET 0 /* A/B: LDS a CU may spend on two workgroups incl. their code strips (0: small tables only) */
 #endif

@@ -280,9 +280,24 @@ __device__ __forceinline__ uint32_t match_pair(const DemuxParams& p, const LdsTa
     return code;
 }
 
+// every byte of v is one of A C G T N: (byte >> 1) & 7 tells the five letters apart (A 0, C 1, T 2, G 3, N 7) -- look the
+// letter up (one v_perm_b32 per 4 bytes), compare with the byte
+__device__ __forceinline__ bool qd_bases4(uint32_t v) {
+    return __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, (v >> 1) & 0x07070707u) == v;
+}
+// ... of the bytes of x that `mask` selects (the others count as letters)
+__device__ __forceinline__ bool qd_bases8(u64 x, u64 mask) {
+    const u64 y = x | (0x4141414141414141ull & ~mask);
+    return qd_bases4((uint32_t)y) && qd_bases4((uint32_t)(y >> 32));
+}
+
 // Wide plans (16 < K <= 32; slices of up to 16 bytes per index read; quade_common.h "wide keys"): the slices are
-// folded, nibble-packed and fused into a 16-byte key for the same LDS table probe; a hit is confirmed against
-// the barcode's own bytes (global memory, L2: 32 B per sample) before it counts.
+// folded, nibble-packed and fused into a 16-byte key for the same LDS table probe.  The packing is injective on the
+// alphabet only ('Q' shares its low nibble with 'A'), so a packed hit proves equality only for a read whose key bytes are
+// all letters of the alphabet -- checked in registers (r03; before: a hit was confirmed against the barcode's own bytes in
+// global memory, one dependent L2 round trip per matched pair behind the tile's row loads; QD_WIDE_CONFIRM_GLOBAL=1
+// restores that form for A/B).  The table of a wide plan holds ACGTN-only barcodes (any other sends the plan to the generic
+// kernel), so a key with a foreign byte equals none of them.
 template <bool DUAL>
 __device__ __forceinline__ uint32_t match_pair_wide(const DemuxParams& p, const LdsTable& t, const u64 (&k1)[2],
                                                     const u64 (&k2)[2], u64 m1, u64 m2, const u64 (&q1)[2],
@@ -297,12 +312,20 @@ __device__ __forceinline__ uint32_t match_pair_wide(const DemuxParams& p, const 
     const u64 f2lo = DUAL ? qd_fold8(k2[0]) : 0, f2hi = DUAL ? qd_fold8(k2[1]) : 0;
     u64 klo, khi;
     qd_wide_key(f1lo, f1hi, f2lo, f2hi, p.idx_w[0], &klo, &khi);
-    // a4: packed lookup, then the byte compare that makes it exact
+    // a4: packed lookup + what makes it exact
+#if QD_WIDE_CONFIRM_GLOBAL
     const uint32_t id = probe_lds(t, klo, khi, (uint32_t)p.K, p.seed, p.slot_mask);
     if (id == QD_CODE_UNDET) return QD_CODE_UNDET;
     const ulong2* bv = reinterpret_cast<const ulong2*>(p.bkv) + 2 * (size_t)id;
     const ulong2 b1 = bv[0], b2 = bv[1];
     if (b1.x != f1lo || b1.y != f1hi || b2.x != f2lo || b2.y != f2hi) return QD_CODE_UNDET;
+#else
+    bool letters = qd_bases8(f1lo, p.idx_mask[0]) && qd_bases8(f1hi, p.idx_mask_hi[0]);
+    if (DUAL) letters = letters && qd_bases8(f2lo, p.idx_mask[1]) && qd_bases8(f2hi, p.idx_mask_hi[1]);
+    if (!letters) return QD_CODE_UNDET;
+    const uint32_t id = probe_lds(t, klo, khi, (uint32_t)p.K, p.seed, p.slot_mask);
+    if (id == QD_CODE_UNDET) return QD_CODE_UNDET;
+#endif
     // a5: min-phred gate over the barcode positions
     uint32_t pass = qd_all_ge8(q1[0], p.thr) & qd_all_ge8(q1[1], p.thr);
     if (DUAL) pass &= qd_all_ge8(q2[0], p.thr) & qd_all_ge8(q2[1], p.thr);
@@ -798,8 +821,8 @@ template <int BLOCK_, bool DUAL, class SH = DynShape>
 struct RowsW {
     typedef SH Shape;
     static constexpr int BLOCK = BLOCK_;
-    static constexpr bool PREFETCH = false;   // 128 B per lane per tile: a second tile in registers costs more in
-                                              // occupancy (132 VGPRs) than it hides (0.74 vs 0.60 ms, static 10+10)
+    static constexpr bool PREFETCH = QD_WIDE_PREFETCH != 0 && SH::STATIC;  // 128 B per lane per tile: a second tile in registers costs
+                                              // more in occupancy (132 VGPRs) than it hides (0.74 vs 0.60 ms, static 10+10, r02)
     static constexpr bool GUARD_LAST = true;  // strides < 8: the first block passes the lane's rows
     static constexpr int RUNS = DUAL ? QD_FAST_RUNS : 0;
     struct Tile {
