@@ -247,14 +247,14 @@ __device__ __forceinline__ void store_mol2(uint8_t* dst, u64 alo, u64 ahi, u64 b
 // One pair from its extracted slices to its routing code: fuse, fold, match, gate, count.
 // k1/k2 = barcode slices of index read 1/2 (<= 8 bytes each, little-endian, masked), m1/m2 = molecular
 // slices, q1/q2 = quality bytes of the barcode slices (bytes beyond the slice = 0xFF).
-template <bool DUAL>
+template <bool DUAL, bool MOL = true>  // MOL = false: the caller fuses the molecular index itself (slices wider than 8 bytes)
 __device__ __forceinline__ uint32_t match_pair(const DemuxParams& p, const LdsTable& t, u64 k1, u64 k2, u64 m1,
                                                u64 m2, u64 q1, u64 q2, u64& mlo, u64& mhi) {
     // a1: fused barcode (Quade.py:217 / :246)
     u64 klo = k1, khi = 0;
     if (DUAL) fuse(k1, k2, p.idx_w[0], klo, khi);
     // a2: fused molecular index, raw case (Quade.py:218 / :247)
-    if (p.M > 0) {
+    if (MOL && p.M > 0) {
         mlo = m1;
         mhi = 0;
         if (DUAL) fuse(m1, m2, p.mol_w[0], mlo, mhi);
@@ -404,12 +404,22 @@ __device__ __forceinline__ void store_mol_wave(const DemuxParams& p, uint8_t* st
     const uint32_t w0[4] = {(uint32_t)m0lo, (uint32_t)(m0lo >> 32), (uint32_t)m0hi, (uint32_t)(m0hi >> 32)};
     const uint32_t w1[4] = {(uint32_t)m1lo, (uint32_t)(m1lo >> 32), (uint32_t)m1hi, (uint32_t)(m1hi >> 32)};
     const int nd = M >> 2;  // dwords per pair, wave-uniform
+    if ((M & 3) == 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (j < nd) {
-            mine[j] = w0[j];
-            mine[nd + j] = w1[j];
-        }
+        for (int j = 0; j < 4; ++j)
+            if (j < nd) {
+                mine[j] = w0[j];
+                mine[nd + j] = w1[j];
+            }
+    } else {  // any width (the shapes with a 9..11-base molecular index): bytes -- the second pair's start is not word aligned
+        uint8_t* b8 = strip + lane * 2 * M;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < M) {
+                b8[j] = (uint8_t)(w0[j >> 2] >> (8 * (j & 3)));
+                b8[M + j] = (uint8_t)(w1[j >> 2] >> (8 * (j & 3)));
+            }
+    }
     typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
     if (run) {
         if (!co.last) return;
@@ -899,6 +909,115 @@ struct RowsW {
             store_codes_full<RUNS>(p, co, p0, c[0] | (c[1] << 16));
         } else {
             store_unit(p, p0, two, c[0], c[1], m0lo, m0hi, m1lo, m1hi);
+        }
+        return undet;
+    }
+};
+
+// ---- RowsU: index read 1 = 8-base barcode + a molecular index of 9..12 bases right behind it, index read 2 = 8-base
+// barcode alone -- the dual-index kits whose i7 read carries the UMI (IDT xGen UDI-UMI: 8 + 9; NEBNext UMI: 8 + 11 / 12).
+// Rows of 18 / 20 bytes: the 36 / 40 bytes of a lane's two pairs take three 16-byte loads (the third end-aligned with the
+// second row, as RowsX does with its second), the other three streams are 8-byte rows (one aligned load each).  Static
+// only; r02 / early r03 sent these layouts to the generic kernel (0.13-0.17 of peak).
+template <int MW>
+struct StaticUmi1 {
+    static constexpr bool STATIC = true;
+    static constexpr int MOLW = MW;
+    static constexpr int STRIDE = (8 + MW + 1) & ~1;
+    static_assert(MW > 8 && MW <= 12, "molecular index of 9..12 bases behind an 8-base barcode");
+    static __device__ __forceinline__ void apply(DemuxParams& p) {
+        p.n_streams = 2;
+        p.K = 16;
+        p.M = MW;
+        p.seq_stride[0] = STRIDE;
+        p.seq_stride[1] = 8;
+        p.mol_off[0] = 8;
+        p.mol_w[0] = MW;
+        p.mol_off[1] = p.mol_w[1] = 0;
+        p.mol_mask[0] = ~0ull;
+        p.mol_mask[1] = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            p.qual_stride[k] = 8;
+            p.idx_off[k] = 0;
+            p.idx_w[k] = 8;
+            p.idx_mask[k] = ~0ull;
+        }
+    }
+    static bool matches(const DemuxParams& p) {
+        return p.n_streams == 2 && p.K == 16 && p.M == MW && p.seq_stride[0] == STRIDE && p.seq_stride[1] == 8 && p.qual_stride[0] == 8 &&
+               p.qual_stride[1] == 8 && p.idx_off[0] == 0 && p.idx_off[1] == 0 && p.idx_w[0] == 8 && p.idx_w[1] == 8 && p.mol_w[0] == MW &&
+               p.mol_off[0] == 8 && p.mol_w[1] == 0;
+    }
+};
+
+template <int BLOCK_, class SH>
+struct RowsU {
+    typedef SH Shape;
+    static constexpr int BLOCK = BLOCK_, S1 = SH::STRIDE, MW = SH::MOLW;
+    static constexpr bool PREFETCH = false;   // 96 B per lane per tile
+    static constexpr bool GUARD_LAST = true;  // the first two blocks of a lane pass its rows' end on the batch's last tile
+    static constexpr int RUNS = QD_FAST_RUNS;
+    struct Tile {
+        u64 s1[6];  // full tiles: bytes [0, 32) of the lane's two rows, then bytes [2*S1 - 16, 2*S1); guarded tiles: bytes [0, 2*S1) in a row
+        u64 q1[2], s2[2], q2[2];
+    };
+
+    template <bool FULL>
+    static __device__ __forceinline__ void load(Tile& T, const DemuxParams& p, int64_t base, uint32_t tid) {
+        const int64_t n = p.n, p0 = base + (int64_t)tid * 2;
+        if (!FULL && p0 >= n) return;
+        const uint8_t* src = p.seq[0] + p0 * S1;  // p0 even, S1 even: 4-byte aligned
+        if (FULL) {
+            const U128 a = ld16u(src), b = ld16u(src + 16), c = ld16u(src + 2 * S1 - 16);
+            T.s1[0] = a.lo; T.s1[1] = a.hi; T.s1[2] = b.lo; T.s1[3] = b.hi; T.s1[4] = c.lo; T.s1[5] = c.hi;
+        } else {
+            ld_exact(T.s1, src, (p0 + 1 < n ? 2 : 1) * S1);
+        }
+        if (FULL || p0 + 1 < n) {
+            const U128 a = ld16s(p.qual[0] + p0 * 8), b = ld16s(p.seq[1] + p0 * 8), c = ld16s(p.qual[1] + p0 * 8);
+            T.q1[0] = a.lo; T.q1[1] = a.hi; T.s2[0] = b.lo; T.s2[1] = b.hi; T.q2[0] = c.lo; T.q2[1] = c.hi;
+        } else {  // the batch's last, odd pair: never read past row n-1
+            T.q1[0] = ld8(p.qual[0] + p0 * 8); T.s2[0] = ld8(p.seq[1] + p0 * 8); T.q2[0] = ld8(p.qual[1] + p0 * 8);
+            T.q1[1] = T.s2[1] = T.q2[1] = 0;
+        }
+    }
+
+    template <bool FULL, int TAG>
+    static __device__ __forceinline__ uint32_t compute(const Tile& T, const DemuxParams& p, const LdsTable& t, int64_t base, uint32_t tid,
+                                                       const CodeOut& co) {
+        asm volatile("; demux tile copy %0" ::"i"(TAG));
+        const int64_t n = p.n, p0 = base + (int64_t)tid * 2;
+        if (!FULL && p0 >= n) return 0;
+        const bool two = FULL || (p0 + 1 < n);
+        constexpr u64 HI = (1ull << (8 * (MW - 8))) - 1;  // bytes 8 .. MW-1 of the molecular index
+        const u64 head[4] = {T.s1[0], T.s1[1], T.s1[2], T.s1[3]}, tail[2] = {T.s1[4], T.s1[5]};
+        u64 mlo[2] = {0, 0}, mhi[2] = {0, 0};
+        uint32_t c[2] = {0, 0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !two) break;
+            // a1 + a2: the barcode at the row's start, the molecular index behind it (raw case; Quade.py:217-218 / :246-247)
+            const u64 k1 = take8(head, h * S1);
+            if (h == 0) {
+                mlo[0] = take8(head, 8);
+                mhi[0] = take8(head, 16) & HI;
+            } else if (FULL) {  // row 1's molecular index lies in the end-aligned block, at byte (S1 + 8) - (2 * S1 - 16)
+                mlo[1] = take8(tail, 24 - S1);
+                mhi[1] = take8(tail, 32 - S1) & HI;
+            } else {
+                mlo[1] = take8(T.s1, S1 + 8);
+                mhi[1] = take8(T.s1, S1 + 16) & HI;
+            }
+            u64 d0, d1;
+            c[h] = match_pair<true, false>(p, t, k1, T.s2[h], 0, 0, T.q1[h], T.q2[h], d0, d1);
+        }
+        const uint32_t undet = (c[0] == QD_CODE_UNDET) + (two && c[1] == QD_CODE_UNDET);
+        if (FULL && p.mol_strip_off) {
+            store_codes_full<RUNS>(p, co, p0, c[0] | (c[1] << 16));
+            store_mol_wave<RUNS>(p, t.strips, co, p0, mlo[0], mhi[0], mlo[1], mhi[1]);
+        } else {
+            store_unit(p, p0, two, c[0], c[1], mlo[0], mhi[0], mlo[1], mhi[1]);
         }
         return undet;
     }
@@ -1661,6 +1780,14 @@ hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, in
 #endif
         return launch_fast_t<RowsW<BLOCK, true>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
     }
+#if !defined(QD_NO_STATIC_SHAPES) && !defined(QD_SWEEP_BUILD)
+    // 8-base barcodes, a molecular index of 9..12 bases behind the one of index read 1 (rows of 18 / 20 bytes: static shapes only)
+    if (StaticUmi1<9>::matches(p)) return launch_fast_t<RowsU<BLOCK, StaticUmi1<9>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+    if (StaticUmi1<10>::matches(p)) return launch_fast_t<RowsU<BLOCK, StaticUmi1<10>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+    if (StaticUmi1<11>::matches(p)) return launch_fast_t<RowsU<BLOCK, StaticUmi1<11>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+    if (StaticUmi1<12>::matches(p)) return launch_fast_t<RowsU<BLOCK, StaticUmi1<12>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+#endif
+    if (p.seq_stride[0] > 16 || p.seq_stride[1] > 16) return hipErrorInvalidValue;  // (the host sends such plans here only for the shapes above)
     const bool all8 = p.seq_stride[0] == 8 && p.qual_stride[0] == 8 &&
                       (!dual || (p.seq_stride[1] == 8 && p.qual_stride[1] == 8));
     if (all8) {

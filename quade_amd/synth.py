@@ -40,11 +40,16 @@ CONFIGS = {
     "kit8u8": dict(dual=True, S=96, read_len=16, mol=True, min_qual=25, pairs=60_000_000, iw=8),
     "kit12": dict(dual=True, S=96, read_len=12, mol=False, min_qual=25, pairs=60_000_000, iw=12),
     "kit10u6": dict(dual=True, S=96, read_len=16, mol=True, min_qual=25, pairs=60_000_000, iw=10),
+    # mol1_only: the molecular index sits in index read 1 alone (the i7 read of IDT xGen UDI-UMI: 8 + 9 bases, of NEBNext UMI: 8 + 12),
+    # index read 2 is its 8-base barcode
+    "kit8u9": dict(dual=True, S=96, read_len=17, mol=True, min_qual=25, pairs=60_000_000, iw=8, mol1_only=True),
+    "kit8u12": dict(dual=True, S=96, read_len=20, mol=True, min_qual=25, pairs=60_000_000, iw=8, mol1_only=True),
 }
 # algorithmic bytes per pair (SURVEY.md 8d / BASELINE.md section 3): barcode + molecular bases and barcode qualities
 # read, code and molecular bytes written
 ALGO_BYTES = {"cfg2": 18, "cfg3": 34, "cfg4": 58, "cfg5": 34, "wide10": 42,
-              "kit6": 26, "kit8u8": 66, "kit12": 50, "kit10u6": 66}
+              "kit6": 26, "kit8u8": 66, "kit12": 50, "kit10u6": 66,
+              "kit8u9": 52, "kit8u12": 58}  # 8 + u bases and 8 qualities of index read 1, 8 + 8 of index read 2, 2 + u bytes out
 
 
 def config_plan(name):
@@ -52,7 +57,7 @@ def config_plan(name):
     iw = c.get("iw", 8)
     mol = (iw, c["read_len"]) if c["mol"] else (0, 0)
     return make_plan(c["dual"], c["min_qual"], (0, iw), (0, iw) if c["dual"] else (0, 0),
-                     mol, mol if c["dual"] else (0, 0))
+                     mol, mol if (c["dual"] and not c.get("mol1_only")) else (0, 0))
 
 
 def _key64(rows):
@@ -173,7 +178,7 @@ def generate(name, n, seed=None, device="cpu", chunk=8_000_000, layout=None, bar
         for k in range(ns):
             seq[k][a:a + m].zero_()
             seq[k][a:a + m, 0:iw] = key[:, iw * k:iw * k + iw]
-            if c["mol"]:
+            if c["mol"] and (k == 0 or not c.get("mol1_only")):
                 seq[k][a:a + m, iw:L] = acgt[ri(0, 4, (m, L - iw))]
             qual[k][a:a + m].fill_(0xFF)
             qual[k][a:a + m, 0:iw] = q[:, iw * k:iw * k + iw]
