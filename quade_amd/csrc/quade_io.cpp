@@ -25,6 +25,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cerrno>
 #include <condition_variable>
@@ -89,11 +90,14 @@ LibDeflate& deflate_lib() {
 // ---- where the host's CPU time goes: thread-CPU seconds per stage, summed over all threads of the library -----------
 // (qd_io_stage_seconds; two clock reads per job or per 4 MB piece -- nothing per record)
 enum Stage { ST_INFLATE, ST_DEV_INFLATE, ST_READ, ST_SCAN_COPY, ST_SCAN_LINES, ST_SCAN_RECORDS, ST_SCATTER, ST_FORMAT, ST_CRC, ST_DEFLATE, ST_LANE, ST_APPEND,
+             ST_LANE_WALL, ST_LANE_BATCHES, ST_LANE_PIECES, ST_NO_BUFFER,  // (the last three are counts, not seconds)
              ST_COUNT };
 const char* const STAGE_NAMES[ST_COUNT] = {"inflate (pool jobs)", "reader device lanes: stage, launch, wait, CRC-32", "read + cut input (reader threads)", "scanner: copy into the batch",
                                            "scanner: newlines", "scanner: records + batch hand-over", "sink: scatter by code",
                                            "sink: format records", "sink: CRC-32", "sink: deflate on the host",
-                                           "device lanes: launch, wait, copy members", "file appends"};
+                                           "device lanes: launch, wait, copy members", "file appends",
+                                           "device lanes: WALL seconds inside qd_deflater_run", "device lanes: launches (count / 1e9)",
+                                           "device lanes: pieces (count / 1e9)", "pieces that found no page-locked buffer (count / 1e9)"};
 std::atomic<int64_t> g_stage_ns[ST_COUNT];
 inline int64_t thread_cpu_ns() {
     timespec ts;
@@ -592,19 +596,37 @@ void finish_piece(qd_sink* s, OutFile* f, uint64_t seq, int64_t text_bytes, int6
 class DeflateService {
   public:
     static constexpr size_t BUF_BYTES = (size_t)JOB_BYTES + (JOB_BYTES >> 2) + (256u << 10);  // a piece, its tags, slack
-    static constexpr int MAX_BUFS = 192, MAX_BATCH = 32;  // (192 = 4 slabs)
+    static constexpr int MAX_BATCH = 32;
+    // page-locked buffers at most (made as the lanes come up and as pieces ask for more) and how long a pool job waits for one:
+    // the defaults, or QUADE_DEFLATE_BUFFERS / QUADE_DEFLATE_BUFFER_WAIT_MS (measurement knobs)
+    const int MAX_BUFS = [] {
+        const char* e = getenv("QUADE_DEFLATE_BUFFERS");
+        const int v = e && *e ? atoi(e) : 288;
+        return v < 16 ? 16 : (v > 4096 ? 4096 : v);
+    }();
+    const int wait_ms_ = [] {
+        const char* e = getenv("QUADE_DEFLATE_BUFFER_WAIT_MS");
+        const int v = e && *e ? atoi(e) : 0;  // (12 ms: 13 % -> 1 % of the pieces coded by the host, 0.1 core-s per M pairs saved -- and
+        return v < 0 ? 0 : (v > 1000 ? 1000 : v);  //  the run no faster: 6.6 vs 7.2 M pairs/s, profiles/r03_e2e_deflate_buffers_ab.txt)
+    }();
     explicit DeflateService(int device) : device_(device) {
         for (int i = 0; i < LANES; ++i) lanes_.emplace_back([this] { lane(); });
     }
     // a buffer of BUF_BYTES, or nullptr (none free right now: the caller codes its piece itself).  Buffers are made
     // by the lanes, a slab at a time, off the pool threads' path (page-locking 120 MB takes tens of milliseconds).
+    // A routed batch is ~400 pieces at once, more than the lanes drain while the pool formats them: ~10 % of the pieces find
+    // no buffer and are coded by libdeflate on their pool thread (the host and the device share the work by whoever is free).
+    // A job can wait for a buffer instead (QUADE_DEFLATE_BUFFER_WAIT_MS); measured, that saves CPU and no time.
     uint8_t* take_buffer() {
-        std::lock_guard<std::mutex> g(m_);
-        if (failed_ || free_.empty()) {
-            want_slab_ = !failed_ && made_ < MAX_BUFS;
-            if (want_slab_) cv_.notify_one();
-            return nullptr;
+        std::unique_lock<std::mutex> g(m_);
+        if (!failed_ && free_.empty()) {
+            if (made_ < MAX_BUFS) {
+                want_slab_ = true;
+                cv_.notify_one();
+            }
+            if (wait_ms_ > 0) cv_free_.wait_for(g, std::chrono::milliseconds(wait_ms_), [this] { return failed_ || !free_.empty(); });
         }
+        if (failed_ || free_.empty()) return nullptr;
         uint8_t* p = free_.back();
         free_.pop_back();
         if (free_.size() < 8 && made_ < MAX_BUFS) {
@@ -614,8 +636,11 @@ class DeflateService {
         return p;
     }
     void give_buffer(uint8_t* p) {
-        std::lock_guard<std::mutex> g(m_);
-        free_.push_back(p);
+        {
+            std::lock_guard<std::mutex> g(m_);
+            free_.push_back(p);
+        }
+        cv_free_.notify_one();
     }
     void submit(const DevPiece& d) {
         {
@@ -632,7 +657,11 @@ class DeflateService {
         const char* fa = getenv("QUADE_TEST_DEFLATE_FAIL_AFTER");  // test hook: the device "fails" after this many batches
         const int64_t fail_after = fa && *fa ? atoll(fa) : -1;
         int64_t batches = 0;
-        if (usable) add_slab();
+        if (usable) {  // this lane's share now: a lane that is never idle would not get round to more later
+            add_slab(12);
+            add_slab(36);
+            add_slab();
+        }
         for (;;) {
             std::vector<DevPiece> b;
             bool slab = false;
@@ -669,12 +698,19 @@ class DeflateService {
             if (ok) {
                 stride = qd_huffman_member_bound(longest);
                 out = take_block((size_t)stride * b.size());
+                const auto w0 = std::chrono::steady_clock::now();
                 ok = out->p && qd_deflater_run(def, (int32_t)b.size(), tp.data(), tl.data(), crc.data(), 1, out->p, stride, ml.data()) == QD_OK;
+                g_stage_ns[ST_LANE_WALL].fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count());
+                g_stage_ns[ST_LANE_BATCHES].fetch_add(1);
+                g_stage_ns[ST_LANE_PIECES].fetch_add((int64_t)b.size());
                 ++batches;
                 if (!ok) {  // a HIP error: the host takes over from here (pool jobs stop asking for buffers)
                     usable = false;
-                    std::lock_guard<std::mutex> g(m_);
-                    failed_ = true;
+                    {
+                        std::lock_guard<std::mutex> g(m_);
+                        failed_ = true;
+                    }
+                    cv_free_.notify_all();
                 }
             }
             // The members go to their files on the pool's threads (a copy out of the batch's block, the appends in file
@@ -738,24 +774,28 @@ class DeflateService {
         });
     }
     std::vector<MemberBlock*> blocks_;
-    void add_slab() {  // SLAB more page-locked buffers, cut from one allocation (kept for the life of the process)
+    // `count` more page-locked buffers, cut from one allocation (kept for the life of the process).  Page-locking costs
+    // ~1 ms per MB: a lane's first slab is a small one, so that the first pieces of a run find buffers
+    void add_slab(int count = SLAB) {
         {
             std::lock_guard<std::mutex> g(m_);
             if (made_ >= MAX_BUFS) return;
-            made_ += SLAB;
+            count = std::min(count, MAX_BUFS - made_);
+            made_ += count;
         }
-        uint8_t* p = qd_pinned_alloc ? (uint8_t*)qd_pinned_alloc((int64_t)(BUF_BYTES * SLAB)) : nullptr;
+        uint8_t* p = qd_pinned_alloc ? (uint8_t*)qd_pinned_alloc((int64_t)(BUF_BYTES * (size_t)count)) : nullptr;
         std::lock_guard<std::mutex> g(m_);
         if (!p) {
             made_ = MAX_BUFS;  // no more page-locked memory to be had: work with what there is
             return;
         }
-        for (int i = 0; i < SLAB; ++i) free_.push_back(p + (size_t)i * BUF_BYTES);
+        for (int i = 0; i < count; ++i) free_.push_back(p + (size_t)i * BUF_BYTES);
+        cv_free_.notify_all();
     }
     static constexpr int SLAB = 48, LANES = 3;
     int device_;
     std::mutex m_;
-    std::condition_variable cv_;
+    std::condition_variable cv_, cv_free_;
     std::deque<DevPiece> q_;
     std::vector<uint8_t*> free_;
     int made_ = 0;
@@ -965,6 +1005,7 @@ static int route_impl(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_
                 DeflateService* sv = deflate_service(s->deflate_device);
                 const size_t need = (size_t)p.text_bytes + 8 * (size_t)p.n_sel + 16;
                 uint8_t* buf = need <= DeflateService::BUF_BYTES ? sv->take_buffer() : nullptr;
+                if (!buf) g_stage_ns[ST_NO_BUFFER].fetch_add(1);
                 if (buf) {
                     int64_t w;
                     {

@@ -212,14 +212,17 @@ def _gzip_members(data, path, level, member_bytes, threads=0):
 
 
 def write_fastq_dataset(workdir, n_pairs, n_samples=96, insert_len=150, seed=5, gz_level=1, member_bytes="bgzf",
-                        threads=0, plain=False):
+                        threads=0, plain=False, qualities="uniform"):
     """2 x insert_len bp insert reads + dual 8 bp index reads of n_pairs pairs as four fastq(.gz) files
     under workdir (SURVEY.md 8d recipe: 90 % carry a sample's barcode pair, 10 % get an N; qualities
     phred 30..40, 15 % of the index reads with one position at phred 2..24).  Names are identical across
     the four streams.  member_bytes: "bgzf" (bgzip layout, the default), N > 0 (gzip members of N text bytes) or 0
-    (one gzip member).  Returns (paths dict, barcode pairs)."""
+    (one gzip member).  qualities: "uniform" (phred 30..40 uniformly at random: nothing for a compressor or an inflater
+    to gain -- the worst case, and the benchmarks' default) or "binned" (the insert reads as current instruments write
+    them: 'F' with up to three short stretches of ':' ',' '#').  Returns (paths dict, barcode pairs)."""
     import os
     import numpy as np
+    assert qualities in ("uniform", "binned")
     rng = np.random.default_rng(seed)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     bcs = set()
@@ -262,7 +265,19 @@ def write_fastq_dataset(workdir, n_pairs, n_samples=96, insert_len=150, seed=5, 
         rec[:, o + 1:o + 1 + L] = lut_acgt[raw(n * L).reshape(n, L)] if seq is None else seq
         o += 1 + L
         rec[:, o:o + 3] = np.frombuffer(b"\n+\n", np.uint8)
-        rec[:, o + 3:o + 3 + L] = lut_phred[raw(n * L).reshape(n, L)]  # phred 30..40
+        if qualities == "binned" and L == insert_len:
+            cols = np.arange(L, dtype=np.int32)[None, :]
+            for a0 in range(0, n, 1 << 20):  # a million rows at a time (the masks are n x L)
+                a1 = min(n, a0 + (1 << 20))
+                q = np.full((a1 - a0, L), ord("F"), np.uint8)
+                for _ in range(3):
+                    at = rng.integers(0, L, a1 - a0).astype(np.int32)[:, None]
+                    wd = rng.integers(0, 12, a1 - a0).astype(np.int32)[:, None]
+                    ch = np.frombuffer(b":,#", np.uint8)[rng.integers(0, 3, a1 - a0)][:, None]
+                    q = np.where((cols >= at) & (cols < at + wd), ch, q)
+                rec[a0:a1, o + 3:o + 3 + L] = q
+        else:
+            rec[:, o + 3:o + 3 + L] = lut_phred[raw(n * L).reshape(n, L)]  # phred 30..40
         if L != insert_len:  # 15 % of the index reads: one barcode position at phred 2..24
             bad = np.flatnonzero(rng.integers(0, 100, n) < 15)
             rec[bad, o + 3 + rng.integers(0, L, bad.size)] = (rng.integers(2, 25, bad.size) + 33).astype(np.uint8)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end rate: synthetic 2x150 bp fastq.gz chunks in -> per-sample fastq.gz + report out through
 the CLI driver.  Host bound (gunzip, scan, format, gzip); printed as one JSON line.
-usage: python tools/e2e_bench.py [pairs] [gzip level] [chunks] [--single-member | --members] [--ranks N]
+usage: python tools/e2e_bench.py [pairs] [gzip level] [chunks] [--single-member | --members] [--binned] [--ranks N]
 input files: BGZF (bgzip layout) by default, --members = 8 MB gzip members, --single-member = one gzip member
 env: E2E_PARALLEL_GUNZIP (1; 0 = ordinary gzip files on one thread each), E2E_GUNZIP_CHUNK, E2E_GUNZIP_IN_FLIGHT, E2E_DEVICE_INFLATE (0; 1 = BGZF inflate on the GPU), E2E_DEVICE_DEFLATE (0; 1 = Huffman-only members made on the GPU, level -1), E2E_WORKERS (chunk_workers), E2E_IO_THREADS, E2E_SAMPLES (96), E2E_BATCH (500000), QUADE_PROFILE=1 (stage timers)"""
 import json
@@ -35,7 +35,8 @@ for _name, _env in (("parallel_gunzip", "E2E_PARALLEL_GUNZIP"), ("gunzip_chunk_b
         assert _hb.load_library().qd_io_set_option(_name.encode(), int(os.environ[_env])) == 0
 try:
     t0 = time.perf_counter()
-    paths, bcs = synth.write_fastq_dataset(work, n, n_samples=n_samples, member_bytes=fmt)
+    quals = "binned" if "--binned" in sys.argv else "uniform"  # --binned: insert-read qualities as current instruments write them
+    paths, bcs = synth.write_fastq_dataset(work, n, n_samples=n_samples, member_bytes=fmt, qualities=quals)
     t_gen = time.perf_counter() - t0
     conf = os.path.join(work, "conf.txt")
     dev_inflate = os.environ.get("E2E_DEVICE_INFLATE", "0") not in ("0", "false", "False")
@@ -72,17 +73,25 @@ try:
         if os.environ.get("QUADE_PROFILE"):  # thread-CPU seconds of the library's stages (all threads)
             k = _lib.qd_io_stage_seconds(_names, _secs, 32, 0)
             tot = (c1.user - c0.user) + (c1.system - c0.system)
+            cpu_sum = 0.0
             for i in range(k):
-                print("\t[cpu] %-44s %7.2f s  %5.2f core-s per M pairs" % (_names[i].decode(), _secs[i], _secs[i] / (n * n_chunks / 1e6)))
+                nm = _names[i].decode()
+                if "count / 1e9" in nm:
+                    print("\t[n]   %-60s %d" % (nm.replace(" (count / 1e9)", ""), round(_secs[i] * 1e9)))
+                elif "WALL" in nm:
+                    print("\t[wall] %-59s %7.2f s" % (nm, _secs[i]))
+                else:
+                    cpu_sum += _secs[i]
+                    print("\t[cpu] %-44s %7.2f s  %5.2f core-s per M pairs" % (nm, _secs[i], _secs[i] / (n * n_chunks / 1e6)))
             print("\t[cpu] %-44s %7.2f s  %5.2f core-s per M pairs (python main thread, index packing, tags, unaccounted)"
-                  % ("everything else", tot - sum(_secs[:k]), (tot - sum(_secs[:k])) / (n * n_chunks / 1e6)))
+                  % ("everything else", tot - cpu_sum, (tot - cpu_sum) / (n * n_chunks / 1e6)))
         cpu_s = (c1.user - c0.user) + (c1.system - c0.system)  # every thread of this process (readers, pool, main)
         cpu_user, cpu_sys = c1.user - c0.user, c1.system - c0.system
         counts = Sample.COUNTS()[:4]
     from quade_amd.fastq_writer import host_cores, io_backend, io_threads
     print(json.dumps({"mode": "end-to-end fastq.gz -> fastq.gz", "chunks": n_chunks, "pairs": n * n_chunks, "seconds": dt,
                       "pairs_per_s": n * n_chunks / dt, "gzip_level": level, "counts": counts, "chunk_workers": workers,
-                      "ranks": ranks, "device_inflate": dev_inflate, "device_deflate": dev_deflate, "parallel_gunzip": os.environ.get("E2E_PARALLEL_GUNZIP", "1") != "0", "samples": n_samples, "batch_pairs": batch, "input": {0: "single gzip member", "bgzf": "BGZF"}.get(fmt, "8 MB gzip members"), "gzip_backend": io_backend(),
+                      "ranks": ranks, "qualities": quals, "device_inflate": dev_inflate, "device_deflate": dev_deflate, "parallel_gunzip": os.environ.get("E2E_PARALLEL_GUNZIP", "1") != "0", "samples": n_samples, "batch_pairs": batch, "input": {0: "single gzip member", "bgzf": "BGZF"}.get(fmt, "8 MB gzip members"), "gzip_backend": io_backend(),
                       "io_threads": io_threads(), "host_cores": host_cores(), "host_logical_cpus": os.cpu_count(), "dataset_seconds": round(t_gen, 1),
                       "cpu_seconds": cpu_s, "cpu_user_sys": [round(cpu_user, 2), round(cpu_sys, 2)] if cpu_s else None, "cpu_seconds_per_M_pairs": cpu_s / (n * n_chunks / 1e6) if cpu_s else None,
                       "core_utilisation": cpu_s / (dt * host_cores()) if cpu_s else None}))
