@@ -57,6 +57,7 @@ def test_single_gpu_line():
     # the reference's real input format (one gzip member per file) and the driver's default output level, same line
     sm1 = e["single_member_gzip"]
     assert sm1["value"] > 0 and sm1["counts_equal"] is True and sm1["gzip_level"] == 1 and sm1["vs_bgzf_input"] > 0
+    assert e["binned_qualities"]["value"] > 0 and e["binned_qualities"]["counts_equal"] is True
     assert e["host_level6"]["gzip_level"] == 6 and e["host_level6"]["counts_equal"] is True and e["default_level"] == 1
     # hygiene: what ran as warm-up, the step-based fraction beside the event-based one
     assert j["warmup_ran"] == j["untimed_launches"] and 0 < r["frac_by_step"] <= r["frac"] * 1.001
