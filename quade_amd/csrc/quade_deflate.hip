@@ -297,11 +297,12 @@ hipError_t qd_launch_huffman(const uint8_t* text, const qd_deflate_piece* pieces
 //     (literal | length, distance) replace the candidates in the scratch, in text order; their symbols go into two LDS
 //     histograms.
 //  3. the two length-limited codes: symbols ranked by (count, symbol) by all threads, the two-queue merge and the Kraft
-//     repair of the Huffman-only kernel by one; the header carries the code lengths as plain 4-bit numbers.
+//     repair of the Huffman-only kernel by one; the header carries the code lengths run-length coded with a fixed
+//     code-length code (~65 bytes per block).
 //  4. 256 tokens per step are coded in parallel: bits and bit count per lane, workgroup scan, OR into an LDS word buffer,
 //     whole words leave coalesced.
 // Against the host's coders on 2 MB of fastq text (tools/lz_model.cpp is the parse on the CPU; tools/lz_bench.py the device):
-// binned qualities 18.8 % of the text (zlib level 1: 22.5 %, level 6: 19.0 %), uniform random qualities 50.0 % (52.2 / 47.8).
+// binned qualities 18.7 % of the text (zlib level 1: 22.5 %, level 6: 19.0 %), uniform random qualities 49.9 % (52.2 / 47.8).
 // Nothing is read or written outside the piece's text, the scratch slots and the output slots; a sub-block or member
 // that would not fit its slot is reported with length 0 and the host makes that member itself.
 // ------------------------------------------------------------------------------------------------------------------------
@@ -633,14 +634,49 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
         put((uint32_t)(nl - 257), 5);
         put((uint32_t)(nd - 1), 5);
         put(15, 4);
+        // The code lengths, run-length coded with a FIXED code-length code (complete: 1/4 + 2/8 + 16/32): a zero costs 2
+        // bits, "3-10 zeros" (17) and "11-138 zeros" (18) 3 + their 3 / 7 extra bits, a length 1..15 and "repeat the last
+        // length 3-6 times" (16) 5 (+ 2).  Most of the 286 + 30 lengths are zero: ~65 bytes of header per block where plain
+        // 4-bit lengths took 160 (1 % of a block of fastq text).  Canonical codes: 0 -> 00, 17 -> 010, 18 -> 011, L -> 10000 + (L - 1).
         const uint8_t ord[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-        for (int k = 0; k < 19; ++k) put(ord[k] < 16 ? 4 : 0, 3);  // lengths 0..15 as 4-bit codes, no run-length symbols
-        for (int s = 0; s < nl; ++s) put(rev_bits(llen[s], 4), 4);
-        for (int s = 0; s < nd; ++s) put(rev_bits(dlen[s], 4), 4);
+        for (int k = 0; k < 19; ++k) put(ord[k] == 0 ? 2u : ((ord[k] == 17 || ord[k] == 18) ? 3u : 5u), 3);
+        auto len_at = [&](int i) -> uint32_t { return i < nl ? llen[i] : dlen[i - nl]; };
+        auto put_len = [&](uint32_t v) { put(rev_bits(15u + v, 5), 5); };  // v = 1..15; 16 ("repeat") is 15 + 16 = 11111
+        const int nseq = nl + nd;
+        for (int i = 0; i < nseq;) {
+            const uint32_t v = len_at(i);
+            int run = 1;
+            while (i + run < nseq && len_at(i + run) == v) ++run;
+            i += run;
+            if (v == 0) {
+                while (run >= 11) {
+                    const int r = run < 138 ? run : 138;
+                    put(6, 3);  // 18: 011, sent most significant bit first
+                    put((uint32_t)(r - 11), 7);
+                    run -= r;
+                }
+                if (run >= 3) {
+                    put(2, 3);  // 17: 010
+                    put((uint32_t)(run - 3), 3);
+                    run = 0;
+                }
+                for (; run > 0; --run) put(0, 2);
+            } else {
+                put_len(v);
+                --run;
+                while (run >= 3) {
+                    const int r = run < 6 ? run : 6;
+                    put_len(16);
+                    put((uint32_t)(r - 3), 2);
+                    run -= r;
+                }
+                for (; run > 0; --run) put_len(v);
+            }
+        }
         carry_word = (uint32_t)acc;
         carry_bits = (uint32_t)cnt;
         // the block must fit its slot: header, symbols + extra bits, end of block, the empty stored block
-        uint64_t bits = 3 + 14 + 19 * 3 + 4 * (uint64_t)(nl + nd);
+        uint64_t bits = 3 + 14 + 19 * 3 + 5 * (uint64_t)(nl + nd);  // (the header: at most 5 bits per length)
         for (int s = 0; s < LZ_NL; ++s) bits += (uint64_t)lfreq[s] * (llen[s] + (s > 256 ? len_extra_bits((uint32_t)s) : 0u));
         for (int s = 0; s < LZ_ND; ++s) bits += (uint64_t)dfreq[s] * (dlen[s] + dist_extra_bits((uint32_t)s));
         ctl[0] = (uint32_t)wi;

@@ -226,7 +226,25 @@ int main(int argc, char** argv) {
         int nl = 286, nd = 30;
         while (nl > 257 && !lf[nl - 1]) --nl;
         while (nd > 1 && !df[nd - 1]) --nd;
-        total_bits += huff_bits(lf) + huff_bits(df) + extra + 3 + 14 + 57 + 4 * (nl + nd) + 3 + 7 + 32;
+        // header: the code lengths run-length coded with the kernel's fixed code-length code -- 5 bits per used symbol (equal
+        // neighbours would repeat for 7: not modelled), 2 per lone zero, 6 / 10 per run of 3-10 / 11-138 zeros
+        double hdr = 3 + 14 + 57;
+        {
+            int run = 0;
+            auto flush = [&] {
+                while (run >= 11) hdr += 10, run -= std::min(run, 138);
+                if (run >= 3) hdr += 6, run = 0;
+                hdr += 2 * run;
+                run = 0;
+            };
+            for (int i = 0; i < nl + nd; ++i) {
+                const bool used = i < nl ? lf[i] != 0 : df[i - nl] != 0;
+                if (used) flush(), hdr += 5;
+                else ++run;
+            }
+            flush();
+        }
+        total_bits += huff_bits(lf) + huff_bits(df) + extra + hdr + 3 + 7 + 32;
     }
     printf("%s:", argv[1]);
     for (int i = 2; i < argc; ++i) printf(" %s", argv[i]);
