@@ -149,7 +149,8 @@ def test_cli_with_device_deflate_writes_the_same_files(tmp_path, monkeypatch, fa
     from quade_amd.quade import Quade
     from quade_amd.sample import Sample
     work = str(tmp_path)
-    paths, bcs = synth.write_fastq_dataset(work, 120_000, n_samples=24)
+    # (level 1 without the failure: records with binned qualities -- long runs, matches across quality lines -- the others uniform ones)
+    paths, bcs = synth.write_fastq_dataset(work, 120_000, n_samples=24, qualities="binned" if (level == 1 and not fail_after) else "uniform")
     if fail_after:
         monkeypatch.setenv("QUADE_TEST_DEFLATE_FAIL_AFTER", fail_after)
     outs = {}
