@@ -1318,6 +1318,14 @@ struct qd_deflater {
 
 namespace {
 thread_local std::string g_deflater_error;
+// The coder's launches are short (2 ms per 64 MB) and everything downstream waits for them: its stream gets the device's
+// highest priority, so that its workgroups are placed before those of long-running kernels that share the GPU (the BGZF
+// inflater's launches hold their CUs for ~16 ms).
+hipError_t make_priority_stream(hipStream_t* st) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest);
+}
 int def_fail(qd_deflater* f, int code, const std::string& msg) {
     if (f) f->err = msg;
     else g_deflater_error = msg;
@@ -1345,7 +1353,7 @@ int qd_deflater_create(int device_id, qd_deflater** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return def_fail(nullptr, QD_ERR_NO_DEVICE, "no such HIP device");
     qd_deflater* f = new qd_deflater();
     f->device = device_id;
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess ||
+    if (hipSetDevice(device_id) != hipSuccess || make_priority_stream(&f->stream) != hipSuccess ||
         hipEventCreateWithFlags(&f->done, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
         delete f;
         return def_fail(nullptr, QD_ERR_HIP, "hipStreamCreate failed");

@@ -1460,7 +1460,7 @@ struct BgzfRun {  // consecutive blocks inflated by one pool job
 constexpr size_t BGZF_RUN_BYTES = 2u << 20;  // compressed bytes per job
 std::atomic<int64_t> g_bgzf_in_flight{6};  // runs of blocks a reader keeps with the pool (qd_io_set_option "bgzf_in_flight")
 constexpr size_t BGZF_DEVICE_RUN_BYTES = 16u << 20;  // per device launch: ~500 blocks (a launch takes ~16 ms whether it holds 500 blocks or 8 000)
-constexpr size_t BGZF_DEVICE_LANES = 3;              // launches in flight per reader
+std::atomic<int64_t> g_bgzf_device_lanes{3};         // launches in flight per reader (qd_io_set_option "bgzf_device_lanes")
 
 // the blocks of a run, one after the other, on this thread
 void host_inflate_run(BgzfRun& run, LibDeflate& L) {
@@ -1600,7 +1600,7 @@ bool inflate_bgzf(qd_reader* r, Input& in, int& cur, bool& ok) {
     // batcher works on the previous run meanwhile; a run the device refuses is inflated here instead
     bool on_device = r->inflate_device >= 0 && qd_inflater_create && qd_inflater_run && qd_inflater_destroy;
     if (on_device && r->dev_threads.empty())
-        for (size_t i = 0; i < BGZF_DEVICE_LANES; ++i) r->dev_threads.emplace_back(device_lane, r);
+        for (int64_t i = 0, nl = g_bgzf_device_lanes.load(); i < nl; ++i) r->dev_threads.emplace_back(device_lane, r);
     while (ok && more) {
         // one run: whole blocks up to BGZF_RUN_BYTES
         std::shared_ptr<BgzfRun> run = std::make_shared<BgzfRun>();
@@ -1678,7 +1678,7 @@ bool inflate_bgzf(qd_reader* r, Input& in, int& cur, bool& ok) {
                 pool().submit([run, &L] { host_inflate_run(*run, L); }, true);
             }
         }
-        while (ok && !flight.empty() && (flight.size() >= (on_device ? BGZF_DEVICE_LANES + 1 : (size_t)g_bgzf_in_flight.load()) || !more)) collect_one();
+        while (ok && !flight.empty() && (flight.size() >= (on_device ? r->dev_threads.size() + 1 : (size_t)g_bgzf_in_flight.load()) || !more)) collect_one();
     }
     while (!flight.empty()) {  // stopping early (close / error): the jobs still reference their runs; just wait them out
         std::shared_ptr<BgzfRun> run = flight.front();
@@ -2016,6 +2016,7 @@ int qd_io_set_option(const char* name, int64_t value) {
     else if (n == "gunzip_min_file_bytes" && value >= 0) g_pgz_min_file_bytes = value;
     else if (n == "gunzip_in_flight" && value >= 0 && value <= 256) g_pgz_in_flight = value;
     else if (n == "bgzf_in_flight" && value >= 1 && value <= 256) g_bgzf_in_flight = value;
+    else if (n == "bgzf_device_lanes" && value >= 1 && value <= 16) g_bgzf_device_lanes = value;
     else return QD_ERR_INVALID;
     return QD_OK;
 }
