@@ -46,6 +46,9 @@
 #ifndef QD_WIDE_PREFETCH
 #define QD_WIDE_PREFETCH 0 /* A/B: register double buffering for the static wide shapes */
 #endif
+#ifndef QD_GENERIC_LDS_TABLE
+#define QD_GENERIC_LDS_TABLE (24 * 1024) /* specialised generic kernels: the table of every barcode is staged in LDS while histogram + table fit this many bytes (A/B: 0 = global memory, r02 / early r03) */
+#endif
 #ifndef QD_STRIPS_LDS_BUDGET
 #define QD_STRIPS_LDS_BUDGET 0 /* A/B: LDS a CU may spend on two workgroups incl. their code strips (0: small tables only) */
 #endif

@@ -1498,8 +1498,11 @@ __device__ __forceinline__ void load_slice(const uint8_t* p, int nbytes, u64 (&w
         load_bytes<NW>(p, nbytes, nbytes, w);
 }
 
-template <int NS, int KW, int MWORDS, int ALIGN>
-__device__ __forceinline__ uint32_t special_pair(const DemuxParams& p, int64_t r) {
+// tslots / tkeys / tlens: the table of every barcode -- in global memory (keys QD_KEY_WORDS words apart) or, LT, the workgroup's
+// copy in LDS (keys KW words apart)
+template <int NS, int KW, int MWORDS, int ALIGN, bool LT>
+__device__ __forceinline__ uint32_t special_pair(const DemuxParams& p, int64_t r, const uint32_t* tslots, const u64* tkeys,
+                                                 const uint8_t* tlens) {
     u64 w[KW];
 #pragma unroll
     for (int i = 0; i < KW; ++i) w[i] = 0;
@@ -1520,7 +1523,7 @@ __device__ __forceinline__ uint32_t special_pair(const DemuxParams& p, int64_t r
         or_shifted<KW>(w, v, at);                                                     // a1
         at += iw;
     }
-    // a4: the global table of every barcode (a K-long key can only equal a K-long barcode)
+    // a4: the table of every barcode (a K-long key can only equal a K-long barcode)
     uint32_t code = QD_CODE_UNDET;
     {
         uint32_t h = qd_hash_init((uint32_t)at, p.gseed);
@@ -1531,12 +1534,12 @@ __device__ __forceinline__ uint32_t special_pair(const DemuxParams& p, int64_t r
         const uint32_t fp = h >> 16;
         uint32_t s = h & p.gmask;
         for (;;) {
-            const uint32_t e = p.gslots[s];
+            const uint32_t e = tslots[s];
             if (e == QD_EMPTY_SLOT) break;
             if ((e >> 16) == fp) {
                 const uint32_t id = e & 0xFFFFu;
-                const u64* b = p.bk32 + (size_t)id * QD_KEY_WORDS;
-                bool same = p.blen[id] == (uint8_t)at;
+                const u64* b = tkeys + (size_t)id * (LT ? KW : QD_KEY_WORDS);
+                bool same = tlens[id] == (uint8_t)at;
 #pragma unroll
                 for (int i = 0; i < KW; ++i) same = same && b[i] == w[i];
                 if (same) {
@@ -1575,7 +1578,10 @@ __device__ __forceinline__ uint32_t special_pair(const DemuxParams& p, int64_t r
     return code;
 }
 
-template <int NS, int KW, int MWORDS, int ALIGN>
+// LT: the workgroup stages the table of every barcode in LDS behind its histogram (slots | keys, KW words each | lengths) and
+// probes it there: the two dependent trips to global memory per pair (slot, then key) were most of what the one-pair-per-lane
+// kernels waited for; the launcher picks it while the copy is small (a few workgroups per CU must still fit).
+template <int NS, int KW, int MWORDS, int ALIGN, bool LT>
 __global__ __launch_bounds__(QD_GEN_BLOCK) void demux_special(const DemuxParams p, uint32_t hist_entries) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw);
@@ -1583,10 +1589,24 @@ __global__ __launch_bounds__(QD_GEN_BLOCK) void demux_special(const DemuxParams 
     const uint32_t S = p.n_samples;
     qd_row_t* row = p.partial + (size_t)(blockIdx.x % p.partial_rows) * p.cnt_stride;
     for (uint32_t i = threadIdx.x; i < hist_entries; i += QD_GEN_BLOCK) hist[i] = 0;
-    if (hist_entries) __syncthreads();
+    const uint32_t* tslots = p.gslots;
+    const u64* tkeys = p.bk32;
+    const uint8_t* tlens = p.blen;
+    if (LT) {
+        uint32_t* ls = reinterpret_cast<uint32_t*>(lds_raw + (((size_t)hist_entries * 4 + 15) & ~(size_t)15));
+        u64* lk = reinterpret_cast<u64*>(ls + (p.gmask + 1));
+        uint8_t* ll = reinterpret_cast<uint8_t*>(lk + (size_t)S * KW);
+        for (uint32_t i = threadIdx.x; i <= p.gmask; i += QD_GEN_BLOCK) ls[i] = p.gslots[i];
+        for (uint32_t i = threadIdx.x; i < S * KW; i += QD_GEN_BLOCK) lk[i] = p.bk32[(size_t)(i / KW) * QD_KEY_WORDS + (i % KW)];
+        for (uint32_t i = threadIdx.x; i < S; i += QD_GEN_BLOCK) ll[i] = p.blen[i];
+        tslots = ls;
+        tkeys = lk;
+        tlens = ll;
+    }
+    if (hist_entries || LT) __syncthreads();
     uint32_t undet = 0;
     for (int64_t r = (int64_t)blockIdx.x * QD_GEN_BLOCK + threadIdx.x; r < p.n; r += stride) {
-        const uint32_t code = special_pair<NS, KW, MWORDS, ALIGN>(p, r);
+        const uint32_t code = special_pair<NS, KW, MWORDS, ALIGN, LT>(p, r, tslots, tkeys, tlens);
         if (code == QD_CODE_UNDET)
             ++undet;
         else if (hist_entries)
@@ -1855,11 +1875,18 @@ hipError_t qd_launch_fast(const DemuxParams& p, QdKernelCache& cache, int cus, i
 }
 
 namespace {
+template <int NS, int KW, int ALIGN, bool LT>
+void launch_special_t(const DemuxParams& p, int grid, size_t lds, uint32_t entries, hipStream_t st) {
+    if (p.M == 0) hipLaunchKernelGGL((demux_special<NS, KW, 0, ALIGN, LT>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
+    else if (p.M <= 16) hipLaunchKernelGGL((demux_special<NS, KW, 2, ALIGN, LT>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
+    else hipLaunchKernelGGL((demux_special<NS, KW, 4, ALIGN, LT>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
+}
 template <int NS, int KW, int ALIGN>
 void launch_special_a(const DemuxParams& p, int grid, size_t lds, uint32_t entries, hipStream_t st) {
-    if (p.M == 0) hipLaunchKernelGGL((demux_special<NS, KW, 0, ALIGN>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
-    else if (p.M <= 16) hipLaunchKernelGGL((demux_special<NS, KW, 2, ALIGN>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
-    else hipLaunchKernelGGL((demux_special<NS, KW, 4, ALIGN>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
+    // the table in LDS while histogram + slots + keys + lengths stay within QD_GENERIC_LDS_TABLE bytes (needs the histogram there too)
+    const size_t tbl = (((size_t)entries * 4 + 15) & ~(size_t)15) + ((size_t)p.gmask + 1) * 4 + (size_t)p.n_samples * KW * 8 + p.n_samples;
+    if (QD_GENERIC_LDS_TABLE && entries && tbl <= (size_t)QD_GENERIC_LDS_TABLE) launch_special_t<NS, KW, ALIGN, true>(p, grid, (tbl + 15) & ~(size_t)15, entries, st);
+    else launch_special_t<NS, KW, ALIGN, false>(p, grid, lds, entries, st);
 }
 // what every slice address of the launch is a multiple of: 8, 4 or nothing in particular (row arrays are 16-byte aligned)
 int slice_alignment(const DemuxParams& p) {
