@@ -25,7 +25,7 @@ Optional [gpu] section (not in Quade 0.3.2; a conf file without it runs with the
   gzip_level : 1         deflate level of the output fastq.gz files (0-9; -1 = Huffman coding only).  1, the default, is
                          the level the GPU codes itself (device_deflate): 4.9 M pairs/s end to end against 3.0 on a 16-core
                          host's pool, files smaller than libdeflate's level 6 on records with binned qualities (19.1 % of
-                         the text; level 6: 19.2 %, level 1: 20.9 %) and 7 % larger on uniformly random qualities; levels
+                         the text; level 6: 19.2 %, level 1: 20.9 %), between its levels 6 and 1 on uniformly random ones (41.7 %; 40.3 / 43.2 %); levels
                          2-9 are libdeflate on the host's pool (level 6: 1.3 M pairs/s).  The reference writes with
                          Python's gzip default (9); only the decompressed bytes are its format
   chunk_workers : 1      chunks processed concurrently by host threads (outputs identical)

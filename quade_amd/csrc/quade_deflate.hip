@@ -287,8 +287,10 @@ hipError_t qd_launch_huffman(const uint8_t* text, const qd_deflate_piece* pieces
 //     that hash (16 bit each; an entry is only a guess), compares both candidates and the position before its own
 //     (distance 1: runs) with its own next 32 bytes, keeps the longest (the nearest on a tie), and enters its own
 //     position.  A match that covers only bases (ACGTN: literals of ~2 bits) must be 12 bytes long to be kept, any other
-//     4 -- short matches inside the sequence lines cost more than their literals.  (length <= 32, distance) per
-//     position goes to the sub-block's scratch.
+//     4, and every match must be worth its bits: (its length) x (what the 8 bytes at its start cost as literals, from
+//     the sub-block's byte histogram) against 13 + log2(distance) -- short matches inside the sequence lines and inside
+//     lines of random qualities cost more than their literals.  (length <= 32, distance) per position goes to the
+//     sub-block's scratch.
 //  2. the parse: every wave walks a quarter of the sub-block (a match never crosses into the next quarter), 64
 //     positions at a time, as a scalar loop: a position with a match is deferred by one literal when its successor's
 //     match is longer (lazy evaluation on the 32-byte views); a 32-byte match is extended by all 64 lanes comparing 4
@@ -302,13 +304,13 @@ hipError_t qd_launch_huffman(const uint8_t* text, const qd_deflate_piece* pieces
 //  4. 256 tokens per step are coded in parallel: bits and bit count per lane, workgroup scan, OR into an LDS word buffer,
 //     whole words leave coalesced.
 // Against the host's coders on 2 MB of fastq text (tools/lz_model.cpp is the parse on the CPU; tools/lz_bench.py the device):
-// binned qualities 18.7 % of the text (zlib level 1: 22.5 %, level 6: 19.0 %), uniform random qualities 49.9 % (52.2 / 47.8).
+// binned qualities 18.7 % of the text (zlib level 1: 22.5 %, level 6: 19.0 %), uniform random qualities 49.7 % (52.2 / 47.8).
 // Nothing is read or written outside the piece's text, the scratch slots and the output slots; a sub-block or member
 // that would not fit its slot is reported with length 0 and the host makes that member itself.
 // ------------------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int LZ_SUB = QD_LZ_SUB, LZ_WAVES = 4, LZ_BLOCK = 64 * LZ_WAVES, LZ_REG = LZ_SUB / LZ_WAVES;
-constexpr int LZ_HASH_BITS = 11, LZ_NICE = 32, LZ_DNA_MIN = 12, LZ_MAXLEN = 256;
+constexpr int LZ_HASH_BITS = 11, LZ_NICE = 32, LZ_DNA_MIN = 12, LZ_MATCH_BITS = 13, LZ_MAXLEN = 256;
 constexpr int LZ_TEXT_WORDS = (LZ_SUB + 320) / 4;  // the text and what the widest compare may read behind it
 constexpr int LZ_NL = 286, LZ_ND = 30;
 static_assert(LZ_SUB == 65536, "table entries are 16-bit positions inside the sub-block");
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
     uint32_t* tw = reinterpret_cast<uint32_t*>(lz_lds);                                   // LZ_TEXT_WORDS
     uint32_t* table = reinterpret_cast<uint32_t*>(lz_lds + (size_t)LZ_TEXT_WORDS * 4);     // 1 << LZ_HASH_BITS buckets of 2 x 16 bit
     __shared__ uint32_t lfreq[288], dfreq[32], llut[288], dlut[32];
-    __shared__ uint8_t llen[288], dlen[32];
+    __shared__ uint8_t llen[288], dlen[32], bcost[256];
     __shared__ uint32_t wave_ntok[LZ_WAVES], scan[LZ_WAVES], ctl[4];
     __shared__ uint32_t carry_word, carry_bits;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -467,7 +469,13 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
     uint32_t* dst = reinterpret_cast<uint32_t*>(sub_out + (int64_t)blockIdx.x * sub_stride);
     uint32_t* tok0 = tokens + (size_t)blockIdx.x * LZ_SUB;  // candidates per position, then the waves' token lists
 
-    // 0. stage the text (zero behind it), empty table and histograms
+    // 0. stage the text (zero behind it) and count its bytes on the way (8 replicas of a histogram in the table's space, which is
+    //    not in use yet): what a literal costs, in bits, decides below which matches are worth taking
+    static_assert((1u << LZ_HASH_BITS) == 8 * 256, "the byte histogram's replicas borrow the hash table's space");
+    for (uint32_t i = tid; i < (1u << LZ_HASH_BITS); i += LZ_BLOCK) table[i] = 0;
+    for (uint32_t i = tid; i < 288; i += LZ_BLOCK) lfreq[i] = 0;
+    if (tid < 32) dfreq[tid] = 0;
+    __syncthreads();
     for (uint32_t i = tid; i < (uint32_t)LZ_TEXT_WORDS / 4; i += LZ_BLOCK) {
         uint4 v = make_uint4(0, 0, 0, 0);
         const uint32_t b = i * 16;
@@ -479,10 +487,24 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
             v = make_uint4(q[0], q[1], q[2], q[3]);
         }
         reinterpret_cast<uint4*>(tw)[i] = v;
+        if (b < L) {
+            const uint32_t q[4] = {v.x, v.y, v.z, v.w}, nby = min(16u, L - b);
+            uint32_t* rep = table + ((tid & 7u) << 8);
+#pragma unroll
+            for (uint32_t k = 0; k < 16; ++k)
+                if (k < nby) atomicAdd(&rep[(q[k >> 2] >> (8 * (k & 3))) & 0xFFu], 1u);
+        }
     }
+    __syncthreads();
+    if (tid < 256) {  // bits of a literal of this byte under an ideal code, 1 .. 12 (a byte the text does not hold: 12)
+        uint32_t h = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) h += table[(r << 8) + tid];
+        const int c = h ? (int)(__log2f((float)L / (float)h) + 0.5f) : 12;
+        bcost[tid] = (uint8_t)(c < 1 ? 1 : (c > 12 ? 12 : c));
+    }
+    __syncthreads();
     for (uint32_t i = tid; i < (1u << LZ_HASH_BITS); i += LZ_BLOCK) table[i] = 0;
-    for (uint32_t i = tid; i < 288; i += LZ_BLOCK) lfreq[i] = 0;
-    if (tid < 32) dfreq[tid] = 0;
     __syncthreads();
 
     // 1. candidates: rounds of 256 positions, one barrier per round
@@ -510,7 +532,14 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
                 }
                 best = min(best, L - p);
                 const uint32_t need = (bases4(a[0]) && bases4(a[1])) ? (uint32_t)LZ_DNA_MIN : 4u;
-                if (best < need) best = 0;
+                // ... and worth its bits: the literals it replaces, priced by the 8 bytes at its start, against ~13 bits of
+                // length and distance symbols + the distance's extra bits (short matches inside lines of random qualities lose,
+                // as those inside the sequence lines do: 43.0 -> 41.5 % of the benchmarks' synthetic records, tools/lz_model.cpp)
+                uint32_t c8 = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c8 += bcost[(a[k >> 2] >> (8 * (k & 3))) & 0xFFu];
+                const uint32_t mbits = (uint32_t)LZ_MATCH_BITS + (dist > 1 ? 31u - (uint32_t)__clz(dist) : 0u);
+                if (best < need || best * c8 < mbits * 8) best = 0;
                 table[h] = (bucket << 16) | p;
             }
             tok0[p] = best | (dist << 8);

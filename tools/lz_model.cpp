@@ -5,12 +5,14 @@
 // binned-quality records (zlib level 1: 22.5 % of the text, level 6: 19.0 %):
 //   waves=4 look=64 cut=0 ways=1 hash=14 nice=0 lazy=0 dna=0 run=0   31.8 %  four waves on quarters of a sub-block, side by side
 //   waves=1 look=64 cut=0 ways=4 hash=12 run=0                         19.5 %  one wave per sub-block (complete history): 10 ms per 64 MB
-//   (defaults)                                                           18.8 %  the run candidate always compared, rounds of 256
+//   cost=0                                                               18.8 %  the run candidate always compared, rounds of 256
+//   (defaults)                                                           18.7 %  + matches priced against their literals (the benchmarks' records with random qualities: 43.0 -> 41.5 %)
 // The device's members are checked with zlib by tests/test_gpu_deflate.py.
 //   g++ -O2 -o /tmp/lz_model tools/lz_model.cpp && /tmp/lz_model text [key=value ...]
 //   keys: sub (65536) look (256: positions looked up before any of them is entered) cut (16384: the walk's regions)
 //         hash (11) ways (2) run (1: distance 1 always compared) minlen (4) nice (32) lazy (1)
 //         dna (12: least length of a match that covers only ACGTN) waves (1: > 1 = regions looked up side by side, the first form)
+//         cost (2: a match must cost less than the literals it replaces, priced by the 8 bytes at its start; 1: without the dna rule; 0: off) cbase (13)
 //         hist (0: bytes of history before the sub-block) far (0: a match of < far_len bytes farther than `far` is dropped) far_len (0)
 #include <algorithm>
 #include <array>
@@ -26,7 +28,7 @@
 
 static std::map<std::string, long> opt = {{"sub", 65536}, {"waves", 1},  {"hash", 11},   {"minlen", 4}, {"ways", 2},
                                           {"hist", 0},    {"lazy", 1},   {"far", 0},     {"far_len", 0}, {"maxlen", 256},
-                                          {"dna", 12},    {"nice", 32},  {"look", 256}, {"cut", 16384}, {"run", 1}};
+                                          {"dna", 12},    {"nice", 32},  {"look", 256}, {"cut", 16384}, {"run", 1},    {"cost", 2},   {"cbase", 13}};
 
 static double huff_bits(const std::vector<uint64_t>& f) {  // total bits of an (unlimited) Huffman code for these counts
     std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> q;
@@ -75,7 +77,7 @@ int main(int argc, char** argv) {
     while ((r = fread(buf, 1, sizeof buf, f)) > 0) text.insert(text.end(), buf, buf + r);
     fclose(f);
     const long SUB = opt["sub"], W = opt["waves"], HB = opt["hash"], MINLEN = opt["minlen"], WAYS = opt["ways"], HIST = opt["hist"],
-               MAXLEN = opt["maxlen"], LAZY = opt["lazy"], FAR = opt["far"], FAR_LEN = opt["far_len"], DNA = opt["dna"], NICE = opt["nice"], LOOK = opt["look"], CUT = opt["cut"], RUN = opt["run"];
+               MAXLEN = opt["maxlen"], LAZY = opt["lazy"], FAR = opt["far"], FAR_LEN = opt["far_len"], DNA = opt["dna"], NICE = opt["nice"], LOOK = opt["look"], CUT = opt["cut"], RUN = opt["run"], COST = opt["cost"], CBASE = opt["cbase"];
     const size_t N = text.size();
     text.resize(N + 512, 0);
     double total_bits = 0;
@@ -97,6 +99,14 @@ int main(int argc, char** argv) {
             b[0] = (int32_t)p;
         };
         for (long p = -H; p + 4 <= 0 && p < 0; ++p) insert(p);  // (the device would enter the history in parallel)
+        // cost = 1: literal costs from the sub-block's byte histogram (bits, rounded), a match is taken when the literals it
+        // replaces (priced by the 8 bytes at its start) cost more than cbase + log2(distance) bits
+        int bcost[256];
+        {
+            uint64_t h[256] = {0};
+            for (long i = 0; i < L; ++i) ++h[t[i]];
+            for (int b = 0; b < 256; ++b) bcost[b] = h[b] ? std::max(1, std::min(12, (int)std::lround(std::log2((double)L / (double)h[b])))) : 12;
+        }
         std::vector<uint64_t> lf(286, 0), df(30, 0);
         uint64_t extra = 0;
         lf[256] = 1;
@@ -188,6 +198,13 @@ int main(int argc, char** argv) {
                         long cheap = 0;
                         for (long k = 0; k < 8; ++k) cheap += t[ps + k] && strchr("ACGTN", t[ps + k]) != nullptr;
                         if (cheap == 8) need = DNA;
+                    }
+                    if (COST) {
+                        long c8 = 0;
+                        for (long k = 0; k < 8; ++k) c8 += bcost[t[ps + k]];
+                        const long mbits = CBASE + (bdist > 1 ? 63 - __builtin_clzl((unsigned long)bdist) : 0);
+                        if (COST == 1) need = MINLEN;  // (cost = 2: the rule for bases stays as well)
+                        if (blen * c8 < mbits * 8) blen = 0;  // (length x average literal cost of the first 8 bytes) against the match's own cost
                     }
                     if (blen < need || (FAR && bdist > FAR && blen < FAR_LEN)) blen = 0;
                 };
