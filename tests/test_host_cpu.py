@@ -379,3 +379,35 @@ def test_c99_client_builds_against_the_header_and_fails_loudly_without_a_gpu(tmp
         assert r.returncode == 0, (r.stdout, r.stderr)
     else:
         assert r.returncode == 77 and "no CPU fallback" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_stage_accounting_of_the_host_io(tmp_path):
+    """qd_io_stage_seconds: thread-CPU seconds per stage of the reader / sink / pool -- names for every stage, nothing
+    negative, and a reader that inflates a BGZF file shows up under inflate and the scanner's stages (no GPU involved)."""
+    import ctypes as C
+    from quade_amd import hip_backend as hb, synth
+    from quade_amd.fastq_reader import FastqStream
+    lib = hb.load_library()
+    names, secs = (C.c_char_p * 32)(), (C.c_double * 32)()
+    lib.qd_io_stage_seconds(None, None, 0, 1)  # reset
+    paths, _ = synth.write_fastq_dataset(str(tmp_path), 60_000)
+    lib.qd_io_stage_seconds(None, None, 0, 1)  # (the dataset was written through the same pool)
+    st = FastqStream(paths["seq_R1"], 20_000)
+    n = 0
+    while True:
+        b = st.take()
+        n += b.n
+        m = b.n
+        b.release()
+        if m < 20_000:
+            break
+    st.close()
+    assert n == 60_000
+    k = lib.qd_io_stage_seconds(names, secs, 32, 0)
+    got = {names[i].decode(): secs[i] for i in range(k)}
+    assert k >= 12 and all(v >= 0 for v in got.values()), got
+    assert got["inflate (pool jobs)"] > 0 and got["scanner: copy into the batch"] > 0 and got["scanner: newlines"] > 0, got
+    assert got["sink: format records"] == 0 and got["sink: deflate on the host"] == 0, got
+    assert lib.qd_io_stage_seconds(names, secs, 3, 1) == 3  # cap is respected; reset
+    lib.qd_io_stage_seconds(names, secs, 32, 0)
+    assert secs[0] == 0
