@@ -20,7 +20,7 @@ def _run(args, env=None, launcher=None):
 
 
 def test_single_gpu_line():
-    j = _run(["--steps", "3", "--warmup", "1", "--pairs", "3000000", "--cpu-sample", "20000", "--e2e-pairs", "30000",
+    j = _run(["--steps", "3", "--warmup", "1", "--pairs", "3000000", "--cpu-sample", "20000", "--e2e-pairs", "30000", "--e2e-chunks", "1",
               "--strong-sample", "1000000"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
