@@ -128,6 +128,8 @@ def test_device_lz_members_inflate_with_zlib_to_the_text():
             for t, m, h in zip(pieces[:2], members[:2], huff):
                 z1 = len(zlib.compress(t, 1))
                 assert len(m) < 0.97 * len(h) and len(m) < z1, (len(t), len(m), len(h), z1)  # smaller than zlib's level 1
+            # ... and, on the records with binned qualities, within 3 % of zlib's level 6 (the parse's choices are tuned there)
+            assert len(members[0]) < 1.03 * len(zlib.compress(pieces[0], 6)), (len(members[0]), len(zlib.compress(pieces[0], 6)))
             assert len(members[11]) < 2000 and len(members[12]) < 2000  # runs: one match per 256 bytes
         # the two levels alternate on one deflater
         assert gzip.decompress(_run(lib, d, [fqb[:100000]], False, level=-1)[0]) == fqb[:100000]
