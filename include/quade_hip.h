@@ -392,6 +392,10 @@ int qd_inflater_run_pinned(qd_inflater* inflater, const uint8_t* comp, int64_t c
                            int32_t* bad_block);
 void* qd_pinned_alloc(int64_t bytes); /* NULL on failure */
 void qd_pinned_free(void* p);
+/* ABI v4.  Which kernel inflates the blocks: 1 (the default) = one wave per block, one symbol after the other; 2 = 256 lanes per block
+ * (guessed starts that synchronise, matches resolved from a list: quade_inflate.hip).  Same results, same status codes.
+ * The environment variable QUADE_INFLATE_FORM sets the form new inflaters start with. */
+int qd_inflater_set_form(qd_inflater* inflater, int32_t form);
 int qd_inflater_destroy(qd_inflater* inflater);
 const char* qd_inflater_last_error(const qd_inflater* inflater);
 /* A reader whose BGZF runs go through an inflater on `device_id` (< 0: host threads, as qd_reader_open). */

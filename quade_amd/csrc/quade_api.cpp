@@ -1113,6 +1113,10 @@ struct qd_inflater {
     int32_t *h_st = nullptr, *d_st = nullptr;
     size_t cap_blk = 0, cap_st = 0;
     std::vector<uint32_t> crc;
+    // the kernel's second form (256 lanes per block; QUADE_INFLATE_FORM=2 or qd_inflater_set_form): its match lists
+    int form = 1;
+    unsigned long long* d_matches = nullptr;
+    size_t cap_matches = 0;  // blocks the scratch holds
 };
 
 namespace {
@@ -1177,6 +1181,7 @@ int qd_inflater_create(int device_id, qd_inflater** out) {
         delete f;
         return QD_ERR_HIP;
     }
+    if (const char* e = getenv("QUADE_INFLATE_FORM")) f->form = atoi(e) == 2 ? 2 : 1;
     *out = f;
     return QD_OK;
 }
@@ -1199,7 +1204,14 @@ int qd_inflater_destroy(qd_inflater* f) {
     if (f->d_blk) (void)hipFree(f->d_blk);
     if (f->h_st) (void)hipHostFree(f->h_st);
     if (f->d_st) (void)hipFree(f->d_st);
+    if (f->d_matches) (void)hipFree(f->d_matches);
     delete f;
+    return QD_OK;
+}
+
+int qd_inflater_set_form(qd_inflater* f, int32_t form) {
+    if (!f || (form != 1 && form != 2)) return QD_ERR_INVALID;
+    f->form = form;
     return QD_OK;
 }
 
@@ -1271,7 +1283,44 @@ static int inflater_run(qd_inflater* f, const uint8_t* comp, int64_t comp_len, u
     memcpy(f->h_blk, blk.data(), blk.size() * sizeof(qd_inflate_block));
     INFCHK(f, hipMemcpyAsync(f->d_comp, f->h_comp, (size_t)comp_len, hipMemcpyHostToDevice, f->stream));
     INFCHK(f, hipMemcpyAsync(f->d_blk, f->h_blk, blk.size() * sizeof(qd_inflate_block), hipMemcpyHostToDevice, f->stream));
-    INFCHK(f, qd_launch_inflate(f->d_comp, f->d_blk, (uint32_t)blk.size(), f->d_out, f->d_st, f->stream));
+    uint32_t longest = 0;
+    for (const qd_inflate_block& bk : blk) longest = std::max(longest, bk.in_len);
+    if (f->form == 2 && qd_inflate2_lds(longest) <= 160 * 1024) {  // (a run with a payload beyond ~52 KB -- stored blocks -- takes the first form)
+        if (blk.size() > f->cap_matches) {
+            if (f->d_matches) (void)hipFree(f->d_matches);
+            f->d_matches = nullptr;
+            f->cap_matches = 0;
+            const size_t nb = blk.size() + blk.size() / 4 + 16;
+            INFCHK(f, hipMalloc((void**)&f->d_matches, nb * (size_t)QD_INFLATE_MATCHES_PER_BLOCK * 8));
+            f->cap_matches = nb;
+        }
+        static const bool debug_rounds = getenv("QUADE_INFLATE_DEBUG") != nullptr;  // measurement: rounds per block on stderr
+        uint32_t* d_rounds = nullptr;
+        if (debug_rounds) INFCHK(f, hipMalloc((void**)&d_rounds, blk.size() * 32));
+        INFCHK(f, qd_launch_inflate2(f->d_comp, f->d_blk, (uint32_t)blk.size(), f->d_out, f->d_st, f->d_matches, QD_INFLATE_MATCHES_PER_BLOCK, longest,
+                                     f->stream, d_rounds));
+        if (debug_rounds) {
+            std::vector<uint32_t> r(blk.size() * 8);
+            INFCHK(f, hipMemcpy(r.data(), d_rounds, blk.size() * 32, hipMemcpyDeviceToHost));
+            (void)hipFree(d_rounds);
+            uint64_t sum = 0, db = 0, tk[8] = {0};
+            uint32_t mx = 0, over8 = 0;
+            for (size_t q = 0; q < blk.size(); ++q) {
+                const uint32_t v = r[8 * q];
+                sum += v & 0xFFFF;
+                db += v >> 16;
+                mx = std::max(mx, v & 0xFFFF);
+                over8 += (v & 0xFFFF) > 8;
+                for (int k = 1; k < 8; ++k) tk[k] += r[8 * q + k];
+            }
+            const double us = 0.01 / (double)blk.size();  // 100 MHz ticks -> microseconds per block
+            fprintf(stderr, "[inflate form 2] %zu blocks: %.2f rounds and %.2f deflate blocks per block, most %u, %u blocks over 8 rounds; us per block: stage %.0f "
+                            "header+tables %.0f rounds %.0f scan+write %.0f matches %.0f flush %.0f; %.0f matches per block\n", blk.size(), (double)sum / blk.size(),
+                    (double)db / blk.size(), mx, over8, tk[1] * us, tk[2] * us, tk[3] * us, tk[4] * us, tk[5] * us, tk[6] * us, (double)tk[7] / blk.size());
+        }
+    } else {
+        INFCHK(f, qd_launch_inflate(f->d_comp, f->d_blk, (uint32_t)blk.size(), f->d_out, f->d_st, f->stream));
+    }
     INFCHK(f, hipMemcpyAsync(f->h_st, f->d_st, blk.size() * 4, hipMemcpyDeviceToHost, f->stream));
     if (out_len) INFCHK(f, hipMemcpyAsync(text, f->d_out, (size_t)out_len, hipMemcpyDeviceToHost, f->stream));
     INFCHK(f, hipEventRecord(f->done, f->stream));

@@ -20,3 +20,11 @@ struct qd_inflate_block {
 
 hipError_t qd_launch_inflate(const uint8_t* comp, const qd_inflate_block* blocks, uint32_t n_blocks, uint8_t* out,
                              int32_t* status, hipStream_t st);
+
+// Second form: 256 lanes per block (speculative spans that synchronise; matches resolved from a list).  matches: scratch of
+// n_blocks x matches_per_block 64-bit entries; max_in_len: the longest payload of the launch (sizes the workgroups' LDS).
+#define QD_INFLATE_MATCHES_PER_BLOCK 12288
+size_t qd_inflate2_lds(uint32_t max_in_len);  // LDS a workgroup of the second form needs; above 160 KB (payloads beyond ~52 KB: stored blocks) use the first
+hipError_t qd_launch_inflate2(const uint8_t* comp, const qd_inflate_block* blocks, uint32_t n_blocks, uint8_t* out, int32_t* status,
+                              unsigned long long* matches, uint32_t matches_per_block, uint32_t max_in_len, hipStream_t st,
+                              uint32_t* rounds_out = nullptr);  // rounds_out (measurement): per block, rounds | deflate blocks << 16

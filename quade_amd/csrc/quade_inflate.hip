@@ -203,6 +203,489 @@ __device__ int codes(Bits& b, Lds& L, uint8_t* o, uint32_t& opos, uint32_t olen,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Second form (late r03): the block's symbols decoded by 256 lanes at once.
+// The first form's chain -- one symbol after the other, run redundantly by a whole wave -- makes a launch take ~16 ms
+// whatever it holds and fills the GPU at 13 GB/s; end to end its lanes starve the coder's launches.  Here one
+// workgroup of 256 threads inflates a block:
+//   * header and tables of a deflate block as before (wave-uniform, cheap);
+//   * the block's bit range is cut into 256 spans.  Lane i decodes tokens from a GUESSED bit position near the start of its span
+//     until one ends behind the span, and reports where (exit position), how many bytes and matches it saw.  Lane 0's
+//     start is true; in the next round every lane starts where its predecessor ended.  Huffman codes resynchronise after
+//     a few symbols, so after 2-4 rounds every lane starts at its predecessor's exit: the chain 0, 1, ... up to the lane
+//     that meets the end-of-block symbol is then exactly the sequential decode (each round confirms at least one more
+//     lane, so 256 rounds bound it);
+//   * a scan of the byte and match counts places every span's output; the lanes decode their spans once more, writing
+//     literals into the block's text in LDS and matches (destination, length, distance) into a list in text order;
+//   * one wave walks the list, every match copied by its 64 lanes inside LDS; the text leaves with coalesced stores.
+// The payload is staged in LDS too (a lane reads bits at arbitrary positions).  Same status codes and bounds as the first form.
+#ifndef QD_INFLATE2_MAX_ROUNDS
+#define QD_INFLATE2_MAX_ROUNDS (256 + 1) /* every round confirms at least one more lane (A/B: a small bound shows how many rounds real blocks need) */
+#endif
+namespace v2 {
+constexpr int NT = 256;
+struct Lds2 {
+    Lds t;
+    uint32_t start[NT], exitp[NT], nout[NT], nmat[NT], flag[NT];
+    uint32_t ctl[8];
+};
+enum { F_EOB = 1, F_ERR_CODE = 2, F_ERR_TRUNC = 4 };
+
+__device__ __forceinline__ uint32_t peek(const uint32_t* pw, uint32_t pos) {  // 32 bits of the payload from bit `pos` on
+    const uint32_t i = pos >> 5;
+    return __builtin_amdgcn_alignbit(pw[i + 1], pw[i], pos & 31u);
+}
+// canonical decode of a code longer than the first-level table; bits = the stream from the code's first bit; -1 = none
+__device__ __forceinline__ int slow_sym(uint32_t bits, const uint16_t* count, const uint16_t* symbol, int nsym, uint32_t& used) {
+    int code = 0, first = 0, index = 0;
+#pragma unroll 1
+    for (int len = 1; len <= 15; ++len) {
+        code |= (int)((bits >> (len - 1)) & 1u);
+        const int c = (int)count[len];
+        if (code - c < first) {
+            used = (uint32_t)len;
+            const int at = index + (code - first);
+            return at < nsym ? (int)symbol[at] : -1;
+        }
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+// Tokens from bit `pos` on while they start before `limit`.  WRITE: literals -> ob[o...], matches -> list[m...].
+template <bool WRITE>
+__device__ __forceinline__ void decode_span(const uint32_t* pw, uint32_t total_bits, const Lds& L, int nlsym, int ndsym, uint32_t pos,
+                                            uint32_t limit, uint8_t* ob, uint32_t o, uint32_t olen, unsigned long long* list, uint32_t m,
+                                            uint32_t mcap, uint32_t& exit_pos, uint32_t& n_out, uint32_t& n_mat, uint32_t& flag) {
+    uint32_t out = 0, mat = 0, fl = 0;
+#pragma unroll 1
+    for (int guard = 0; guard < 70000 && pos < limit; ++guard) {
+        if (pos >= total_bits) {
+            fl = F_ERR_TRUNC;
+            break;
+        }
+        uint32_t w = peek(pw, pos);
+        int sym;
+        uint32_t used;
+        const uint32_t e = L.llut[w & ((1u << LBITS) - 1u)];
+        if (e >> 9) {
+            sym = (int)(e & 511u);
+            used = e >> 9;
+        } else {
+            sym = slow_sym(w, L.lcount, L.lsym, nlsym, used);
+            if (sym < 0) {
+                fl = F_ERR_CODE;
+                break;
+            }
+        }
+        pos += used;
+        if (sym < 256) {
+            if (WRITE) {
+                if (o + out < olen) ob[o + out] = (uint8_t)sym;
+                else fl = F_ERR_CODE;
+            }
+            ++out;
+            continue;
+        }
+        if (sym == 256) {
+            fl |= F_EOB;
+            break;
+        }
+        sym -= 257;
+        if (sym >= 29) {
+            fl = F_ERR_CODE;
+            break;
+        }
+        w >>= used;  // (code <= 15 bits + <= 5 extra bits: inside the 32 peeked)
+        const uint32_t le = LEXT[sym], len = (uint32_t)LBASE[sym] + (w & ((1u << le) - 1u));
+        pos += le;
+        w = peek(pw, pos);
+        int ds;
+        const uint32_t d = L.dlut[w & ((1u << DBITS) - 1u)];
+        if (d >> 5) {
+            ds = (int)(d & 31u);
+            used = d >> 5;
+        } else {
+            ds = slow_sym(w, L.dcount, L.dsym, ndsym, used);
+        }
+        if (ds < 0 || ds >= 30) {
+            fl = F_ERR_CODE;
+            break;
+        }
+        w >>= used;
+        const uint32_t de = DEXT[ds], dist = (uint32_t)DBASE[ds] + (w & ((1u << de) - 1u));
+        pos += used + de;
+        if (pos > total_bits) {
+            fl = F_ERR_TRUNC;
+            break;
+        }
+        if (WRITE) {
+            if (m + mat < mcap) list[m + mat] = (unsigned long long)(o + out) | ((unsigned long long)len << 20) | ((unsigned long long)dist << 32);
+            else fl = F_ERR_CODE;
+        }
+        out += len;
+        ++mat;
+    }
+    exit_pos = pos;
+    n_out = out;
+    n_mat = mat;
+    flag = fl;
+}
+
+__global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, const qd_inflate_block* blocks, uint32_t n_blocks, uint8_t* out,
+                                                           int32_t* status, unsigned long long* matches, uint32_t mcap, uint32_t pay_words,
+                                                           uint32_t* rounds_out) {
+    uint32_t rounds_used = 0, dblocks = 0;
+    uint64_t tm[8] = {(uint64_t)wall_clock64(), 0, 0, 0, 0, 0, 0, 0};  // measurement: where a block's time goes (100 MHz ticks), summed over its deflate blocks
+    auto stamp = [&](int k, uint64_t& since) {
+        const uint64_t now = (uint64_t)wall_clock64();
+        tm[k] += now - since;
+        since = now;
+    };
+    uint64_t since = tm[0];
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    Lds2& S = *reinterpret_cast<Lds2*>(lds_raw);
+    Lds& L = S.t;
+    uint32_t* pw = reinterpret_cast<uint32_t*>(lds_raw + ((sizeof(Lds2) + 15) & ~(size_t)15));  // the payload, pay_words + 4 words
+    uint32_t* ow = pw + pay_words + 4;                                                          // the text, 64 KiB + 16 bytes
+    uint8_t* ob = reinterpret_cast<uint8_t*>(ow);
+    const uint32_t i = blockIdx.x, tid = threadIdx.x;
+    if (i >= n_blocks) return;
+    const qd_inflate_block blk = blocks[i];
+    const uint32_t olen = blk.out_len, total_bits = blk.in_len * 8u;
+    unsigned long long* list = matches + (size_t)i * mcap;
+    int err = 0, last = 0;
+    uint32_t opos = 0;
+    if (olen > WINDOW || ((blk.in_len + 3) >> 2) > pay_words) err = QD_INFLATE_OVERRUN;
+    // the payload -> LDS (zero behind it)
+    for (uint32_t k = tid; k < pay_words + 4; k += NT) {
+        uint32_t w = 0;
+        const uint32_t at = 4 * k;
+        if (!err && at < blk.in_len) {
+            const uint8_t* p = comp + blk.in_off + at;
+            const uint32_t left = blk.in_len - at;
+            w = p[0];
+            if (left > 1) w |= (uint32_t)p[1] << 8;
+            if (left > 2) w |= (uint32_t)p[2] << 16;
+            if (left > 3) w |= (uint32_t)p[3] << 24;
+        }
+        pw[k] = w;
+    }
+    __syncthreads();
+    stamp(1, since);  // payload staged
+    Bits b{comp + blk.in_off, 0, blk.in_len, 0, 0, 0, 0};
+    fetch_ahead(b);
+#pragma unroll 1
+    for (int guard = 0; guard < 4096 && !last && !err; ++guard) {
+        refill(b);
+        last = (int)take(b, 1);
+        const int type = (int)take(b, 2);
+        if (b.cnt < 0) {
+            err = QD_INFLATE_TRUNCATED;
+            break;
+        }
+        if (type == 0) {  // stored: byte aligned LEN, NLEN, then LEN bytes
+            const int drop = b.cnt & 7;
+            b.buf >>= drop;
+            b.cnt -= drop;
+            refill(b);
+            if (b.cnt < 32) {
+                err = QD_INFLATE_TRUNCATED;
+                break;
+            }
+            const uint32_t len = take(b, 16), nlen = take(b, 16);
+            const uint32_t back = ((uint32_t)b.cnt >> 3) + b.ahead_bytes;
+            b.pos -= back;
+            b.buf = 0;
+            b.cnt = 0;
+            b.ahead = b.ahead_bytes = 0;
+            if ((len ^ 0xFFFFu) != nlen) err = QD_INFLATE_BAD_STORED;
+            else if (len > b.end - b.pos) err = QD_INFLATE_TRUNCATED;
+            else if (len > olen - opos) err = QD_INFLATE_OVERRUN;
+            else {
+                for (uint32_t k = tid; k < len; k += NT) ob[opos + k] = b.p[b.pos + k];
+                opos += len;
+                b.pos += len;
+                fetch_ahead(b);
+                __syncthreads();
+            }
+            continue;
+        }
+        if (type != 1 && type != 2) {
+            err = QD_INFLATE_BAD_TYPE;
+            break;
+        }
+        int nlen = 288, ndist = 30;
+        if (type == 1) {  // fixed codes
+            for (uint32_t s = tid; s < 288; s += NT) L.lengths[s] = s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8));
+            for (uint32_t s = tid; s < 30; s += NT) L.lengths[288 + s] = 5;
+            __syncthreads();
+        } else {  // dynamic codes: the code-length code first
+            nlen = (int)take(b, 5) + 257;
+            ndist = (int)take(b, 5) + 1;
+            const int ncode = (int)take(b, 4) + 4;
+            if (b.cnt < 0 || nlen > 286 || ndist > 30) {
+                err = b.cnt < 0 ? QD_INFLATE_TRUNCATED : QD_INFLATE_BAD_TABLE;
+                break;
+            }
+            if (tid < 19) L.lengths[tid] = 0;
+            __syncthreads();
+            for (int k = 0; k < ncode; ++k) {
+                refill(b);
+                const uint32_t v = take(b, 3);
+                if (tid == 0) L.lengths[CLORDER[k]] = (uint8_t)v;
+            }
+            __syncthreads();
+            if (b.cnt < 0 || build(L.lengths, 19, L.lcount, L.lsym, L.llut, 7, 9, tid) != 0) {
+                err = b.cnt < 0 ? QD_INFLATE_TRUNCATED : QD_INFLATE_BAD_TABLE;
+                break;
+            }
+            int idx = 0, prev = 0;
+#pragma unroll 1
+            while (idx < nlen + ndist && !err) {
+                refill(b);
+                int sym;
+                const uint32_t e = uni(L.llut[(uint32_t)b.buf & 127u]);
+                if (e >> 9) {
+                    sym = e & 511;
+                    b.buf >>= (e >> 9);
+                    b.cnt -= (e >> 9);
+                } else {
+                    sym = -1;
+                }
+                if (b.cnt < 0 || sym < 0 || sym > 18) {
+                    err = b.cnt < 0 ? QD_INFLATE_TRUNCATED : QD_INFLATE_BAD_CODE;
+                    break;
+                }
+                int rep = 1, v = sym;
+                if (sym == 16) {
+                    if (idx == 0) {
+                        err = QD_INFLATE_BAD_TABLE;
+                        break;
+                    }
+                    v = prev;
+                    rep = 3 + (int)take(b, 2);
+                } else if (sym == 17) {
+                    v = 0;
+                    rep = 3 + (int)take(b, 3);
+                } else if (sym == 18) {
+                    v = 0;
+                    rep = 11 + (int)take(b, 7);
+                }
+                if (b.cnt < 0 || idx + rep > nlen + ndist) {
+                    err = b.cnt < 0 ? QD_INFLATE_TRUNCATED : QD_INFLATE_BAD_TABLE;
+                    break;
+                }
+                for (int k = (int)tid; k < rep; k += NT) {
+                    const int at = idx + k;
+                    L.lengths[at < nlen ? at : 288 + (at - nlen)] = (uint8_t)v;
+                }
+                idx += rep;
+                prev = v;
+            }
+            if (err) break;
+            __syncthreads();
+            if (L.lengths[256] == 0) {
+                err = QD_INFLATE_BAD_TABLE;
+                break;
+            }
+        }
+        int r = build(L.lengths, nlen, L.lcount, L.lsym, L.llut, LBITS, 9, tid);
+        const int lit_codes = L.lcount[0] == 0xFFFF ? 0 : nlen - (int)L.lcount[0];
+        if (type == 2 && (r < 0 || (r > 0 && lit_codes != 1))) {
+            err = QD_INFLATE_BAD_TABLE;
+            break;
+        }
+        r = build(L.lengths + 288, ndist, L.dcount, L.dsym, L.dlut, DBITS, 5, tid);
+        const int dist_codes = L.dcount[0] == 0xFFFF ? 0 : ndist - (int)L.dcount[0];
+        if (type == 2 && (r < 0 || (r > 0 && dist_codes > 1))) {
+            err = QD_INFLATE_BAD_TABLE;
+            break;
+        }
+        stamp(2, since);  // header + tables
+        // ---- the block's symbols: 256 spans, guessed starts, rounds until the chain from lane 0 is confirmed up to the end-of-block symbol
+        const uint32_t bitpos = 8u * (b.pos - b.ahead_bytes) - (uint32_t)b.cnt;  // (cnt >= 0: checked above)
+        const uint32_t rest = total_bits > bitpos ? total_bits - bitpos : 0;
+        uint32_t span = (rest + NT - 1) / NT;
+        if (span < 64) span = 64;
+        const uint32_t my_limit = tid == NT - 1 ? 0xFFFFFFF0u : bitpos + (tid + 1) * span;
+        S.start[tid] = bitpos + tid * span;
+        __syncthreads();
+        uint32_t eob_lane = NT;
+#pragma unroll 1
+        for (int round = 0; round <= QD_INFLATE2_MAX_ROUNDS; ++round) {
+            uint32_t ex, no, nm, fl;
+            const uint32_t st = S.start[tid];
+            decode_span<false>(pw, total_bits, L, lit_codes, dist_codes, st, my_limit, ob, 0, olen, list, 0, mcap, ex, no, nm, fl);
+            S.exitp[tid] = ex;
+            S.nout[tid] = no;
+            S.nmat[tid] = nm;
+            S.flag[tid] = fl;
+            if (tid == 0) {
+                S.ctl[0] = NT;  // first lane that does not start at its predecessor's exit
+                S.ctl[1] = NT;  // first lane that ends the block or fails
+            }
+            __syncthreads();
+            if (tid > 0 && st != S.exitp[tid - 1]) atomicMin(&S.ctl[0], tid);
+            if (fl) atomicMin(&S.ctl[1], tid);
+            __syncthreads();
+            const uint32_t confirmed = S.ctl[0], ender = S.ctl[1];  // lanes [0, confirmed) are the sequential decode
+            __syncthreads();
+            if (ender < confirmed) {
+                eob_lane = ender;
+                break;
+            }
+            if (confirmed >= NT) break;  // every lane confirmed and none met the end: the payload ended first
+            if (tid > 0) S.start[tid] = S.exitp[tid - 1];
+            __syncthreads();
+            ++rounds_used;
+        }
+        ++rounds_used;
+        ++dblocks;
+        stamp(3, since);  // rounds
+        if (eob_lane >= NT) {
+            err = QD_INFLATE_TRUNCATED;
+            break;
+        }
+        if (!(S.flag[eob_lane] & F_EOB) || (S.flag[eob_lane] & (F_ERR_CODE | F_ERR_TRUNC))) {
+            err = (S.flag[eob_lane] & F_ERR_TRUNC) ? QD_INFLATE_TRUNCATED : QD_INFLATE_BAD_CODE;
+            break;
+        }
+        // where every span's bytes and matches go (one lane sums 256 counts)
+        if (tid == 0) {
+            uint32_t o = opos, m = 0;
+            for (uint32_t k = 0; k <= eob_lane; ++k) {
+                const uint32_t no = S.nout[k], nm = S.nmat[k];
+                S.nout[k] = o;
+                S.nmat[k] = m;
+                o += no;
+                m += nm;
+            }
+            S.ctl[2] = o;
+            S.ctl[3] = m;
+        }
+        __syncthreads();
+        const uint32_t new_opos = S.ctl[2], n_matches = S.ctl[3];
+        tm[7] += n_matches;
+        if (new_opos > olen) {
+            err = QD_INFLATE_OVERRUN;
+            break;
+        }
+        if (n_matches > mcap) {
+            err = QD_INFLATE_OVERRUN;  // (more matches than the list holds: the host inflates this run)
+            break;
+        }
+        if (tid <= eob_lane) {
+            uint32_t ex, no, nm, fl;
+            decode_span<true>(pw, total_bits, L, lit_codes, dist_codes, S.start[tid], my_limit, ob, S.nout[tid], olen, list, S.nmat[tid], mcap, ex, no,
+                              nm, fl);
+        }
+        __threadfence_block();
+        __syncthreads();
+        stamp(4, since);  // scan + write pass
+        // The matches.  Walking them in text order, one dependent LDS read -> write trip each, took 1.2 of a block's 1.8 ms (6 800
+        // matches per block of libdeflate-1 fastq), whatever was batched.  Instead every byte that a match produces gets a
+        // parent -- the byte `distance` before it (true for overlapping matches too) -- and the chains are shortened by
+        // pointer jumping: a byte whose parent is final takes its value and becomes final, another one adopts its parent's
+        // parent; every round halves the chains (a name copied from record to record through a whole block: 8 rounds).
+        // A quarter of the text (16 Ki positions) at a time: that many 16-bit parents fit LDS beside the text.
+        {
+            constexpr uint32_t Q = 16384;
+            // (volatile: a lane reads a parent's state, then -- only if that is final -- its byte; the two reads stay in that order,
+            //  as the writes "byte, then final" of the lane that owns the parent do)
+            volatile uint16_t* par = reinterpret_cast<volatile uint16_t*>(ow + 16384 + 4);
+            volatile uint8_t* vob = ob;
+            if (tid == 0) S.ctl[4] = 0;
+            __syncthreads();
+#pragma unroll 1
+            for (uint32_t qb = (opos / Q) * Q; qb < new_opos; qb += Q) {
+                const uint32_t lo = max(qb, opos), hi = min(qb + Q, new_opos);  // (positions below `lo` are final)
+                for (uint32_t p = lo + tid; p < hi; p += NT) par[p - qb] = (uint16_t)p;
+                __syncthreads();
+                for (uint32_t m = tid; m < n_matches; m += NT) {
+                    const unsigned long long e = list[m];
+                    const uint32_t d = (uint32_t)e & 0xFFFFFu, len = ((uint32_t)e >> 20), dist = (uint32_t)(e >> 32);
+                    if (dist == 0 || dist > d || len > olen - d) {
+                        S.ctl[4] = 1;
+                        continue;
+                    }
+                    const uint32_t a = max(d, lo), z = min(d + len, hi);
+                    for (uint32_t p = a; p < z; ++p) par[p - qb] = (uint16_t)(p - dist);
+                }
+                __syncthreads();
+#pragma unroll 1
+                for (int round = 0; round < 20; ++round) {
+                    if (tid == 0) S.ctl[5] = 0;
+                    __syncthreads();
+                    uint32_t pending = 0;
+                    for (uint32_t p = lo + tid; p < hi; p += NT) {
+                        const uint32_t q = par[p - qb];
+                        if (q == p) continue;
+                        if (q < lo || par[q - qb] == q) {
+                            vob[p] = vob[q];
+                            par[p - qb] = (uint16_t)p;
+                        } else {
+                            par[p - qb] = par[q - qb];
+                            pending = 1;
+                        }
+                    }
+                    if (pending) S.ctl[5] = 1;
+                    __syncthreads();
+                    if (S.ctl[5] == 0) break;
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();
+        stamp(5, since);  // matches
+        if (S.ctl[4]) {
+            err = QD_INFLATE_BAD_DISTANCE;
+            break;
+        }
+        opos = new_opos;
+        // the next deflate block's header starts where the end-of-block symbol ended
+        {
+            const uint32_t np = S.exitp[eob_lane];
+            __syncthreads();
+            b.pos = np >> 3;
+            b.buf = 0;
+            b.cnt = 0;
+            b.ahead = b.ahead_bytes = 0;
+            fetch_ahead(b);
+            refill(b);
+            refill(b);
+            const int drop = (int)(np & 7u);
+            b.buf >>= drop;
+            b.cnt -= drop;
+        }
+    }
+    if (!err && !last) err = QD_INFLATE_BAD_TYPE;
+    if (!err && opos != olen) err = QD_INFLATE_LENGTH;
+    __syncthreads();
+    if (!err) {  // the text leaves: bytes up to the first 4-byte boundary of the destination, dwords, the tail
+        uint8_t* const o = out + blk.out_off;
+        const uint32_t head = min(olen, (uint32_t)((4u - ((uintptr_t)o & 3u)) & 3u));
+        if (tid < head) o[tid] = ob[tid];
+        const uint32_t nd = (olen - head) >> 2;
+        for (uint32_t k = tid; k < nd; k += NT) {
+            const uint32_t at = head + 4 * k, wi = at >> 2;
+            *reinterpret_cast<uint32_t*>(o + at) = __builtin_amdgcn_alignbyte(ow[wi + 1], ow[wi], at & 3u);
+        }
+        for (uint32_t k = head + 4 * nd + tid; k < olen; k += NT) o[k] = ob[k];
+    }
+    stamp(6, since);  // flush
+    if (tid == 0) status[i] = err;
+    if (tid == 0 && rounds_out) {
+        rounds_out[8 * i] = rounds_used | (dblocks << 16);
+        for (int k = 1; k < 8; ++k) rounds_out[8 * i + k] = (uint32_t)tm[k];
+    }
+}
+}  // namespace v2
+
 }  // namespace
 
 // One workgroup of 64 lanes (one wave) per block.  blocks[i]: payload (raw deflate) at comp + in_off, in_len bytes
@@ -354,6 +837,24 @@ __global__ __launch_bounds__(64) void inflate_bgzf_blocks(const uint8_t* comp, c
     if (!err && !last) err = QD_INFLATE_BAD_TYPE;
     if (!err && opos != olen) err = QD_INFLATE_LENGTH;
     if (lane == 0) status[i] = err;
+}
+
+// dynamic LDS of the second form's workgroups for a launch whose longest payload is max_in_len bytes: tables | payload | text | parents
+size_t qd_inflate2_lds(uint32_t max_in_len) {
+    return ((sizeof(v2::Lds2) + 15) & ~(size_t)15) + ((size_t)((max_in_len + 3) / 4) + 4) * 4 + 65536 + 16 + 32768;
+}
+
+hipError_t qd_launch_inflate2(const uint8_t* comp, const qd_inflate_block* blocks, uint32_t n_blocks, uint8_t* out, int32_t* status,
+                              unsigned long long* matches, uint32_t matches_per_block, uint32_t max_in_len, hipStream_t st, uint32_t* rounds_out) {
+    if (n_blocks == 0) return hipSuccess;
+    const uint32_t pay_words = (max_in_len + 3) / 4;
+    const size_t lds = qd_inflate2_lds(max_in_len);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::inflate_bgzf_blocks2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(v2::inflate_bgzf_blocks2, dim3(n_blocks), dim3(v2::NT), lds, st, comp, blocks, n_blocks, out, status, matches,
+                       matches_per_block, pay_words, rounds_out);
+    return hipGetLastError();
 }
 
 hipError_t qd_launch_inflate(const uint8_t* comp, const qd_inflate_block* blocks, uint32_t n_blocks, uint8_t* out,

@@ -124,6 +124,7 @@ SYMBOLS = [
     ("qd_deflater_run", C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int64, _P]),
     ("qd_huffman_member_bound", C.c_int64, [C.c_int64]),
     ("qd_deflater_set_level", C.c_int, [_P, C.c_int32]),
+    ("qd_inflater_set_form", C.c_int, [_P, C.c_int32]),
     ("qd_deflater_destroy", C.c_int, [_P]),
     ("qd_deflater_last_error", C.c_char_p, [_P]),
     ("qd_sink_set_device_deflate", C.c_int, [_P, C.c_int32]),
