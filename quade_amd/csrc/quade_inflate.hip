@@ -97,23 +97,32 @@ __device__ int slow_decode(Bits& b, const uint16_t* count, const uint16_t* symbo
     return -1;
 }
 
-// Tables of one Huffman code from n code lengths (lane 0 writes; the wave waits).  Returns 0 for a complete code,
-// > 0 incomplete, < 0 over-subscribed.  lut entries: symbol | length << shift for codes of at most `bits` bits.
+// Tables of one Huffman code from n code lengths, by all threads of the workgroup: the lengths are counted with LDS atomics, one
+// thread derives the first code and the first slot of every length, then every thread places its symbols (a symbol's place among
+// those of its length = how many earlier symbols have that length) and fills their look-up entries.  (Lane 0 alone -- a chain
+// of dependent LDS read-modify-writes per symbol -- took ~90 us per block of the second form's 580.)  Returns 0 for a complete
+// code, > 0 incomplete, < 0 over-subscribed.  lut entries: symbol | length << shift for codes of at most `bits` bits.
 __device__ int build(const uint8_t* length, int n, uint16_t* count, uint16_t* symbol, uint16_t* lut, int bits, int shift,
                      uint32_t lane) {
-    for (uint32_t i = lane; i < (1u << bits); i += 64) lut[i] = 0;
+    const uint32_t nthr = blockDim.x;
+    __shared__ uint32_t cnt32[16];
+    __shared__ uint16_t offs[16], next[16];
+    __shared__ int verdict, usable;
+    for (uint32_t i = lane; i < (1u << bits); i += nthr) lut[i] = 0;
+    if (lane < 16) cnt32[lane] = 0;
     __syncthreads();
-    int left = 1;
+    for (uint32_t s = lane; s < (uint32_t)n; s += nthr) atomicAdd(&cnt32[length[s] & 15], 1u);
+    __syncthreads();
     if (lane == 0) {
-        uint16_t offs[16], next[16];
-        for (int l = 0; l <= 15; ++l) count[l] = 0;
-        for (int s = 0; s < n; ++s) ++count[length[s] & 15];
+        int left = 1;
+        for (int l = 0; l <= 15; ++l) count[l] = (uint16_t)cnt32[l];
         for (int l = 1; l <= 15; ++l) {
             left <<= 1;
             left -= count[l];
             if (left < 0) break;
         }
-        if (left >= 0 && count[0] != n) {
+        usable = left >= 0 && count[0] != n;
+        if (usable) {
             offs[1] = 0;
             int code = 0;
             next[0] = 0;
@@ -122,24 +131,26 @@ __device__ int build(const uint8_t* length, int n, uint16_t* count, uint16_t* sy
                 next[l] = (uint16_t)code;
                 if (l < 15) offs[l + 1] = offs[l] + count[l];
             }
-#pragma unroll 1
-            for (int s = 0; s < n; ++s) {
-                const int l = length[s] & 15;
-                if (!l) continue;
-                symbol[offs[l]++] = (uint16_t)s;
-                const uint32_t c = next[l]++;
-                if (l <= bits) {  // the stream carries codes MSB first inside an LSB-first bit order: index by the reversed code
-                    const uint32_t rev = __brev(c) >> (32 - l);
-                    const uint16_t e = (uint16_t)(s | (l << shift));
-                    for (uint32_t k = rev; k < (1u << bits); k += 1u << l) lut[k] = e;
-                }
-            }
         }
         count[0] = (uint16_t)(count[0] == n ? 0xFFFF : count[0]);  // no codes at all: marked
+        verdict = left;
     }
-    // every lane needs the verdict: through LDS (lengths[] is free for that after the build; use lut-independent slot)
-    __shared__ int verdict;
-    if (lane == 0) verdict = left;
+    __syncthreads();
+    if (usable) {
+        for (uint32_t s = lane; s < (uint32_t)n; s += nthr) {
+            const uint32_t l = length[s] & 15;
+            if (!l) continue;
+            uint32_t rank = 0;
+            for (uint32_t q = 0; q < s; ++q) rank += (length[q] & 15u) == l ? 1u : 0u;
+            symbol[offs[l] + rank] = (uint16_t)s;
+            const uint32_t c = next[l] + rank;
+            if ((int)l <= bits) {  // the stream carries codes MSB first inside an LSB-first bit order: index by the reversed code
+                const uint32_t rev = __brev(c) >> (32 - l);
+                const uint16_t e = (uint16_t)(s | (l << shift));
+                for (uint32_t k = rev; k < (1u << bits); k += 1u << l) lut[k] = e;
+            }
+        }
+    }
     __syncthreads();
     return verdict;
 }
@@ -221,10 +232,13 @@ __device__ int codes(Bits& b, Lds& L, uint8_t* o, uint32_t& opos, uint32_t olen,
 //   * one wave walks the list, every match copied by its 64 lanes inside LDS; the text leaves with coalesced stores.
 // The payload is staged in LDS too (a lane reads bits at arbitrary positions).  Same status codes and bounds as the first form.
 #ifndef QD_INFLATE2_MAX_ROUNDS
-#define QD_INFLATE2_MAX_ROUNDS (256 + 1) /* every round confirms at least one more lane (A/B: a small bound shows how many rounds real blocks need) */
+#define QD_INFLATE2_MAX_ROUNDS (1024 + 1) /* every round confirms at least one more lane (A/B: a small bound shows how many rounds real blocks need) */
+#endif
+#ifndef QD_INFLATE2_THREADS
+#define QD_INFLATE2_THREADS 512 /* lanes (= spans) per block: 0.58 ms per block against 0.83 with 256 (rounds 211 vs 298 us, write 98 vs 155, matches 136 vs 235) */
 #endif
 namespace v2 {
-constexpr int NT = 256;
+constexpr int NT = QD_INFLATE2_THREADS;
 struct Lds2 {
     Lds t;
     uint32_t start[NT], exitp[NT], nout[NT], nmat[NT], flag[NT];
@@ -377,7 +391,8 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
     }
     __syncthreads();
     stamp(1, since);  // payload staged
-    Bits b{comp + blk.in_off, 0, blk.in_len, 0, 0, 0, 0};
+    // (the headers are read from the staged copy as well: the wave-uniform reader's byte loads then cost an LDS trip, not a global one)
+    Bits b{reinterpret_cast<const uint8_t*>(pw), 0, blk.in_len, 0, 0, 0, 0};
     fetch_ahead(b);
 #pragma unroll 1
     for (int guard = 0; guard < 4096 && !last && !err; ++guard) {
