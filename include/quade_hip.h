@@ -392,8 +392,8 @@ int qd_inflater_run_pinned(qd_inflater* inflater, const uint8_t* comp, int64_t c
                            int32_t* bad_block);
 void* qd_pinned_alloc(int64_t bytes); /* NULL on failure */
 void qd_pinned_free(void* p);
-/* ABI v4.  Which kernel inflates the blocks: 1 (the default) = one wave per block, one symbol after the other; 2 = 256 lanes per block
- * (guessed starts that synchronise, matches resolved from a list: quade_inflate.hip).  Same results, same status codes.
+/* ABI v4.  Which kernel inflates the blocks: 2 (the default) = 512 lanes per block (spans decoded from guessed starts that synchronise,
+ * matches resolved by pointer jumping: quade_inflate.hip); 1 = one wave per block, one symbol after the other (r02).  Same results, same status codes.
  * The environment variable QUADE_INFLATE_FORM sets the form new inflaters start with. */
 int qd_inflater_set_form(qd_inflater* inflater, int32_t form);
 int qd_inflater_destroy(qd_inflater* inflater);

@@ -33,8 +33,10 @@ Optional [gpu] section (not in Quade 0.3.2; a conf file without it runs with the
   device_deflate : True  with gzip_level -1 or 1: the output members are made on the GPU (-1: one workgroup per ~2 MB piece of
                          formatted text, Huffman coding only; 1: LZ77 + Huffman, one workgroup per 64 KiB of it) while
                          page-locked buffers last, on the host's pool otherwise; no effect at the other levels
-  device_inflate : False BGZF (bgzip) input files are inflated on the GPU, one block per wave (default: on host threads --
-                         on a 16-core host both ways run at the same rate; the GPU way uses 5-10 % less CPU)
+  device_inflate : True  BGZF (bgzip) input files are inflated on the GPU, one workgroup of 512 lanes per block (every block's
+                         CRC-32 is checked on the host, a run that fails is inflated there): on a 16-core host + 16 % end to end
+                         on records with random qualities, level on binned ones, 20-30 % less CPU either way; ordinary gzip
+                         files are inflated by the host's threads whatever this says
 """
 
 
@@ -111,7 +113,7 @@ class QuadeConf(object):
         self.gzip_level = opt("gzip_level", 1)
         self.chunk_workers = opt("chunk_workers", 1)
         self.io_threads = opt("io_threads", 0)
-        self.device_inflate = opt("device_inflate", "False", str).strip().lower() in ("true", "1", "yes", "on")
+        self.device_inflate = opt("device_inflate", "True", str).strip().lower() in ("true", "1", "yes", "on")
         self.device_deflate = opt("device_deflate", "True", str).strip().lower() in ("true", "1", "yes", "on")
 
         self._test_values()

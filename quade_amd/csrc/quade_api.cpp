@@ -1113,8 +1113,8 @@ struct qd_inflater {
     int32_t *h_st = nullptr, *d_st = nullptr;
     size_t cap_blk = 0, cap_st = 0;
     std::vector<uint32_t> crc;
-    // the kernel's second form (256 lanes per block; QUADE_INFLATE_FORM=2 or qd_inflater_set_form): its match lists
-    int form = 1;
+    // which kernel: 2 (the default) = 512 lanes per block, 1 = one wave per block (QUADE_INFLATE_FORM / qd_inflater_set_form); the second form's match lists
+    int form = 2;
     unsigned long long* d_matches = nullptr;
     size_t cap_matches = 0;  // blocks the scratch holds
 };
@@ -1152,6 +1152,11 @@ thread_local std::string g_inflater_error;
 // hipEventBlockingSync (measured: the reader's device lanes burnt 0.95 core-seconds per M pairs waiting for their kernels,
 // profiles/r03_e2e_16m_level1_stages_device_inflate.txt).  A few immediate polls (short kernels), then naps of 100 us.
 hipError_t wait_event_napping(hipEvent_t ev) {
+    static const int nap_us = [] {
+        const char* e = getenv("QUADE_NAP_US");  // measurement knob
+        const int v = e && *e ? atoi(e) : 100;
+        return v < 10 ? 10 : (v > 5000 ? 5000 : v);
+    }();
     for (int i = 0; i < 64; ++i) {
         const hipError_t e = hipEventQuery(ev);
         if (e != hipErrorNotReady) return e;
@@ -1159,7 +1164,7 @@ hipError_t wait_event_napping(hipEvent_t ev) {
     for (;;) {
         const hipError_t e = hipEventQuery(ev);
         if (e != hipErrorNotReady) return e;
-        usleep(100);
+        usleep(nap_us);
     }
 }
 }  // namespace
@@ -1181,7 +1186,7 @@ int qd_inflater_create(int device_id, qd_inflater** out) {
         delete f;
         return QD_ERR_HIP;
     }
-    if (const char* e = getenv("QUADE_INFLATE_FORM")) f->form = atoi(e) == 2 ? 2 : 1;
+    if (const char* e = getenv("QUADE_INFLATE_FORM")) f->form = atoi(e) == 1 ? 1 : 2;
     *out = f;
     return QD_OK;
 }

@@ -1185,6 +1185,7 @@ int qd_inflater_create(int device_id, qd_inflater** out) __attribute__((weak));
 int qd_inflater_run(qd_inflater* inflater, const uint8_t* comp, int64_t comp_len, uint8_t* out, int64_t out_len,
                     int32_t* bad_block) __attribute__((weak));
 int qd_inflater_destroy(qd_inflater* inflater) __attribute__((weak));
+int qd_inflater_set_form(qd_inflater* inflater, int32_t form) __attribute__((weak));
 int qd_inflater_run_pinned(qd_inflater* inflater, const uint8_t* comp, int64_t comp_len, uint8_t* out, int64_t out_len,
                            int32_t* bad_block) __attribute__((weak));
 void* qd_pinned_alloc(int64_t bytes) __attribute__((weak));
@@ -1459,8 +1460,10 @@ struct BgzfRun {  // consecutive blocks inflated by one pool job
 
 constexpr size_t BGZF_RUN_BYTES = 2u << 20;  // compressed bytes per job
 std::atomic<int64_t> g_bgzf_in_flight{6};  // runs of blocks a reader keeps with the pool (qd_io_set_option "bgzf_in_flight")
-constexpr size_t BGZF_DEVICE_RUN_BYTES = 16u << 20;  // per device launch: ~500 blocks (a launch takes ~16 ms whether it holds 500 blocks or 8 000)
-std::atomic<int64_t> g_bgzf_device_lanes{3};         // launches in flight per reader (qd_io_set_option "bgzf_device_lanes")
+std::atomic<int64_t> g_bgzf_device_run_bytes{8 << 20};  // compressed bytes per device launch (qd_io_set_option "bgzf_device_run_bytes"): ~240 blocks,
+                                                         // one workgroup each for the inflater's second form (2 launches in flight x 8 MB measured best
+                                                         // end to end: profiles/r03_e2e_device_inflate_form2_ab.txt; the first form wanted 3 x 16 MB)
+std::atomic<int64_t> g_bgzf_device_lanes{2};         // launches in flight per reader (qd_io_set_option "bgzf_device_lanes")
 
 // the blocks of a run, one after the other, on this thread
 void host_inflate_run(BgzfRun& run, LibDeflate& L) {
@@ -1522,6 +1525,10 @@ void device_lane(qd_reader* r) {
     LibDeflate& L = deflate_lib();
     qd_inflater* inf = borrow_inflater(r->inflate_device);
     bool usable = inf != nullptr;
+    if (usable && qd_inflater_set_form) {  // (a borrowed inflater may have been made under another setting)
+        const char* fe = getenv("QUADE_INFLATE_FORM");
+        (void)qd_inflater_set_form(inf, fe && atoi(fe) == 1 ? 1 : 2);
+    }
     // test hook: pretend the device fails once the reader has inflated this many runs on it (the fall-back to the
     // host pool in the middle of a file is otherwise unreachable without breaking a GPU)
     const char* fa = getenv("QUADE_TEST_INFLATE_FAIL_AFTER");
@@ -1605,7 +1612,7 @@ bool inflate_bgzf(qd_reader* r, Input& in, int& cur, bool& ok) {
         // one run: whole blocks up to BGZF_RUN_BYTES
         std::shared_ptr<BgzfRun> run = std::make_shared<BgzfRun>();
         size_t out_bytes = 0;
-        while (run->in.size() < (on_device ? BGZF_DEVICE_RUN_BYTES : BGZF_RUN_BYTES)) {
+        while (run->in.size() < (on_device ? (size_t)g_bgzf_device_run_bytes.load() : BGZF_RUN_BYTES)) {
             if (!in.refill(1u << 17)) {
                 fail_reader(r, strerror(errno));
                 ok = false;
@@ -2017,6 +2024,7 @@ int qd_io_set_option(const char* name, int64_t value) {
     else if (n == "gunzip_in_flight" && value >= 0 && value <= 256) g_pgz_in_flight = value;
     else if (n == "bgzf_in_flight" && value >= 1 && value <= 256) g_bgzf_in_flight = value;
     else if (n == "bgzf_device_lanes" && value >= 1 && value <= 16) g_bgzf_device_lanes = value;
+    else if (n == "bgzf_device_run_bytes" && value >= (1 << 20) && value <= (16 << 20)) g_bgzf_device_run_bytes = value;
     else return QD_ERR_INVALID;
     return QD_OK;
 }

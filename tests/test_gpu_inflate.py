@@ -12,6 +12,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["1", "2"])
+def inflater_form(request, monkeypatch):
+    """Every test runs with both kernels: 1 = one wave per block, one symbol after the other; 2 = 512 lanes per block (spans decoded
+    from guessed starts that synchronise, matches resolved by pointer jumping)."""
+    monkeypatch.setenv("QUADE_INFLATE_FORM", request.param)
+    return request.param
+
+
 def _bgzf_block(text, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
     """one BGZF block (bgzip / htslib layout) of <= 65280 text bytes"""
     c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)

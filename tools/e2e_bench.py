@@ -30,7 +30,8 @@ batch = int(os.environ.get("E2E_BATCH", "500000"))
 work = tempfile.mkdtemp(prefix="quade_e2e_")
 from quade_amd import hip_backend as _hb  # noqa: E402
 for _name, _env in (("parallel_gunzip", "E2E_PARALLEL_GUNZIP"), ("gunzip_chunk_bytes", "E2E_GUNZIP_CHUNK"), ("gunzip_in_flight", "E2E_GUNZIP_IN_FLIGHT"),
-                    ("bgzf_in_flight", "E2E_BGZF_IN_FLIGHT"), ("bgzf_device_lanes", "E2E_BGZF_DEVICE_LANES")):
+                    ("bgzf_in_flight", "E2E_BGZF_IN_FLIGHT"), ("bgzf_device_lanes", "E2E_BGZF_DEVICE_LANES"),
+                    ("bgzf_device_run_bytes", "E2E_BGZF_DEVICE_RUN_BYTES")):
     if os.environ.get(_env):  # ordinary gzip inputs: the parallel inflater on / off, its chunk size, chunks in flight per file
         assert _hb.load_library().qd_io_set_option(_name.encode(), int(os.environ[_env])) == 0
 try:
