@@ -414,7 +414,7 @@ int qd_reader_inflate_stats(const qd_reader* reader, int64_t* device_runs, int64
  * (ordinary memory, out_stride >= qd_huffman_member_bound(longest piece), a multiple of 4), its length in
  * member_len[i]; member_len[i] == 0: that member did not fit out_stride (make it on the host).  Blocking.
  * qd_sink_set_device_deflate: the sink's Huffman-only members are made on `device_id` while the process has
- * page-locked buffers to spare (288 x 2.5 MB); a piece that finds none is coded on its pool thread as before, so the
+ * page-locked buffers to spare (576 x 2.75 MB, made as its six lanes come up); a piece that finds none is coded on its pool thread as before, so the
  * host and the device share the work; device_id < 0: host only (the default).  gzip_level -1 and 1 are affected (the levels
  * the device implements, qd_deflater_set_level); sinks at other levels ignore the device. */
 typedef struct qd_deflater qd_deflater;
