@@ -313,7 +313,7 @@ constexpr int LZ_SUB = QD_LZ_SUB, LZ_WAVES = 4, LZ_BLOCK = 64 * LZ_WAVES, LZ_REG
 constexpr int LZ_HASH_BITS = 11, LZ_NICE = 32, LZ_DNA_MIN = 12, LZ_MATCH_BITS = 13, LZ_MAXLEN = 256;
 constexpr int LZ_TEXT_WORDS = (LZ_SUB + 320) / 4;  // the text and what the widest compare may read behind it
 constexpr int LZ_NL = 286, LZ_ND = 30;
-static_assert(LZ_SUB == 65536, "table entries are 16-bit positions inside the sub-block");
+static_assert(LZ_SUB <= 65536 && LZ_SUB % 256 == 0, "table entries are 16-bit positions inside the sub-block");
 
 __device__ __forceinline__ uint32_t rd32(const uint32_t* tw, uint32_t p) {  // 4 bytes at any byte position of the LDS text
     const uint32_t i = p >> 2;
