@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""BGZF inflate: the device inflater (one lane per block) against libdeflate on one host thread, on synthetic 2x150 bp
+"""BGZF inflate: the device inflater (QUADE_INFLATE_FORM=1: one wave per block, 2 = the default: 512 lanes per block) against libdeflate on host threads, on synthetic 2x150 bp
 fastq text.  usage: python tools/inflate_bench.py [MB of text] [run MB of compressed bytes]"""
 import os
 import struct
