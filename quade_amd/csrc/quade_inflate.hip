@@ -238,6 +238,9 @@ __device__ int codes(Bits& b, Lds& L, uint8_t* o, uint32_t& opos, uint32_t olen,
 #define QD_INFLATE2_THREADS 512 /* lanes (= spans) per block: 0.58 ms per block against 0.83 with 256 (rounds 211 vs 298 us, write 98 vs 155, matches 136 vs 235) */
 #endif
 namespace v2 {
+#ifndef QD_INFLATE2_Q
+#define QD_INFLATE2_Q 16384 /* positions per window of the match stage (2 bytes of LDS each) */
+#endif
 constexpr int NT = QD_INFLATE2_THREADS;
 struct Lds2 {
     Lds t;
@@ -607,9 +610,9 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
         // parent -- the byte `distance` before it (true for overlapping matches too) -- and the chains are shortened by
         // pointer jumping: a byte whose parent is final takes its value and becomes final, another one adopts its parent's
         // parent; every round halves the chains (a name copied from record to record through a whole block: 8 rounds).
-        // A quarter of the text (16 Ki positions) at a time: that many 16-bit parents fit LDS beside the text.
+        // A window of the text (QD_INFLATE2_Q positions: a quarter by default) at a time: that many 16-bit parents lie in LDS beside the text.
         {
-            constexpr uint32_t Q = 16384;
+            constexpr uint32_t Q = QD_INFLATE2_Q;
             // (volatile: a lane reads a parent's state, then -- only if that is final -- its byte; the two reads stay in that order,
             //  as the writes "byte, then final" of the lane that owns the parent do)
             volatile uint16_t* par = reinterpret_cast<volatile uint16_t*>(ow + 16384 + 4);
@@ -856,7 +859,7 @@ __global__ __launch_bounds__(64) void inflate_bgzf_blocks(const uint8_t* comp, c
 
 // dynamic LDS of the second form's workgroups for a launch whose longest payload is max_in_len bytes: tables | payload | text | parents
 size_t qd_inflate2_lds(uint32_t max_in_len) {
-    return ((sizeof(v2::Lds2) + 15) & ~(size_t)15) + ((size_t)((max_in_len + 3) / 4) + 4) * 4 + 65536 + 16 + 32768;
+    return ((sizeof(v2::Lds2) + 15) & ~(size_t)15) + ((size_t)((max_in_len + 3) / 4) + 4) * 4 + 65536 + 16 + 2 * QD_INFLATE2_Q;
 }
 
 hipError_t qd_launch_inflate2(const uint8_t* comp, const qd_inflate_block* blocks, uint32_t n_blocks, uint8_t* out, int32_t* status,
