@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 4
+#define QD_ABI_VERSION 5
 
 #define QD_OK 0
 #define QD_ERR_INVALID (-1)     /* bad argument (NULL pointer, misaligned buffer, size out of range)   */
@@ -431,6 +431,64 @@ int qd_deflater_destroy(qd_deflater* deflater);
 const char* qd_deflater_last_error(const qd_deflater* deflater);
 int qd_sink_set_device_deflate(qd_sink* sink, int32_t device_id);
 int qd_sink_device_members(qd_sink* sink, int64_t* device_members); /* of qd_sink_stats' members: made on the device */
+
+/* ---- device-resident chunk pipeline (ABI v5) ---------------------------------------------------------------------
+ * Replaces, for whole chunks, the per-pair loop of Quade.double_index_parser / simple_index_parser and everything it
+ * calls (src/Quade.py:195-254: four FastqReader.next(), slice + fuse, Sample.FINDER; src/FastqWriter.py:48-90: name tag,
+ * record format, gzip append) with the fastq TEXT staying on the device between the stages: BGZF blocks are inflated
+ * there, records are found (a record whose sequence and quality lengths differ is dropped inside its own stream,
+ * SURVEY.md F6), pairs are formed in lock step (the chunk ends with its first exhausted stream, Quade.py:223-224), index
+ * rows are packed and matched (the context's counters move), records are scattered by routing code in input order,
+ * formatted ("@name:IDX[:MOL]", FastqWriter.py:61-69), CRC-32'd and coded into gzip members; only compressed bytes
+ * cross PCIe.  Inputs the device cannot inflate (ordinary gzip members, plain text) are inflated by the host's readers
+ * and join the same path as text.  The sink must be at gzip_level 1 or -1 (the levels the device codes).
+ * qd_pipe_run processes the chunks in order (input for the next chunks is read ahead) and returns when every member is
+ * in its file; it is driven by one thread, the context must not be used by another meanwhile.  begin_message /
+ * end_message (may be NULL) are printed to stdout when a chunk starts / when its last record is in its files. */
+typedef struct qd_pipe qd_pipe;
+typedef struct qd_pipe_chunk {
+    const char* r1;  /* seq_R1 file of the chunk (src/Quade.py:119) */
+    const char* r2;  /* seq_R2 */
+    const char* i1;  /* index_R1 */
+    const char* i2;  /* index_R2; NULL with a single-index plan */
+    qd_sink* sink;   /* where the chunk's records go (one sink for the run, or one per chunk part directory) */
+    const char* begin_message;
+    const char* end_message;
+} qd_pipe_chunk;
+typedef struct qd_pipe_stats {
+    int64_t pairs, batches;
+    int64_t bgzf_blocks;         /* inflated (and CRC-checked) on the device */
+    int64_t host_inflated_runs;  /* runs of BGZF blocks the device refused and the host inflated */
+    int64_t text_segments;       /* uploads of text inflated by the host's readers (ordinary gzip, plain files) */
+    int64_t pieces;              /* gzip members made */
+    int64_t host_coded_pieces;   /* of them by the host (a member that did not fit its slot on the device) */
+    int64_t text_in_bytes, text_out_bytes, gzip_bytes;
+    int64_t rescans;             /* window scans repeated (line table too small, host-inflated text) */
+} qd_pipe_stats;
+int qd_pipe_create(qd_ctx* ctx, qd_pipe** out); /* the context holds plan and barcodes */
+/* "batch_pairs": pairs per batch at most (default 2 000 000; windows of text are sized from it, at most 1 GiB per stream);
+ * "test_fail_inflate_batch": tests -- the device's BGZF result of that batch is treated as refused */
+int qd_pipe_set_option(qd_pipe* pipe, const char* name, int64_t value);
+int qd_pipe_run(qd_pipe* pipe, const qd_pipe_chunk* chunks, int32_t n_chunks, qd_pipe_stats* stats);
+const char* qd_pipe_last_error(const qd_pipe* pipe);
+int qd_pipe_destroy(qd_pipe* pipe);
+/* ---- the pipeline's device stages one at a time, over host buffers (bindings that hold text in memory; tests) ----------
+ * qd_dev_fastq_scan: the record scan of qd_pipe_run on `device_id` (what qd_fastq_index does on the host, same rules): text
+ * = whole lines from a record start on; at_eof: a last line without newline counts; need: reads shorter than this count as
+ * short; line_cap: lines the scan's table holds (result[5] != 0: more than that -- result[0] says how many).  recs_out:
+ * 6 uint32 per kept record (head, name_off, name_len, seq, seq_len, qual -- offsets into text), at most recs_cap records;
+ * result_out: uint32[8] = n_lines, n_records, n_kept, n_short, tail_start, overflow, -, -.  Returns the kept records. */
+int64_t qd_dev_fastq_scan(int device_id, const uint8_t* text, int64_t text_len, int32_t at_eof, int32_t want_names, int32_t need,
+                          int64_t line_cap, uint32_t* recs_out, int64_t recs_cap, uint32_t* result_out);
+/* CRC-32 (gzip's) of n bytes, made on the device from ranges of range_bytes (<= 65536) whose CRCs are combined */
+int qd_dev_crc32(int device_id, const uint8_t* data, int64_t n, int64_t range_bytes, uint32_t* crc_out);
+/* the stable sort by destination of the scatter stage: perm_out[k] = the pair at sorted position k; with len / offsets_out
+ * (n + 1 values) also the exclusive sums of len in sorted order, i.e. where every pair's output record starts */
+int qd_dev_sort_by_dest(int device_id, const uint16_t* dest, int64_t n, int32_t n_dest, const uint32_t* len, uint32_t* perm_out,
+                        uint32_t* offsets_out);
+/* what a context was made with / holds (the pipeline reads them; bindings may too) */
+int qd_get_plan(const qd_ctx* ctx, qd_plan* out);
+int qd_context_device(const qd_ctx* ctx, int32_t* device_id);
 
 #ifdef __cplusplus
 }

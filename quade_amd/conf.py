@@ -115,6 +115,10 @@ class QuadeConf(object):
         self.io_threads = opt("io_threads", 0)
         self.device_inflate = opt("device_inflate", "True", str).strip().lower() in ("true", "1", "yes", "on")
         self.device_deflate = opt("device_deflate", "True", str).strip().lower() in ("true", "1", "yes", "on")
+        # the whole chunk loop on the device (qd_pipe_*): text stays in HBM from the inflater to the coder.  Needs the device's
+        # inflate and deflate stages and a gzip level the device codes (1, -1); batch_pairs then defaults to 2 000 000
+        self.device_pipeline = opt("device_pipeline", "True", str).strip().lower() in ("true", "1", "yes", "on")
+        self.batch_pairs_given = cp.has_section("gpu") and cp.has_option("gpu", "batch_pairs")
 
         self._test_values()
 

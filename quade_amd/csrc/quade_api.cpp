@@ -602,6 +602,19 @@ int qd_get_layout(const qd_ctx* c, qd_layout* out) {
     return QD_OK;
 }
 
+int qd_get_plan(const qd_ctx* c, qd_plan* out) {
+    if (!c || !out) return QD_ERR_INVALID;
+    if (!c->have_plan) return fail(c, QD_ERR_STATE, "no plan set");
+    *out = c->plan;
+    return QD_OK;
+}
+
+int qd_context_device(const qd_ctx* c, int32_t* device_id) {
+    if (!c || !device_id) return QD_ERR_INVALID;
+    *device_id = c->device;
+    return QD_OK;
+}
+
 int qd_set_barcodes(qd_ctx* c, int32_t S, const uint8_t* barcodes, const int32_t* offsets) {
     if (!c || S < 0 || S > QD_MAX_SAMPLES || (S > 0 && (!barcodes || !offsets)))
         return fail(c, QD_ERR_INVALID, "bad barcode arguments (0 <= n_samples <= 32767)");

@@ -498,7 +498,7 @@ void sink_error(qd_sink* s, const std::string& msg) {
     if (s->err.empty()) s->err = msg;
 }
 
-bool append_file(const std::string& path, const Bytes& data, std::string& why) {
+bool append_file(const std::string& path, const uint8_t* data, size_t size, std::string& why) {
     StageTimer timer(ST_APPEND);
     const int fd = open(path.c_str(), O_WRONLY | O_APPEND | O_CREAT | O_CLOEXEC, 0644);
     if (fd < 0) {
@@ -506,8 +506,8 @@ bool append_file(const std::string& path, const Bytes& data, std::string& why) {
         return false;
     }
     size_t off = 0;
-    while (off < data.size()) {
-        const ssize_t w = write(fd, data.data() + off, data.size() - off);
+    while (off < size) {
+        const ssize_t w = write(fd, data + off, size - off);
         if (w < 0) {
             if (errno == EINTR) continue;
             why = path + ": " + strerror(errno);
@@ -522,6 +522,7 @@ bool append_file(const std::string& path, const Bytes& data, std::string& why) {
     }
     return true;
 }
+bool append_file(const std::string& path, const Bytes& data, std::string& why) { return append_file(path, data.data(), data.size(), why); }
 
 // a finished member takes its place in the file's queue; everything that is next in line is written
 void deliver(qd_sink* s, OutFile* f, uint64_t seq, Bytes&& member) {
@@ -891,6 +892,31 @@ int qd_sink_set_quiet(qd_sink* s, int32_t quiet) {
     return QD_OK;
 }
 
+// The two files of routing code `code`: made (truncated, announced) at the destination's first routed pair
+// (src/FastqWriter.py:55-57, 76-81).  nullptr: a file could not be created (the sink's error is set).
+static Dest* sink_dest(qd_sink* s, uint32_t code) {
+    auto it = s->dest.find(code);
+    if (it != s->dest.end()) return it->second.get();
+    const bool undet = code == QD_CODE_UNDETERMINED;
+    std::unique_ptr<Dest> d(new Dest());
+    const std::string base = s->outdir + "/" + (undet ? std::string("Undetermined") : s->names[code >> 1] + ((code & 1) ? "_fail" : "_pass"));
+    d->f[0].path = base + "_R1.fastq.gz";
+    d->f[1].path = base + "_R2.fastq.gz";
+    for (int k = 0; k < 2; ++k) {
+        if (!s->quiet) {
+            printf("\tCreate %s file\n", d->f[k].path.c_str());
+        }
+        const int fd = open(d->f[k].path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+        if (fd < 0) {
+            sink_error(s, d->f[k].path + ": " + strerror(errno));
+            return nullptr;
+        }
+        close(fd);
+    }
+    if (!s->quiet) fflush(stdout);
+    return s->dest.emplace(code, std::move(d)).first->second.get();
+}
+
 // what a batch's jobs need until the last of them has formatted its piece
 struct RouteRes {
     std::vector<int64_t> order;
@@ -954,26 +980,8 @@ static int route_impl(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_
         const bool undet = b == 2 * S;
         if (undet ? !s->write_undet : ((b & 1) ? !s->write_fail : !s->write_pass)) continue;  // counters moved on the device
         const uint32_t code = undet ? QD_CODE_UNDETERMINED : b;
-        auto it = s->dest.find(code);
-        if (it == s->dest.end()) {  // first routed pair of this destination: create (truncate) its two files
-            std::unique_ptr<Dest> d(new Dest());
-            const std::string base = s->outdir + "/" + (undet ? std::string("Undetermined") : s->names[b >> 1] + ((b & 1) ? "_fail" : "_pass"));
-            d->f[0].path = base + "_R1.fastq.gz";
-            d->f[1].path = base + "_R2.fastq.gz";
-            for (int k = 0; k < 2; ++k) {
-                if (!s->quiet) {
-                    printf("\tCreate %s file\n", d->f[k].path.c_str());
-                }
-                const int fd = open(d->f[k].path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
-                if (fd < 0) {
-                    sink_error(s, d->f[k].path + ": " + strerror(errno));
-                    return QD_ERR_FORMAT;
-                }
-                close(fd);
-            }
-            if (!s->quiet) fflush(stdout);
-            it = s->dest.emplace(code, std::move(d)).first;
-        }
+        Dest* dest_of_code = sink_dest(s, code);
+        if (!dest_of_code) return QD_ERR_FORMAT;
         for (int k = 0; k < 2; ++k) {
             const int64_t* off = k ? r2_off : r1_off;
             int64_t a = lo;
@@ -984,7 +992,7 @@ static int route_impl(qd_sink* s, int64_t n, const uint16_t* codes, const uint8_
                     bytes += off[r + 1] - off[r] + tag_len[r];
                     ++e;
                 }
-                OutFile* f = &it->second->f[k];
+                OutFile* f = &dest_of_code->f[k];
                 pieces.push_back(Piece{f, f->next_submit++, k ? r2_text : r1_text, off, order.data() + a, e - a, bytes});
                 a = e;
             }
@@ -1218,6 +1226,11 @@ struct qd_reader {
     std::string path, err;
     int fd = -1;
     bool gz = false;
+    // raw mode (qdio::raw_open): no record scanner; the consumer takes the inflater's text pieces itself
+    bool raw = false;
+    int64_t start_offset = 0;  // raw mode: the file is read from here on
+    int raw_slot = 0;          // next hand-over slot the consumer looks at
+    bool raw_holding = false;  // the consumer still holds the previous slot
     int64_t B = 0;
     size_t depth = 2;
     std::thread th, th_inflate;
@@ -1791,7 +1804,7 @@ void inflate_thread(qd_reader* r) {
                 return;
             }
         }
-        if (in.pos == 0 && g_pgz_enabled.load() && inflate_parallel(r, cur, ok)) {
+        if (in.pos == 0 && r->start_offset == 0 && g_pgz_enabled.load() && inflate_parallel(r, cur, ok)) {
             std::lock_guard<std::mutex> g(r->hm);
             r->inflated = true;
             r->hcv.notify_all();
@@ -2090,6 +2103,140 @@ int qd_reader_inflate_stats(const qd_reader* r, int64_t* device_runs, int64_t* h
 }
 
 }  // extern "C"
+
+// ---- seams for the device chunk pipeline (quade_io_internal.h) -----------------------------------------------------
+#include "quade_io_internal.h"
+namespace qdio {
+
+qd_reader* raw_open(const char* path, int64_t start_offset, std::string* err) {
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0 || (start_offset > 0 && lseek(fd, (off_t)start_offset, SEEK_SET) < 0)) {
+        if (err) *err = std::string(path) + ": " + strerror(errno);
+        if (fd >= 0) close(fd);
+        return nullptr;
+    }
+    qd_reader* r = new qd_reader();
+    r->path = path;
+    r->fd = fd;
+    const size_t n = strlen(path);
+    r->gz = n >= 3 && (path[n - 3] == '.') && (path[n - 2] == 'g' || path[n - 2] == 'G') && (path[n - 1] == 'z' || path[n - 1] == 'Z');
+    r->raw = true;
+    r->start_offset = start_offset;
+    r->B = 1;
+    r->th_inflate = std::thread(inflate_thread, r);
+    return r;
+}
+
+int raw_next(qd_reader* r, const uint8_t** ptr, size_t* len, std::string* err) {
+    std::unique_lock<std::mutex> g(r->hm);
+    if (r->raw_holding) {  // the piece handed out by the previous call goes back to the inflater
+        r->hstate[r->raw_slot] = 0;
+        r->held[r->raw_slot].reset();
+        r->raw_slot ^= 1;
+        r->raw_holding = false;
+        r->hcv.notify_all();
+    }
+    const int j = r->raw_slot;
+    r->hcv.wait(g, [r, j] { return r->stop || r->hstate[j] == 1 || r->inflated; });
+    if (r->hstate[j] == 1) {
+        *ptr = r->hptr[j];
+        *len = r->hlen[j];
+        r->raw_holding = true;
+        return 1;
+    }
+    g.unlock();
+    std::lock_guard<std::mutex> e(r->m);
+    if (!r->err.empty()) {
+        if (err) *err = r->err;
+        return -1;
+    }
+    return 0;
+}
+
+void raw_close(qd_reader* r) { qd_reader_close(r); }
+
+size_t bgzf_block_size(const uint8_t* p, size_t avail) { return ::bgzf_block_size(p, avail); }
+
+bool host_inflate_members(const uint8_t* comp, size_t comp_len, uint8_t* out, size_t out_len) {
+    LibDeflate& L = deflate_lib();
+    size_t ip = 0, op = 0;
+    if (L.ok) {
+        void* dec = L.alloc_decompressor();
+        bool good = dec != nullptr;
+        while (good && ip < comp_len) {
+            size_t ain = 0, aout = 0;
+            good = L.gzip_decompress_ex(dec, comp + ip, comp_len - ip, out + op, out_len - op, &ain, &aout) == 0 && ain > 0;
+            ip += ain;
+            op += aout;
+        }
+        if (dec) L.free_decompressor(dec);
+        return good && op == out_len;
+    }
+    while (ip < comp_len) {  // zlib, member by member
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, 15 + 16) != Z_OK) return false;
+        zs.next_in = const_cast<Bytef*>(comp + ip);
+        zs.avail_in = (uInt)std::min<size_t>(comp_len - ip, 1u << 30);
+        zs.next_out = out + op;
+        zs.avail_out = (uInt)std::min<size_t>(out_len - op, 1u << 30);
+        const uInt in0 = zs.avail_in, out0 = zs.avail_out;
+        const int zr = inflate(&zs, Z_FINISH);
+        ip += in0 - zs.avail_in;
+        op += out0 - zs.avail_out;
+        inflateEnd(&zs);
+        if (zr != Z_STREAM_END) return false;
+    }
+    return op == out_len;
+}
+
+bool host_gzip_member(const uint8_t* text, size_t n, int level, std::vector<uint8_t>* out) {
+    Bytes m;
+    if (!gzip_member(text, n, level, m)) return false;
+    out->assign(m.data(), m.data() + m.size());
+    return true;
+}
+
+uint32_t crc32(const uint8_t* p, size_t n) { return qd_io_crc32(p, n); }
+
+SinkInfo sink_info(const qd_sink* s) {
+    SinkInfo i;
+    i.level = s->level;
+    i.write_pass = s->write_pass;
+    i.write_fail = s->write_fail;
+    i.write_undet = s->write_undet;
+    i.n_samples = (uint32_t)s->names.size();
+    return i;
+}
+
+void* sink_file(qd_sink* s, uint32_t code, int k) {
+    Dest* d = sink_dest(s, code);
+    return d ? &d->f[k] : nullptr;
+}
+
+bool sink_append(qd_sink* s, void* file, const uint8_t* data, size_t n) {
+    OutFile* f = static_cast<OutFile*>(file);
+    std::string why;
+    std::lock_guard<std::mutex> g(f->m);
+    if (append_file(f->path, data, n, why)) return true;
+    sink_error(s, why);
+    return false;
+}
+
+void sink_account(qd_sink* s, int64_t members, int64_t device_members, int64_t text_bytes, int64_t gzip_bytes) {
+    std::lock_guard<std::mutex> g(s->m);
+    s->members += members;
+    s->device_members += device_members;
+    s->bytes_in += text_bytes;
+    s->bytes_out += gzip_bytes;
+}
+
+void sink_fail(qd_sink* s, const std::string& msg) { sink_error(s, msg); }
+
+void pool_submit(std::function<void()> fn) { pool().submit(std::move(fn)); }
+int pool_size() { return pool().size(); }
+
+}  // namespace qdio
 
 // ---- whole-buffer gzip writer (tooling: synthetic inputs; any binding that holds text in memory) ------------
 namespace {

@@ -1,0 +1,1345 @@
+// Device-resident chunk pipeline of libquade_hip.so (include/quade_hip.h, qd_pipe_*).
+//
+// Replaces the reference's per-pair loop body and everything it calls -- src/Quade.py:203-221 (four FastqReader.next(),
+// slice + fuse, Sample.FINDER) and src/FastqWriter.py:61-90 (name tag, record format, gzip append) -- for whole chunks, with
+// the fastq TEXT staying in HBM from the inflater to the coder:
+//
+//   files --read()--> pinned --H2D--> [BGZF blocks]  inflate_bgzf_blocks2 + CRC-32 check          (quade_inflate.hip, quade_text.hip)
+//                                     [other input]  text as the host's readers inflate it --H2D-->
+//     -> window of text per stream -> line / record scan (skip-malformed inside the stream)
+//     -> lock step: pair j = kept record j of every stream, the chunk ends with its first exhausted stream (Quade.py:210-224)
+//     -> index rows -> demux_fast (codes, counters)                                                (quade_kernels.hip)
+//     -> stable sort by destination -> output offsets -> format "@name:IDX[:MOL]\nseq\n+\nqual\n"  (quade_text.hip)
+//     -> CRC-32 -> lz_subblocks / huff_pieces -> members packed                                    (quade_deflate.hip)
+//     --D2H--> pinned --write()--> <dest>_R1/_R2.fastq.gz, in input order
+//
+// Only compressed bytes cross PCIe (text does for inputs the device cannot inflate: ordinary gzip members, plain files).
+// Threads: one feeder per input stream (file -> pinned -> device ring, running ahead into the next chunks), the driver (the
+// caller's thread: launches, three small read-backs per batch), a collector (members -> files on the library's pool).
+// One compute stream: the device runs the stages of consecutive batches back to back; uploads and downloads have their own.
+#include <hip/hip_runtime.h>
+
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/quade_hip.h"
+#include "quade_deflate.h"
+#include "quade_inflate.h"
+#include "quade_io_internal.h"
+#include "quade_text.h"
+
+namespace {
+
+constexpr size_t SEG_BYTES = 16u << 20;  // bytes per upload (compressed blocks or text)
+constexpr int RING_SLOTS = 24;           // device ring per stream: how far a feeder runs ahead of the kernels
+constexpr int PIN_SLOTS = 3;             // page-locked upload buffers per stream
+constexpr uint32_t PIECE_BYTES = 1u << 20;       // text per gzip member
+constexpr size_t WINDOW_MAX = (size_t)1 << 30;   // text per stream and batch (offsets are 32 bit)
+constexpr uint32_t LAUNCH_BLOCKS = 8192;         // BGZF blocks per inflate launch at most (sizes the match scratch)
+constexpr size_t GROUP_SEGMENTS = 8;             // uploads gathered per inflate launch
+
+hipError_t wait_event_napping(hipEvent_t ev) {  // hipEventSynchronize spins on this runtime: poll, then nap
+    for (int i = 0; i < 64; ++i) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+    }
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        usleep(50);
+    }
+}
+
+struct DevBuf {  // grow-only device allocation
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    // keep: the first `keep` bytes survive the growth (copied on `st`, which is then drained)
+    hipError_t need(size_t n, size_t keep = 0, hipStream_t st = nullptr) {
+        if (n <= cap) return hipSuccess;
+        const size_t want = n + n / 4 + (1u << 16);
+        uint8_t* q = nullptr;
+        hipError_t e = hipMalloc((void**)&q, want);
+        if (e != hipSuccess) return e;
+        if (p && keep) {
+            e = hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return e;
+        } else if (p) {
+            (void)hipStreamSynchronize(st);  // nothing queued may still use the old allocation
+        }
+        if (p) (void)hipFree(p);
+        p = q;
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct PinBuf {  // grow-only page-locked host allocation
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    hipError_t need(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = n + n / 4 + 4096;
+        const hipError_t e = hipHostMalloc((void**)&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// Small tables on their way to the device: page-locked chunks that are reused once the copy that read them has run.
+class StagePool {
+  public:
+    ~StagePool() {
+        for (Chunk& c : chunks_) {
+            if (c.ev) (void)hipEventDestroy(c.ev);
+            if (c.p) (void)hipHostFree(c.p);
+        }
+    }
+    // copies n bytes of src to dst (device) on st through a page-locked chunk
+    hipError_t upload(void* dst, const void* src, size_t n, hipStream_t st) {
+        if (!n) return hipSuccess;
+        Chunk* c = nullptr;
+        for (Chunk& k : chunks_)
+            if (k.cap >= n && (!k.used || hipEventQuery(k.ev) == hipSuccess)) {
+                c = &k;
+                break;
+            }
+        if (!c) {
+            Chunk k;
+            k.cap = std::max<size_t>(n + n / 2, 256u << 10);
+            hipError_t e = hipHostMalloc((void**)&k.p, k.cap, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            e = hipEventCreateWithFlags(&k.ev, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+            chunks_.push_back(k);
+            c = &chunks_.back();
+        }
+        memcpy(c->p, src, n);
+        hipError_t e = hipMemcpyAsync(dst, c->p, n, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+        c->used = true;
+        return hipEventRecord(c->ev, st);
+    }
+
+  private:
+    struct Chunk {
+        uint8_t* p = nullptr;
+        size_t cap = 0;
+        hipEvent_t ev = nullptr;
+        bool used = false;
+    };
+    std::deque<Chunk> chunks_;
+};
+
+// ---- feeders: file -> page-locked buffer -> device ring ----------------------------------------------------------------------
+enum { SEG_BGZF, SEG_TEXT, SEG_END, SEG_ERROR };
+struct Segment {
+    int kind = SEG_END;
+    int chunk = 0;
+    int slot = -1;          // ring slot that holds `bytes` bytes
+    size_t bytes = 0;
+    size_t text_bytes = 0;  // BGZF: what the blocks inflate to
+    std::vector<qd_inflate_block> blocks;  // in_off inside the slot, out_off inside the segment's text
+    std::vector<uint32_t> crcs;
+    uint32_t longest = 0;
+    int64_t file_off = 0;   // BGZF: where the blocks start in the file (a run the device refuses is read again by the host)
+    std::string err;
+};
+
+class Feeder {
+  public:
+    Feeder(int device, std::vector<std::string> paths) : device_(device), paths_(std::move(paths)) {}
+    ~Feeder() { stop(); }
+    hipError_t start() {
+        hipError_t e = hipSetDevice(device_);
+        if (e != hipSuccess) return e;
+        if ((e = hipStreamCreateWithFlags(&up_, hipStreamNonBlocking)) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&ring_, (size_t)RING_SLOTS * SEG_BYTES)) != hipSuccess) return e;
+        for (int i = 0; i < RING_SLOTS; ++i) {
+            if ((e = hipEventCreateWithFlags(&ready_[i], hipEventDisableTiming)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&consumed_[i], hipEventDisableTiming)) != hipSuccess) return e;
+        }
+        th_ = std::thread([this] { run(); });
+        return hipSuccess;
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+        if (up_) {
+            (void)hipStreamSynchronize(up_);
+            (void)hipStreamDestroy(up_);
+            up_ = nullptr;
+        }
+        for (int i = 0; i < RING_SLOTS; ++i) {
+            if (ready_[i]) (void)hipEventDestroy(ready_[i]);
+            if (consumed_[i]) (void)hipEventDestroy(consumed_[i]);
+            ready_[i] = consumed_[i] = nullptr;
+        }
+        for (int i = 0; i < PIN_SLOTS; ++i) {
+            if (pin_[i]) (void)hipHostFree(pin_[i]);
+            pin_[i] = nullptr;
+        }
+        if (ring_) (void)hipFree(ring_);
+        ring_ = nullptr;
+    }
+    // the next segment of the stream (blocks); SEG_END closes a chunk
+    Segment pop() {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [this] { return !q_.empty(); });
+        Segment s = std::move(q_.front());
+        q_.pop_front();
+        return s;
+    }
+    const uint8_t* ring() const { return ring_; }
+    hipEvent_t ready(int slot) const { return ready_[slot]; }
+    // the driver has queued the last reader of `slot` on st
+    hipError_t consumed(int slot, hipStream_t st) {
+        const hipError_t e = hipEventRecord(consumed_[slot], st);
+        {
+            std::lock_guard<std::mutex> g(m_);
+            state_[slot] = e == hipSuccess ? 2 : 0;
+        }
+        cv_.notify_all();
+        return e;
+    }
+    // chunks below `c` need no more input (the chunk ended with another stream)
+    void skip_below(int c) {
+        skip_.store(c);
+        cv_.notify_all();
+    }
+
+  private:
+    void push(Segment&& s) {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            q_.push_back(std::move(s));
+        }
+        cv_.notify_all();
+    }
+    void fail(int chunk, const std::string& msg) {
+        Segment s;
+        s.kind = SEG_ERROR;
+        s.chunk = chunk;
+        s.err = msg;
+        push(std::move(s));
+    }
+    bool stopping() {
+        std::lock_guard<std::mutex> g(m_);
+        return stop_;
+    }
+    // a page-locked buffer whose last upload has run; nullptr when stopping or out of memory
+    uint8_t* take_pin() {
+        const int j = pin_next_;
+        pin_next_ = (pin_next_ + 1) % PIN_SLOTS;
+        if (!pin_[j] && hipHostMalloc((void**)&pin_[j], SEG_BYTES + 65536, hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (pin_slot_[j] >= 0 && wait_event_napping(ready_[pin_slot_[j]]) != hipSuccess) return nullptr;
+        pin_slot_[j] = -1;
+        pin_cur_ = j;
+        return pin_[j];
+    }
+    // a free ring slot (-1: stopping)
+    int take_slot() {
+        const int s = slot_next_;
+        slot_next_ = (slot_next_ + 1) % RING_SLOTS;
+        {
+            std::unique_lock<std::mutex> g(m_);
+            cv_.wait(g, [&] { return stop_ || state_[s] != 1; });
+            if (stop_) return -1;
+        }
+        if (state_[s] == 2 && wait_event_napping(consumed_[s]) != hipSuccess) return -1;
+        return s;
+    }
+    // pin[0 .. n) -> a ring slot; the segment goes to the driver
+    bool upload(Segment& seg, const uint8_t* pin, size_t n) {
+        const int s = take_slot();
+        if (s < 0) return false;
+        if (hipMemcpyAsync(ring_ + (size_t)s * SEG_BYTES, pin, n, hipMemcpyHostToDevice, up_) != hipSuccess ||
+            hipEventRecord(ready_[s], up_) != hipSuccess)
+            return false;
+        pin_slot_[pin_cur_] = s;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            state_[s] = 1;
+        }
+        seg.slot = s;
+        seg.bytes = n;
+        push(std::move(seg));
+        return true;
+    }
+    static bool ends_gz(const std::string& p) {
+        const size_t n = p.size();
+        return n >= 3 && p[n - 3] == '.' && (p[n - 2] == 'g' || p[n - 2] == 'G') && (p[n - 1] == 'z' || p[n - 1] == 'Z');
+    }
+
+    void run() {
+        (void)hipSetDevice(device_);
+        for (int c = 0; c < (int)paths_.size(); ++c) {
+            if (stopping()) return;
+            if (skip_.load() <= c) one_file(c);
+            Segment end;
+            end.kind = SEG_END;
+            end.chunk = c;
+            push(std::move(end));
+        }
+    }
+
+    // text of the file from `offset` on, as the host's readers inflate it
+    void text_from(int c, const std::string& path, int64_t offset) {
+        std::string err;
+        qd_reader* r = qdio::raw_open(path.c_str(), offset, &err);
+        if (!r) return fail(c, err);
+        for (;;) {
+            const uint8_t* p = nullptr;
+            size_t len = 0;
+            const int rc = qdio::raw_next(r, &p, &len, &err);
+            if (rc < 0) fail(c, err);
+            if (rc <= 0) break;
+            bool ok = true;
+            for (size_t at = 0; ok && at < len; at += SEG_BYTES) {
+                if (skip_.load() > c || stopping()) {
+                    ok = false;
+                    break;
+                }
+                const size_t n = std::min(SEG_BYTES, len - at);
+                uint8_t* pin = take_pin();
+                if (!pin) {
+                    fail(c, "page-locked memory: allocation or upload failed");
+                    ok = false;
+                    break;
+                }
+                memcpy(pin, p + at, n);
+                Segment seg;
+                seg.kind = SEG_TEXT;
+                seg.chunk = c;
+                ok = upload(seg, pin, n);
+            }
+            if (!ok) break;
+        }
+        qdio::raw_close(r);
+    }
+
+    void one_file(int c) {
+        const std::string& path = paths_[c];
+        if (!ends_gz(path)) return text_from(c, path, 0);
+        const int fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
+        if (fd < 0) return fail(c, path + ": " + strerror(errno));
+        std::vector<uint8_t> tail;  // the partial block behind the last whole one of the previous buffer
+        int64_t file_pos = 0;       // file offset of the buffer's first byte
+        bool eof = false, first = true;
+        int64_t switch_at = -1;     // >= 0: not (or no longer) BGZF from this file offset on
+        while (!eof && switch_at < 0) {
+            if (skip_.load() > c || stopping()) break;
+            uint8_t* pin = take_pin();
+            if (!pin) {
+                fail(c, "page-locked memory: allocation or upload failed");
+                break;
+            }
+            size_t fill = tail.size();
+            if (fill) memcpy(pin, tail.data(), fill);
+            tail.clear();
+            while (fill < SEG_BYTES && !eof) {
+                const ssize_t g = read(fd, pin + fill, SEG_BYTES - fill);
+                if (g < 0) {
+                    if (errno == EINTR) continue;
+                    fail(c, path + ": " + strerror(errno));
+                    close(fd);
+                    return;
+                }
+                if (g == 0) eof = true;
+                fill += (size_t)g;
+            }
+            if (first && !qdio::bgzf_block_size(pin, fill)) {  // ordinary gzip: the host's parallel inflater takes the file
+                switch_at = 0;
+                break;
+            }
+            first = false;
+            Segment seg;
+            seg.kind = SEG_BGZF;
+            seg.chunk = c;
+            seg.file_off = file_pos;
+            size_t pos = 0;
+            while (pos < fill) {
+                const uint8_t* b = pin + pos;
+                const size_t avail = fill - pos;
+                const size_t bs = qdio::bgzf_block_size(b, avail);
+                if (!bs) {
+                    if (avail >= 18 || eof) switch_at = file_pos + (int64_t)pos;  // (fewer bytes than a header: the next read completes it)
+                    break;
+                }
+                if (bs > avail) {
+                    if (eof) switch_at = file_pos + (int64_t)pos;  // a truncated block: the member loop reports it
+                    break;
+                }
+                const size_t xlen = b[10] | ((size_t)b[11] << 8);
+                const uint32_t isize = (uint32_t)b[bs - 4] | ((uint32_t)b[bs - 3] << 8) | ((uint32_t)b[bs - 2] << 16) | ((uint32_t)b[bs - 1] << 24);
+                if (bs < 12 + xlen + 8 || (b[3] & ~4) || isize > 65536) {  // not bgzip's layout
+                    switch_at = file_pos + (int64_t)pos;
+                    break;
+                }
+                const uint32_t crc = (uint32_t)b[bs - 8] | ((uint32_t)b[bs - 7] << 8) | ((uint32_t)b[bs - 6] << 16) | ((uint32_t)b[bs - 5] << 24);
+                const uint32_t in_len = (uint32_t)(bs - 12 - xlen - 8);
+                seg.blocks.push_back(qd_inflate_block{(uint32_t)(pos + 12 + xlen), in_len, (uint32_t)seg.text_bytes, isize});
+                seg.crcs.push_back(crc);
+                seg.longest = std::max(seg.longest, in_len);
+                seg.text_bytes += isize;
+                pos += bs;
+            }
+            if (switch_at < 0 && pos < fill) tail.assign(pin + pos, pin + fill);
+            file_pos += (int64_t)pos;
+            if (!seg.blocks.empty() && !upload(seg, pin, pos)) break;
+        }
+        close(fd);
+        if (switch_at >= 0 && skip_.load() <= c && !stopping()) text_from(c, path, switch_at);
+    }
+
+    int device_;
+    std::vector<std::string> paths_;
+    hipStream_t up_ = nullptr;
+    uint8_t* ring_ = nullptr;
+    hipEvent_t ready_[RING_SLOTS] = {nullptr}, consumed_[RING_SLOTS] = {nullptr};
+    int state_[RING_SLOTS] = {0};  // 0 free, 1 with the driver, 2 its last reader is queued (consumed_ tells when it has run)
+    uint8_t* pin_[PIN_SLOTS] = {nullptr};
+    int pin_slot_[PIN_SLOTS] = {-1, -1, -1};  // the ring slot whose upload read this buffer last
+    int pin_next_ = 0, pin_cur_ = 0, slot_next_ = 0;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Segment> q_;
+    std::atomic<int> skip_{0};
+    bool stop_ = false;
+    std::thread th_;
+};
+
+// ---- what a batch hands to the collector -------------------------------------------------------------------------------------
+struct FileRun {  // the members of one output file made by one batch: pieces [first, first + n)
+    uint32_t code;
+    int k;
+    uint32_t first, n;
+    uint64_t text_bytes;
+};
+struct BatchOut {
+    int set = -1;  // resource set; -1: no members, just a message
+    qd_sink* sink = nullptr;
+    uint32_t n_pieces = 0;
+    std::vector<FileRun> files;
+    std::vector<qd_deflate_piece> pieces;  // host copy (text_off / text_len: the host codes a piece the device gave up)
+    int level = 1;
+    hipEvent_t done = nullptr;  // recorded on the compute stream behind the batch's last kernel
+    std::string message;        // printed when the batch (and everything before it) is in its files
+    bool last = false;
+};
+
+struct OutSet {  // per-batch output resources, two of them: the collector drains one while the device fills the other
+    DevBuf text, pieces, members, member_len, member_off, packed;
+    PinBuf h_packed, h_len;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+};
+
+}  // namespace
+
+struct qd_pipe_stats_impl {
+    int64_t pairs = 0, batches = 0, bgzf_blocks = 0, host_inflated_runs = 0, text_segments = 0, pieces = 0, host_coded_pieces = 0;
+    int64_t text_in_bytes = 0, text_out_bytes = 0, gzip_bytes = 0, rescans = 0;
+};
+
+struct qd_pipe {
+    qd_ctx* ctx = nullptr;
+    int device = 0;
+    std::string err;
+    int64_t batch_pairs = 2000000;
+    int64_t test_fail_inflate_batch = -1;  // option: the device "refuses" the BGZF blocks of this batch (the host inflates them)
+    qd_plan plan{};
+    qd_layout lay{};
+    hipStream_t cs = nullptr, ds = nullptr;
+    hipEvent_t sync_ev = nullptr;
+    StagePool stage;
+    qd_pipe_stats_impl st;
+
+    struct Window {
+        DevBuf buf[2];
+        int cur = 0;
+        uint32_t len = 0;       // bytes of text in buf[cur]
+        bool eof = false;       // the feeder has delivered the stream's last byte
+        bool dirty = true;      // text arrived since the last scan
+        double avg = 0;         // bytes per record, learned
+        uint32_t carry_kept = 0;
+        DevBuf tile_counts, tile_base, lines, rec_tile, recs, status, crc, blk, expect;
+        uint32_t line_cap = 0;
+        std::vector<Segment> pending;                                  // BGZF uploads waiting for their inflate launch
+        uint32_t pending_text = 0;
+        std::vector<std::pair<int64_t, std::pair<size_t, std::pair<uint32_t, uint32_t>>>> runs;  // (file offset, (bytes, (window offset, text bytes))) of this batch's BGZF text
+        uint32_t n_blocks = 0;                                         // blocks inflated into this window since the last verification
+        std::string path;
+        qd_scan_result res{};
+    } win[4];
+    int n_streams = 4;  // R1, R2, I1 [, I2]
+    DevBuf d_res;       // qd_scan_result[4] + pack's short counter
+    PinBuf h_res;
+    DevBuf matches;
+    // index rows, codes, routing scratch (sized for batch_pairs)
+    DevBuf rows_seq[2], rows_qual[2], rows_len[2], codes, mol, short_idx, dest, len1, len2, hist, tmp, perm, sdest, g1, g2, scan_tiles, first, g1_first,
+        g2_first;
+    PinBuf h_first;
+    // tables and scratch of the format / CRC / coder launches: read by kernels on the compute stream only, so one set serves every batch
+    DevBuf subs, first_sub, ranges, crc, tokens, sub_out, sub_bytes, base1, base2;
+    OutSet out[2];
+    std::mutex om;
+    std::condition_variable ocv;
+    // collector
+    std::thread collector;
+    std::mutex cm;
+    std::condition_variable ccv;
+    std::deque<BatchOut> cq;
+    bool collector_failed = false;
+    std::string collector_err;
+};
+
+namespace {
+
+thread_local std::string g_pipe_error;
+
+int pfail(qd_pipe* p, int code, const std::string& msg) {
+    if (p) {
+        if (p->err.empty() || code != QD_OK) p->err = msg;
+    } else {
+        g_pipe_error = msg;
+    }
+    return code;
+}
+#define PCHK(p, call)                                                                                              \
+    do {                                                                                                           \
+        hipError_t e_ = (call);                                                                                    \
+        if (e_ != hipSuccess) return pfail((p), QD_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// waits until everything queued on the compute stream so far has run (the driver's read-backs)
+int sync_compute(qd_pipe* p) {
+    PCHK(p, hipEventRecord(p->sync_ev, p->cs));
+    PCHK(p, wait_event_napping(p->sync_ev));
+    return QD_OK;
+}
+
+// ---- collector: members of finished batches -> files ------------------------------------------------------------------------------
+void collector_fail(qd_pipe* p, const std::string& msg) {
+    std::lock_guard<std::mutex> g(p->cm);
+    if (!p->collector_failed) {
+        p->collector_failed = true;
+        p->collector_err = msg;
+    }
+}
+
+void collect_one(qd_pipe* p, BatchOut& b) {
+    if (b.set >= 0 && b.n_pieces) {
+        OutSet& o = p->out[b.set];
+        hipError_t e = wait_event_napping(b.done);
+        uint64_t* off = nullptr;
+        uint32_t* len = nullptr;
+        if (e == hipSuccess) e = o.h_len.need((size_t)(b.n_pieces + 1) * 8 + (size_t)b.n_pieces * 4);
+        if (e == hipSuccess) {
+            off = reinterpret_cast<uint64_t*>(o.h_len.p);
+            len = reinterpret_cast<uint32_t*>(o.h_len.p + (size_t)(b.n_pieces + 1) * 8);
+            e = hipMemcpyAsync(off, o.member_off.p, (size_t)(b.n_pieces + 1) * 8, hipMemcpyDeviceToHost, p->ds);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(len, o.member_len.p, (size_t)b.n_pieces * 4, hipMemcpyDeviceToHost, p->ds);
+        if (e == hipSuccess) e = hipEventRecord(o.done, p->ds);
+        if (e == hipSuccess) e = wait_event_napping(o.done);
+        const uint64_t total = e == hipSuccess ? off[b.n_pieces] : 0;
+        if (e == hipSuccess && total) e = o.h_packed.need(total);
+        if (e == hipSuccess && total) e = hipMemcpyAsync(o.h_packed.p, o.packed.p, total, hipMemcpyDeviceToHost, p->ds);
+        // members the device gave up (they did not fit their slots: text that does not compress): their text comes back instead
+        std::vector<std::vector<uint8_t>> rescue(b.n_pieces);
+        std::vector<uint8_t> text;
+        for (uint32_t i = 0; e == hipSuccess && i < b.n_pieces; ++i) {
+            if (len[i] != 0) continue;
+            text.resize(b.pieces[i].text_len);
+            if (!text.empty()) e = hipMemcpyAsync(text.data(), o.text.p + b.pieces[i].text_off, text.size(), hipMemcpyDeviceToHost, p->ds);
+            if (e == hipSuccess) e = hipStreamSynchronize(p->ds);
+            if (e == hipSuccess && !qdio::host_gzip_member(text.data(), text.size(), b.level, &rescue[i])) {
+                collector_fail(p, "gzip compression failed");
+                break;
+            }
+            ++p->st.host_coded_pieces;
+        }
+        if (e == hipSuccess) e = hipEventRecord(o.done, p->ds);
+        if (e == hipSuccess) e = wait_event_napping(o.done);
+        if (e != hipSuccess) {
+            collector_fail(p, std::string("download of the members: ") + hipGetErrorString(e));
+        } else {
+            // one job per output file: its members in order; files in the order the reference would have created them
+            struct Latch {
+                std::mutex m;
+                std::condition_variable cv;
+                size_t n;
+            } latch;
+            latch.n = b.files.size();
+            for (const FileRun& f : b.files) {
+                void* file = qdio::sink_file(b.sink, f.code, f.k);
+                const uint8_t* packed = o.h_packed.p;
+                qd_sink* sink = b.sink;
+                auto job = [file, f, off, len, packed, sink, &rescue, &latch] {
+                    if (file) {
+                        uint64_t gz = 0;
+                        uint32_t i = f.first;
+                        while (i < f.first + f.n) {  // runs of device members are contiguous in the packed stream
+                            if (len[i] == 0) {
+                                qdio::sink_append(sink, file, rescue[i].data(), rescue[i].size());
+                                gz += rescue[i].size();
+                                ++i;
+                                continue;
+                            }
+                            uint32_t j = i;
+                            while (j < f.first + f.n && len[j] != 0) ++j;
+                            qdio::sink_append(sink, file, packed + off[i], (size_t)(off[j] - off[i]));
+                            gz += off[j] - off[i];
+                            i = j;
+                        }
+                        qdio::sink_account(sink, f.n, f.n, (int64_t)f.text_bytes, (int64_t)gz);
+                    }
+                    std::lock_guard<std::mutex> g(latch.m);
+                    if (--latch.n == 0) latch.cv.notify_all();
+                };
+                qdio::pool_submit(job);
+            }
+            std::unique_lock<std::mutex> g(latch.m);
+            latch.cv.wait(g, [&] { return latch.n == 0; });
+            p->st.gzip_bytes += (int64_t)total;
+        }
+        {
+            std::lock_guard<std::mutex> g(p->om);
+            o.busy = false;
+        }
+        p->ocv.notify_all();
+    }
+    if (!b.message.empty()) {
+        fputs(b.message.c_str(), stdout);
+        fflush(stdout);
+    }
+}
+
+void collector_thread(qd_pipe* p) {
+    (void)hipSetDevice(p->device);
+    for (;;) {
+        BatchOut b;
+        {
+            std::unique_lock<std::mutex> g(p->cm);
+            p->ccv.wait(g, [p] { return !p->cq.empty(); });
+            b = std::move(p->cq.front());
+            p->cq.pop_front();
+        }
+        collect_one(p, b);
+        if (b.done) (void)hipEventDestroy(b.done);
+        if (b.last) {
+            std::lock_guard<std::mutex> g(p->cm);
+            p->ccv.notify_all();
+            return;
+        }
+    }
+}
+
+void to_collector(qd_pipe* p, BatchOut&& b) {
+    {
+        std::lock_guard<std::mutex> g(p->cm);
+        p->cq.push_back(std::move(b));
+    }
+    p->ccv.notify_all();
+}
+
+// ---- driver ------------------------------------------------------------------------------------------------------------------------
+using Window = qd_pipe::Window;
+
+// room for `extra` more bytes of text in the window (the line kernels read whole tiles: padding behind the text)
+int window_room(qd_pipe* p, Window& w, size_t extra) {
+    const size_t need = (size_t)w.len + extra + 2 * QD_TEXT_TILE;
+    if ((size_t)w.len + extra > WINDOW_MAX) return pfail(p, QD_ERR_UNSUPPORTED, w.path + ": more than 1 GiB of text in one batch (lower batch_pairs)");
+    PCHK(p, w.buf[w.cur].need(need, w.len, p->cs));
+    return QD_OK;
+}
+
+// the pending BGZF uploads of a window -> inflate launches (+ CRC-32 check of every block), text appended to the window
+int launch_inflate(qd_pipe* p, Feeder& f, Window& w, int stream_index) {
+    if (w.pending.empty()) return QD_OK;
+    int rc = window_room(p, w, w.pending_text);
+    if (rc != QD_OK) return rc;
+    std::vector<qd_inflate_block> blk;
+    std::vector<uint32_t> expect;
+    uint32_t longest = 0;
+    for (Segment& s : w.pending) {
+        PCHK(p, hipStreamWaitEvent(p->cs, f.ready(s.slot), 0));
+        for (size_t i = 0; i < s.blocks.size(); ++i) {
+            qd_inflate_block b = s.blocks[i];
+            b.in_off += (uint32_t)((size_t)s.slot * SEG_BYTES);
+            b.out_off += w.len;
+            blk.push_back(b);
+            expect.push_back(s.crcs[i]);
+        }
+        longest = std::max(longest, s.longest);
+        w.runs.push_back({s.file_off, {s.bytes, {w.len, (uint32_t)s.text_bytes}}});
+        w.len += (uint32_t)s.text_bytes;
+        p->st.text_in_bytes += (int64_t)s.text_bytes;
+    }
+    const size_t nb = blk.size();
+    PCHK(p, w.blk.need((size_t)(w.n_blocks + nb) * sizeof(qd_inflate_block), 0, p->cs));
+    PCHK(p, w.expect.need((size_t)(w.n_blocks + nb) * 4, 0, p->cs));
+    PCHK(p, w.status.need((size_t)(w.n_blocks + nb) * 4, 0, p->cs));
+    PCHK(p, w.crc.need((size_t)(w.n_blocks + nb) * 4, 0, p->cs));
+    // (tables of this launch group go behind those of the batch's earlier groups: a growth above drains the stream first)
+    qd_inflate_block* d_blk = w.blk.as<qd_inflate_block>() + w.n_blocks;
+    uint32_t* d_expect = w.expect.as<uint32_t>() + w.n_blocks;
+    int32_t* d_status = w.status.as<int32_t>() + w.n_blocks;
+    uint32_t* d_crc = w.crc.as<uint32_t>() + w.n_blocks;
+    PCHK(p, p->stage.upload(d_blk, blk.data(), nb * sizeof(qd_inflate_block), p->cs));
+    PCHK(p, p->stage.upload(d_expect, expect.data(), nb * 4, p->cs));
+    uint32_t* first_bad = &p->d_res.as<qd_scan_result>()[stream_index].first_bad;
+    const bool form2 = qd_inflate2_lds(longest) <= 160 * 1024;
+    for (size_t at = 0; at < nb; at += LAUNCH_BLOCKS) {
+        const uint32_t n = (uint32_t)std::min<size_t>(LAUNCH_BLOCKS, nb - at);
+        if (form2) {
+            PCHK(p, p->matches.need((size_t)std::min<size_t>(nb, LAUNCH_BLOCKS) * QD_INFLATE_MATCHES_PER_BLOCK * 8, 0, p->cs));
+            PCHK(p, qd_launch_inflate2(f.ring(), d_blk + at, n, w.buf[w.cur].p, d_status + at, p->matches.as<unsigned long long>(), QD_INFLATE_MATCHES_PER_BLOCK,
+                                       longest, p->cs));
+        } else {
+            PCHK(p, qd_launch_inflate(f.ring(), d_blk + at, n, w.buf[w.cur].p, d_status + at, p->cs));
+        }
+    }
+    for (Segment& s : w.pending) PCHK(p, f.consumed(s.slot, p->cs));
+    // every block's CRC-32 against its trailer, on the device: one range per block
+    PCHK(p, qd_text_crc32_blocks(w.buf[w.cur].p, d_blk, (uint32_t)nb, d_crc, p->cs));
+    PCHK(p, qd_text_check_blocks(d_status, d_crc, d_expect, (uint32_t)nb, w.n_blocks, first_bad, p->cs));
+    w.n_blocks += (uint32_t)nb;
+    p->st.bgzf_blocks += (int64_t)nb;
+    w.pending.clear();
+    w.pending_text = 0;
+    w.dirty = true;
+    return QD_OK;
+}
+
+// more input for one window until it holds `want` bytes of text or its stream ends
+int top_up(qd_pipe* p, Feeder& f, Window& w, int stream_index, int chunk, size_t want) {
+    while (!w.eof && (size_t)w.len + w.pending_text < want) {
+        Segment s = f.pop();
+        if (s.kind == SEG_ERROR) return pfail(p, QD_ERR_FORMAT, s.err);
+        if (s.kind == SEG_END) {
+            if (s.chunk != chunk) return pfail(p, QD_ERR_STATE, "feeder out of step with the driver");
+            w.eof = true;
+            w.dirty = true;
+            break;
+        }
+        if (s.chunk != chunk) {  // left over from a chunk that ended early
+            PCHK(p, f.consumed(s.slot, p->cs));
+            continue;
+        }
+        if (s.kind == SEG_BGZF) {
+            w.pending_text += (uint32_t)s.text_bytes;
+            w.pending.push_back(std::move(s));
+            if (w.pending.size() >= GROUP_SEGMENTS) {
+                const int rc = launch_inflate(p, f, w, stream_index);
+                if (rc != QD_OK) return rc;
+            }
+        } else {  // text: straight into the window
+            int rc = launch_inflate(p, f, w, stream_index);  // (order: BGZF text that came first lands first)
+            if (rc == QD_OK) rc = window_room(p, w, s.bytes);
+            if (rc != QD_OK) return rc;
+            PCHK(p, hipStreamWaitEvent(p->cs, f.ready(s.slot), 0));
+            PCHK(p, hipMemcpyAsync(w.buf[w.cur].p + w.len, f.ring() + (size_t)s.slot * SEG_BYTES, s.bytes, hipMemcpyDeviceToDevice, p->cs));
+            PCHK(p, f.consumed(s.slot, p->cs));
+            w.len += (uint32_t)s.bytes;
+            w.dirty = true;
+            ++p->st.text_segments;
+            p->st.text_in_bytes += (int64_t)s.bytes;
+        }
+    }
+    return launch_inflate(p, f, w, stream_index);
+}
+
+// drops what is left of `chunk` in a stream (the chunk ended with another stream)
+int drain_chunk(qd_pipe* p, Feeder& f, Window& w, int chunk) {
+    for (Segment& s : w.pending) PCHK(p, f.consumed(s.slot, p->cs));
+    w.pending.clear();
+    w.pending_text = 0;
+    while (!w.eof) {
+        Segment s = f.pop();
+        if (s.kind == SEG_ERROR) continue;  // (of a stream nobody reads any more)
+        if (s.kind == SEG_END) {
+            if (s.chunk == chunk) w.eof = true;
+            continue;
+        }
+        PCHK(p, f.consumed(s.slot, p->cs));
+    }
+    return QD_OK;
+}
+
+int scan_window(qd_pipe* p, Window& w, int stream_index) {
+    const uint32_t n_tiles = w.len / QD_TEXT_TILE + 1;
+    PCHK(p, w.tile_counts.need((size_t)(n_tiles + 2) * 4, 0, p->cs));
+    PCHK(p, w.tile_base.need((size_t)(n_tiles + 2) * 4, 0, p->cs));
+    if (w.line_cap == 0 || (w.avg > 0 && (double)w.len / w.avg * 4.4 + 4096 > (double)w.line_cap)) {
+        // lines expected: 4 per record of the learned size (first scan: one line per 16 bytes); a scan that finds more says so
+        const double guess = w.avg > 0 ? (double)w.len / w.avg * 4.4 : (double)w.len / 16.0;
+        w.line_cap = (uint32_t)std::min<double>(4.0e9, guess * 1.25 + 65536);
+        w.line_cap = (w.line_cap + 3) & ~3u;
+    }
+    {
+        PCHK(p, w.lines.need((size_t)w.line_cap * 4 + 64, 0, p->cs));
+        PCHK(p, w.rec_tile.need(((size_t)w.line_cap / 4 / 1024 + 4) * 4, 0, p->cs));
+        PCHK(p, w.recs.need(((size_t)w.line_cap / 4 + 1) * sizeof(qd_rec), 0, p->cs));
+        qd_scan_scratch sc;
+        sc.tile_counts = w.tile_counts.as<uint32_t>();
+        sc.tile_base = w.tile_base.as<uint32_t>();
+        sc.lines = w.lines.as<uint32_t>();
+        sc.line_cap = w.line_cap;
+        sc.rec_tile = w.rec_tile.as<uint32_t>();
+        sc.recs = w.recs.as<qd_rec>();
+        const bool insert = stream_index < 2;
+        const int k = stream_index - 2;
+        const uint32_t need = insert ? 0u : (uint32_t)(p->lay.seq_off[k] + p->lay.seq_width[k]);
+        PCHK(p, qd_text_scan(w.buf[w.cur].p, w.len, w.eof ? 1 : 0, insert ? 1 : 0, need, sc, p->d_res.as<qd_scan_result>() + stream_index, p->cs));
+        PCHK(p, hipMemcpyAsync(p->h_res.p + (size_t)stream_index * sizeof(qd_scan_result), p->d_res.p + (size_t)stream_index * sizeof(qd_scan_result),
+                               sizeof(qd_scan_result), hipMemcpyDeviceToHost, p->cs));
+    }
+    return QD_OK;
+}
+
+// the host inflates this batch's BGZF text of one window (the device refused a block): same bytes, or the file is damaged
+int host_inflate_window(qd_pipe* p, Window& w) {
+    const int fd = open(w.path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return pfail(p, QD_ERR_FORMAT, w.path + ": " + strerror(errno));
+    std::vector<uint8_t> comp, text;
+    int rc = QD_OK;
+    for (const auto& r : w.runs) {
+        const int64_t file_off = r.first;
+        const size_t bytes = r.second.first;
+        const uint32_t at = r.second.second.first, tlen = r.second.second.second;
+        comp.resize(bytes);
+        size_t got = 0;
+        while (got < bytes) {
+            const ssize_t g = pread(fd, comp.data() + got, bytes - got, (off_t)(file_off + (int64_t)got));
+            if (g <= 0) break;
+            got += (size_t)g;
+        }
+        text.resize(tlen);
+        if (got != bytes || !qdio::host_inflate_members(comp.data(), bytes, text.data(), tlen)) {
+            rc = pfail(p, QD_ERR_FORMAT, w.path + ": damaged BGZF block");
+            break;
+        }
+        if (tlen && hipMemcpy(w.buf[w.cur].p + at, text.data(), tlen, hipMemcpyHostToDevice) != hipSuccess) {
+            rc = pfail(p, QD_ERR_HIP, "hipMemcpy of host-inflated text failed");
+            break;
+        }
+        ++p->st.host_inflated_runs;
+    }
+    close(fd);
+    return rc;
+}
+
+// an output set the collector is done with
+int take_out_set(qd_pipe* p, int b) {
+    OutSet& o = p->out[b];
+    std::unique_lock<std::mutex> g(p->om);
+    p->ocv.wait(g, [&] { return !o.busy; });
+    o.busy = true;
+    return b;
+}
+
+// pairs [0, n) of the four windows: rows -> codes -> sorted by destination -> formatted -> coded; members to the collector
+int process_batch(qd_pipe* p, uint32_t n, qd_sink* sink, int64_t batch_index) {
+    const qd_layout& L = p->lay;
+    const qdio::SinkInfo si = qdio::sink_info(sink);
+    const uint32_t S = si.n_samples, nd = 2 * S + 1;
+    const int ni = L.n_streams;
+    Window* iw[2] = {&p->win[2], &p->win[3]};
+    // 1. index rows
+    for (int k = 0; k < ni; ++k) {
+        PCHK(p, p->rows_seq[k].need((size_t)n * L.seq_stride[k] + 64, 0, p->cs));
+        PCHK(p, p->rows_qual[k].need((size_t)n * L.qual_stride[k] + 64, 0, p->cs));
+        PCHK(p, p->rows_len[k].need((size_t)n + 64, 0, p->cs));
+    }
+    PCHK(p, p->codes.need((size_t)n * 2 + 64, 0, p->cs));
+    if (L.mol_width) PCHK(p, p->mol.need((size_t)n * L.mol_width + 64, 0, p->cs));
+    const uint32_t short_cap = n / 2 + 64;
+    PCHK(p, p->short_idx.need((size_t)short_cap * 4, 0, p->cs));
+    uint32_t* d_nshort = reinterpret_cast<uint32_t*>(p->d_res.p + 4 * sizeof(qd_scan_result));
+    PCHK(p, hipMemsetAsync(d_nshort, 0, 4, p->cs));
+    qd_pack_args pa{};
+    for (int k = 0; k < ni; ++k) {
+        pa.text[k] = iw[k]->buf[iw[k]->cur].p;
+        pa.recs[k] = iw[k]->recs.as<qd_rec>();
+        pa.seq[k] = p->rows_seq[k].p;
+        pa.qual[k] = p->rows_qual[k].p;
+        pa.len[k] = p->rows_len[k].p;
+    }
+    pa.short_idx = p->short_idx.as<uint32_t>();
+    pa.n_short = d_nshort;
+    pa.short_cap = short_cap;
+    PCHK(p, qd_text_pack_rows(L, n, pa, p->cs));
+    // 2. codes (src/Sample.py:56-91); the counters move in the context
+    qd_rows rows{};
+    bool ragged = false;
+    for (int k = 0; k < ni; ++k) {
+        rows.seq[k] = p->rows_seq[k].p;
+        rows.qual[k] = p->rows_qual[k].p;
+        ragged = ragged || iw[k]->res.n_short > 0;  // (short reads somewhere in the window: maybe among these pairs)
+    }
+    uint8_t* d_mol = L.mol_width ? p->mol.p : nullptr;
+    if (ragged) {
+        uint32_t* h_nshort = reinterpret_cast<uint32_t*>(p->h_res.p + 4 * sizeof(qd_scan_result));
+        PCHK(p, hipMemcpyAsync(h_nshort, d_nshort, 4, hipMemcpyDeviceToHost, p->cs));
+        int rc = sync_compute(p);
+        if (rc != QD_OK) return rc;
+        ragged = *h_nshort > 0;
+        if (ragged) {
+            for (int k = 0; k < ni; ++k) rows.len[k] = p->rows_len[k].p;
+            rc = qd_demux_device_ragged(p->ctx, n, &rows, p->codes.as<uint16_t>(), d_mol, *h_nshort, p->short_idx.as<uint32_t>(), p->cs);
+            if (rc != QD_OK) return pfail(p, rc, std::string("demux: ") + qd_last_error(p->ctx));
+        }
+    }
+    if (!ragged) {
+        const int rc = qd_demux_device(p->ctx, n, &rows, p->codes.as<uint16_t>(), d_mol, p->cs);
+        if (rc != QD_OK) return pfail(p, rc, std::string("demux: ") + qd_last_error(p->ctx));
+    }
+    // 3. destinations, output lengths, stable sort by destination, output offsets
+    PCHK(p, p->dest.need((size_t)n * 2 + 64, 0, p->cs));
+    PCHK(p, p->len1.need((size_t)n * 4 + 64, 0, p->cs));
+    PCHK(p, p->len2.need((size_t)n * 4 + 64, 0, p->cs));
+    const size_t H = 256 * (((size_t)n + 1023) / 1024);
+    PCHK(p, p->hist.need((H + H / 4096 + 8) * 4, 0, p->cs));
+    PCHK(p, p->tmp.need((size_t)n * 4 + 64, 0, p->cs));
+    PCHK(p, p->perm.need((size_t)n * 4 + 64, 0, p->cs));
+    PCHK(p, p->sdest.need((size_t)n * 2 + 64, 0, p->cs));
+    PCHK(p, p->g1.need(((size_t)n + 1) * 4 + 64, 0, p->cs));
+    PCHK(p, p->g2.need(((size_t)n + 1) * 4 + 64, 0, p->cs));
+    PCHK(p, p->scan_tiles.need(((size_t)n / 4096 + 4) * 4, 0, p->cs));
+    PCHK(p, p->first.need((size_t)nd * 4, 0, p->cs));
+    PCHK(p, p->g1_first.need((size_t)nd * 4, 0, p->cs));
+    PCHK(p, p->g2_first.need((size_t)nd * 4, 0, p->cs));
+    qd_route_args ra{};
+    ra.codes = p->codes.as<uint16_t>();
+    ra.r1 = p->win[0].recs.as<qd_rec>();
+    ra.r2 = p->win[1].recs.as<qd_rec>();
+    for (int k = 0; k < ni; ++k) ra.idx[k] = iw[k]->recs.as<qd_rec>();
+    ra.dest = p->dest.as<uint16_t>();
+    ra.len1 = p->len1.as<uint32_t>();
+    ra.len2 = p->len2.as<uint32_t>();
+    PCHK(p, qd_text_dest_lens(p->plan, S, si.write_pass, si.write_fail, si.write_undet, n, ra, p->cs));
+    PCHK(p, qd_text_sort_by_dest(ra.dest, n, nd, p->hist.as<uint32_t>(), p->tmp.as<uint32_t>(), p->perm.as<uint32_t>(), p->cs));
+    PCHK(p, qd_text_scan_gathered(ra.len1, p->perm.as<uint32_t>(), n, p->scan_tiles.as<uint32_t>(), p->g1.as<uint32_t>(), ra.dest, p->sdest.as<uint16_t>(), p->cs));
+    PCHK(p, qd_text_scan_gathered(ra.len2, p->perm.as<uint32_t>(), n, p->scan_tiles.as<uint32_t>(), p->g2.as<uint32_t>(), nullptr, nullptr, p->cs));
+    PCHK(p, qd_text_dest_bounds(p->sdest.as<uint16_t>(), p->g1.as<uint32_t>(), p->g2.as<uint32_t>(), n, nd, p->first.as<uint32_t>(), p->g1_first.as<uint32_t>(),
+                                p->g2_first.as<uint32_t>(), p->cs));
+    // what the next batch keeps of every window
+    {
+        const qd_rec* recs[4] = {nullptr, nullptr, nullptr, nullptr};
+        qd_scan_result* res[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int s = 0; s < p->n_streams; ++s) {
+            recs[s] = p->win[s].recs.as<qd_rec>();
+            res[s] = p->d_res.as<qd_scan_result>() + s;
+        }
+        PCHK(p, qd_text_carry_info(recs, res, p->n_streams, n, p->cs));
+    }
+    // 4. read back: per-destination bounds, totals, carry starts
+    PCHK(p, p->h_first.need((size_t)nd * 12 + 16));
+    uint32_t* h_first = reinterpret_cast<uint32_t*>(p->h_first.p);
+    uint32_t* h_g1f = h_first + nd;
+    uint32_t* h_g2f = h_g1f + nd;
+    uint32_t* h_tot = h_g2f + nd;  // G1[n], G2[n]
+    PCHK(p, hipMemcpyAsync(h_first, p->first.p, (size_t)nd * 4, hipMemcpyDeviceToHost, p->cs));
+    PCHK(p, hipMemcpyAsync(h_g1f, p->g1_first.p, (size_t)nd * 4, hipMemcpyDeviceToHost, p->cs));
+    PCHK(p, hipMemcpyAsync(h_g2f, p->g2_first.p, (size_t)nd * 4, hipMemcpyDeviceToHost, p->cs));
+    PCHK(p, hipMemcpyAsync(h_tot, p->g1.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, p->cs));
+    PCHK(p, hipMemcpyAsync(h_tot + 1, p->g2.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, p->cs));
+    PCHK(p, hipMemcpyAsync(p->h_res.p, p->d_res.p, (size_t)p->n_streams * sizeof(qd_scan_result), hipMemcpyDeviceToHost, p->cs));
+    int rc = sync_compute(p);
+    if (rc != QD_OK) return rc;
+    for (int s = 0; s < p->n_streams; ++s) p->win[s].res.carry_start = reinterpret_cast<qd_scan_result*>(p->h_res.p)[s].carry_start;
+    // 5. layout of the output text: every destination's R1 region, then every R2 region, 16-byte aligned; pieces of 1 MiB
+    std::vector<int64_t> base1(nd, 0), base2(nd, 0);
+    BatchOut bo;
+    bo.sink = sink;
+    bo.level = si.level;
+    std::vector<qd_lz_sub> subs;
+    std::vector<uint32_t> first_sub;
+    std::vector<qd_crc_range> ranges;
+    uint64_t at = 0;
+    {
+        // a destination without pairs starts where the next one does
+        std::vector<uint32_t> g1s(nd + 1), g2s(nd + 1);
+        g1s[nd] = h_tot[0];
+        g2s[nd] = h_tot[1];
+        for (int64_t d = (int64_t)nd - 1; d >= 0; --d) {
+            const bool none = h_first[d] == 0xFFFFFFFFu;
+            g1s[d] = none ? g1s[d + 1] : h_g1f[d];
+            g2s[d] = none ? g2s[d + 1] : h_g2f[d];
+        }
+        for (int k = 0; k < 2; ++k)
+            for (uint32_t d = 0; d < nd; ++d) {
+                const std::vector<uint32_t>& gs = k ? g2s : g1s;
+                const uint64_t bytes = gs[d + 1] - gs[d];
+                (k ? base2 : base1)[d] = (int64_t)at - (int64_t)gs[d];
+                if (!bytes) continue;
+                FileRun fr;
+                fr.code = d == 2 * S ? QD_CODE_UNDETERMINED : d;
+                fr.k = k;
+                fr.first = (uint32_t)bo.pieces.size();
+                fr.text_bytes = bytes;
+                for (uint64_t a = 0; a < bytes; a += PIECE_BYTES) {
+                    const uint32_t plen = (uint32_t)std::min<uint64_t>(PIECE_BYTES, bytes - a);
+                    first_sub.push_back((uint32_t)subs.size());
+                    for (uint32_t q = 0; q < plen; q += QD_LZ_SUB) {
+                        const uint32_t slen = std::min<uint32_t>(QD_LZ_SUB, plen - q);
+                        subs.push_back(qd_lz_sub{at + a + q, slen, (uint32_t)bo.pieces.size()});
+                        ranges.push_back(qd_crc_range{at + a + q, slen, 0});
+                    }
+                    bo.pieces.push_back(qd_deflate_piece{at + a, plen, 0});
+                }
+                fr.n = (uint32_t)bo.pieces.size() - fr.first;
+                bo.files.push_back(fr);
+                at = (at + bytes + 15) & ~(uint64_t)15;
+            }
+        first_sub.push_back((uint32_t)subs.size());
+    }
+    const uint32_t n_pieces = (uint32_t)bo.pieces.size(), n_subs = (uint32_t)subs.size();
+    p->st.pairs += n;
+    ++p->st.batches;
+    p->st.text_out_bytes += (int64_t)h_tot[0] + h_tot[1];
+    p->st.pieces += n_pieces;
+    if (!n_pieces) return QD_OK;  // every destination's write flag is off
+    // 6. format, CRC-32, code, pack
+    const int set = take_out_set(p, (int)(batch_index & 1));
+    OutSet& o = p->out[set];
+    bo.set = set;
+    bo.n_pieces = n_pieces;
+    const int64_t out_stride = qd_huffman_member_bound(PIECE_BYTES);
+    const int64_t sub_stride = qd_huffman_member_bound(QD_LZ_SUB);
+    PCHK(p, o.text.need((size_t)at + 64, 0, p->cs));
+    PCHK(p, p->base1.need((size_t)nd * 8, 0, p->cs));
+    PCHK(p, p->base2.need((size_t)nd * 8, 0, p->cs));
+    PCHK(p, o.pieces.need((size_t)n_pieces * sizeof(qd_deflate_piece), 0, p->cs));
+    PCHK(p, p->subs.need((size_t)(n_subs + 1) * sizeof(qd_lz_sub), 0, p->cs));
+    PCHK(p, p->first_sub.need((size_t)(n_pieces + 1) * 4, 0, p->cs));
+    PCHK(p, p->ranges.need((size_t)(n_subs + 1) * sizeof(qd_crc_range), 0, p->cs));
+    PCHK(p, p->crc.need((size_t)(n_subs + 1) * 4, 0, p->cs));
+    PCHK(p, o.members.need((size_t)n_pieces * (size_t)out_stride, 0, p->cs));
+    PCHK(p, o.member_len.need((size_t)n_pieces * 4, 0, p->cs));
+    PCHK(p, o.member_off.need((size_t)(n_pieces + 1) * 8, 0, p->cs));
+    PCHK(p, o.packed.need((size_t)n_pieces * (size_t)out_stride, 0, p->cs));
+    PCHK(p, p->stage.upload(p->base1.p, base1.data(), (size_t)nd * 8, p->cs));
+    PCHK(p, p->stage.upload(p->base2.p, base2.data(), (size_t)nd * 8, p->cs));
+    PCHK(p, p->stage.upload(o.pieces.p, bo.pieces.data(), (size_t)n_pieces * sizeof(qd_deflate_piece), p->cs));
+    PCHK(p, p->stage.upload(p->subs.p, subs.data(), (size_t)n_subs * sizeof(qd_lz_sub), p->cs));
+    PCHK(p, p->stage.upload(p->first_sub.p, first_sub.data(), (size_t)(n_pieces + 1) * 4, p->cs));
+    PCHK(p, p->stage.upload(p->ranges.p, ranges.data(), (size_t)n_subs * sizeof(qd_crc_range), p->cs));
+    qd_format_args fa{};
+    fa.perm = p->perm.as<uint32_t>();
+    fa.sdest = p->sdest.as<uint16_t>();
+    fa.g1 = p->g1.as<uint32_t>();
+    fa.g2 = p->g2.as<uint32_t>();
+    fa.base1 = p->base1.as<int64_t>();
+    fa.base2 = p->base2.as<int64_t>();
+    fa.text1 = p->win[0].buf[p->win[0].cur].p;
+    fa.text2 = p->win[1].buf[p->win[1].cur].p;
+    fa.r1 = ra.r1;
+    fa.r2 = ra.r2;
+    for (int k = 0; k < ni; ++k) {
+        fa.itext[k] = iw[k]->buf[iw[k]->cur].p;
+        fa.idx[k] = ra.idx[k];
+    }
+    fa.out1 = o.text.p;
+    fa.out2 = o.text.p;
+    PCHK(p, qd_text_format(p->plan, S, si.write_pass, si.write_fail, si.write_undet, n, fa, p->cs));
+    PCHK(p, qd_text_crc32(o.text.p, p->ranges.as<qd_crc_range>(), n_subs, p->crc.as<uint32_t>(), p->cs));
+    PCHK(p, qd_text_crc32_combine(p->ranges.as<qd_crc_range>(), p->crc.as<uint32_t>(), p->first_sub.as<uint32_t>(), n_pieces,
+                                  reinterpret_cast<uint32_t*>(o.pieces.p) + 3, 4, p->cs));
+    static_assert(sizeof(qd_deflate_piece) == 16 && offsetof(qd_deflate_piece, crc32) == 12, "the combined CRCs land in the piece table");
+    if (si.level == 1) {
+        PCHK(p, p->tokens.need((size_t)n_subs * QD_LZ_SUB * 4, 0, p->cs));
+        PCHK(p, p->sub_out.need((size_t)n_subs * (size_t)sub_stride, 0, p->cs));
+        PCHK(p, p->sub_bytes.need((size_t)n_subs * 4, 0, p->cs));
+        PCHK(p, qd_launch_lz(o.text.p, o.pieces.as<qd_deflate_piece>(), n_pieces, p->subs.as<qd_lz_sub>(), p->first_sub.as<uint32_t>(), n_subs, p->tokens.as<uint32_t>(),
+                             p->sub_out.p, sub_stride, p->sub_bytes.as<uint32_t>(), o.members.p, out_stride, o.member_len.as<uint32_t>(), p->cs));
+    } else {
+        PCHK(p, qd_launch_huffman(o.text.p, o.pieces.as<qd_deflate_piece>(), n_pieces, o.members.p, out_stride, o.member_len.as<uint32_t>(), p->cs));
+    }
+    PCHK(p, qd_text_pack_members(o.members.p, out_stride, o.member_len.as<uint32_t>(), n_pieces, o.member_off.as<uint64_t>(), o.packed.p, p->cs));
+    PCHK(p, hipEventCreateWithFlags(&bo.done, hipEventDisableTiming));
+    PCHK(p, hipEventRecord(bo.done, p->cs));
+    to_collector(p, std::move(bo));
+    return QD_OK;
+}
+
+int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chunk, qd_sink* sink, int64_t* batch_index) {
+    const int ns = p->n_streams;
+    const uint32_t B = (uint32_t)std::min<int64_t>(p->batch_pairs, 0x7FFFFFFF);
+    for (int s = 0; s < ns; ++s) {
+        Window& w = p->win[s];
+        w.len = 0;
+        w.eof = false;
+        w.dirty = true;
+        w.carry_kept = 0;
+        w.n_blocks = 0;
+        w.runs.clear();
+    }
+    std::vector<size_t> want(ns, 1);  // first round: one upload, to learn the stream's bytes per record
+    for (;;) {
+        // 1. text
+        for (int s = 0; s < ns; ++s) {
+            const int rc = top_up(p, *feeders[s], p->win[s], s, chunk, want[s]);
+            if (rc != QD_OK) return rc;
+        }
+        // 2. records of the windows that changed
+        bool scanned = false;
+        for (int s = 0; s < ns; ++s) {
+            Window& w = p->win[s];
+            if (!w.dirty) continue;
+            const int rc = scan_window(p, w, s);
+            if (rc != QD_OK) return rc;
+            scanned = true;
+        }
+        if (scanned) {
+            int rc = sync_compute(p);
+            if (rc != QD_OK) return rc;
+            bool again = false;
+            for (int s = 0; s < ns; ++s) {
+                Window& w = p->win[s];
+                if (!w.dirty) continue;
+                w.res = reinterpret_cast<qd_scan_result*>(p->h_res.p)[s];
+                bool redo = false;
+                const bool refused = w.n_blocks && (w.res.first_bad != 0xFFFFFFFFu || *batch_index == p->test_fail_inflate_batch);
+                if (refused) {  // the device did not inflate (or check) a block: the host does this batch's blocks of the stream
+                    rc = host_inflate_window(p, w);
+                    if (rc != QD_OK) return rc;
+                    redo = true;
+                }
+                if (w.n_blocks) PCHK(p, hipMemsetAsync(&p->d_res.as<qd_scan_result>()[s].first_bad, 0xFF, 4, p->cs));
+                w.n_blocks = 0;
+                w.runs.clear();
+                if (w.res.overflow) {  // more lines than the table held: it is known how many now
+                    w.line_cap = (w.res.n_lines + w.res.n_lines / 8 + 4096 + 3) & ~3u;
+                    redo = true;
+                }
+                if (redo) {
+                    ++p->st.rescans;
+                    again = true;
+                    continue;
+                }
+                w.dirty = false;
+                if (w.res.n_records) w.avg = std::max(16.0, (double)w.res.tail_start / (double)w.res.n_records);
+            }
+            if (again) continue;
+        }
+        // 3. a stream short of records that has more input: top it up (its window is scanned again)
+        bool short_of = false;
+        for (int s = 0; s < ns; ++s) {
+            Window& w = p->win[s];
+            if (w.res.n_kept >= B || w.eof) continue;
+            if (w.res.n_kept > 0 && (size_t)w.len > WINDOW_MAX / 2) continue;  // a full window: a smaller batch rather than more text
+            const double per = w.avg > 0 ? w.avg : 256.0;
+            const size_t more = (size_t)((double)(B - w.res.n_kept) * per * 1.03) + 4096;
+            want[s] = std::min<size_t>(std::max<size_t>((size_t)w.len + more, (size_t)w.len + 1), WINDOW_MAX * 3 / 4);
+            if (want[s] <= (size_t)w.len) want[s] = (size_t)w.len + 1;
+            short_of = true;
+        }
+        if (short_of) continue;
+        // 4. lock step: pair j = kept record j of every stream (src/Quade.py:210-221)
+        uint32_t n = B;
+        for (int s = 0; s < ns; ++s) n = std::min(n, p->win[s].res.n_kept);
+        if (n) {
+            const int rc = process_batch(p, n, sink, *batch_index);
+            if (rc != QD_OK) return rc;
+            ++*batch_index;
+        }
+        // 5. the chunk ends with its first exhausted stream (src/Quade.py:223-224)
+        bool done = false;
+        for (int s = 0; s < ns; ++s) done = done || (p->win[s].eof && p->win[s].res.n_kept == n);
+        if (done || n == 0) break;
+        // 6. what is left of every window moves to the front of its other buffer
+        for (int s = 0; s < ns; ++s) {
+            Window& w = p->win[s];
+            const uint32_t from = std::min(w.res.carry_start, w.len), left = w.len - from;
+            const int nx = w.cur ^ 1;
+            PCHK(p, w.buf[nx].need((size_t)left + 2 * QD_TEXT_TILE, 0, p->cs));
+            if (left) PCHK(p, hipMemcpyAsync(w.buf[nx].p, w.buf[w.cur].p + from, left, hipMemcpyDeviceToDevice, p->cs));
+            w.cur = nx;
+            w.len = left;
+            w.carry_kept = w.res.n_kept - n;
+            w.dirty = true;
+            const double per = w.avg > 0 ? w.avg : 256.0;
+            want[s] = std::min<size_t>((size_t)left + (size_t)((double)(B > w.carry_kept ? B - w.carry_kept : 0) * per * 1.03) + 4096, WINDOW_MAX * 3 / 4);
+        }
+    }
+    // the streams the chunk did not exhaust: their feeders stop reading this chunk, what they had read is dropped
+    for (int s = 0; s < ns; ++s) feeders[s]->skip_below(chunk + 1);
+    for (int s = 0; s < ns; ++s) {
+        const int rc = drain_chunk(p, *feeders[s], p->win[s], chunk);
+        if (rc != QD_OK) return rc;
+    }
+    return QD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* qd_pipe_last_error(const qd_pipe* p) { return p ? p->err.c_str() : g_pipe_error.c_str(); }
+
+int qd_pipe_create(qd_ctx* ctx, qd_pipe** out) {
+    if (!ctx || !out) return pfail(nullptr, QD_ERR_INVALID, "bad arguments");
+    *out = nullptr;
+    qd_layout L;
+    qd_plan P;
+    int32_t dev = -1;
+    if (qd_get_layout(ctx, &L) != QD_OK || qd_get_plan(ctx, &P) != QD_OK || qd_context_device(ctx, &dev) != QD_OK)
+        return pfail(nullptr, QD_ERR_STATE, "the context needs a plan before a pipeline is made on it");
+    std::unique_ptr<qd_pipe> p(new qd_pipe());
+    p->ctx = ctx;
+    p->device = dev;
+    p->lay = L;
+    p->plan = P;
+    p->n_streams = 2 + L.n_streams;
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&p->cs, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&p->ds, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming) != hipSuccess)
+        return pfail(nullptr, QD_ERR_HIP, "stream creation failed");
+    for (int i = 0; i < 2; ++i)
+        if (hipEventCreateWithFlags(&p->out[i].done, hipEventDisableTiming) != hipSuccess) return pfail(nullptr, QD_ERR_HIP, "event creation failed");
+    if (p->d_res.need(4 * sizeof(qd_scan_result) + 64) != hipSuccess || p->h_res.need(4 * sizeof(qd_scan_result) + 64) != hipSuccess)
+        return pfail(nullptr, QD_ERR_HIP, "allocation failed");
+    if (hipMemset(p->d_res.p, 0xFF, 4 * sizeof(qd_scan_result) + 64) != hipSuccess) return pfail(nullptr, QD_ERR_HIP, "hipMemset failed");
+    *out = p.release();
+    return QD_OK;
+}
+
+int qd_pipe_set_option(qd_pipe* p, const char* name, int64_t value) {
+    if (!p || !name) return QD_ERR_INVALID;
+    const std::string n(name);
+    if (n == "batch_pairs" && value >= 1) p->batch_pairs = value;
+    else if (n == "test_fail_inflate_batch") p->test_fail_inflate_batch = value;
+    else return pfail(p, QD_ERR_INVALID, "unknown option " + n);
+    return QD_OK;
+}
+
+int qd_pipe_run(qd_pipe* p, const qd_pipe_chunk* chunks, int32_t n_chunks, qd_pipe_stats* stats) {
+    if (!p || n_chunks < 0 || (n_chunks && !chunks)) return pfail(p, QD_ERR_INVALID, "bad arguments");
+    p->err.clear();
+    PCHK(p, hipSetDevice(p->device));
+    const int ns = p->n_streams;
+    for (int c = 0; c < n_chunks; ++c) {
+        if (!chunks[c].r1 || !chunks[c].r2 || !chunks[c].i1 || (ns == 4 && !chunks[c].i2) || !chunks[c].sink) return pfail(p, QD_ERR_INVALID, "chunk without files or sink");
+        const int level = qdio::sink_info(chunks[c].sink).level;
+        if (level != 1 && level != -1) return pfail(p, QD_ERR_UNSUPPORTED, "the device codes gzip_level 1 and -1; other levels run on the host's pool");
+    }
+    std::vector<std::unique_ptr<Feeder>> feeders;
+    for (int s = 0; s < ns; ++s) {
+        std::vector<std::string> paths;
+        for (int c = 0; c < n_chunks; ++c) paths.emplace_back(s == 0 ? chunks[c].r1 : s == 1 ? chunks[c].r2 : s == 2 ? chunks[c].i1 : chunks[c].i2);
+        feeders.emplace_back(new Feeder(p->device, std::move(paths)));
+    }
+    for (auto& f : feeders) PCHK(p, f->start());
+    {
+        std::lock_guard<std::mutex> g(p->cm);
+        p->collector_failed = false;
+        p->collector_err.clear();
+    }
+    p->collector = std::thread(collector_thread, p);
+    int rc = QD_OK;
+    int64_t batch_index = 0;
+    for (int c = 0; c < n_chunks && rc == QD_OK; ++c) {
+        for (int s = 0; s < ns; ++s) p->win[s].path = s == 0 ? chunks[c].r1 : s == 1 ? chunks[c].r2 : s == 2 ? chunks[c].i1 : chunks[c].i2;
+        if (chunks[c].begin_message) {
+            fputs(chunks[c].begin_message, stdout);
+            fflush(stdout);
+        }
+        rc = run_chunk(p, feeders, c, chunks[c].sink, &batch_index);
+        if (rc == QD_OK && chunks[c].end_message) {
+            BatchOut m;
+            m.message = chunks[c].end_message;
+            to_collector(p, std::move(m));
+        }
+        std::lock_guard<std::mutex> g(p->cm);
+        if (p->collector_failed) rc = pfail(p, QD_ERR_FORMAT, p->collector_err);
+    }
+    {
+        BatchOut last;
+        last.last = true;
+        to_collector(p, std::move(last));
+    }
+    p->collector.join();
+    (void)hipStreamSynchronize(p->cs);
+    for (auto& f : feeders) f->stop();
+    {
+        std::lock_guard<std::mutex> g(p->cm);
+        if (rc == QD_OK && p->collector_failed) rc = pfail(p, QD_ERR_FORMAT, p->collector_err);
+    }
+    if (stats) {
+        stats->pairs = p->st.pairs;
+        stats->batches = p->st.batches;
+        stats->bgzf_blocks = p->st.bgzf_blocks;
+        stats->host_inflated_runs = p->st.host_inflated_runs;
+        stats->text_segments = p->st.text_segments;
+        stats->pieces = p->st.pieces;
+        stats->host_coded_pieces = p->st.host_coded_pieces;
+        stats->text_in_bytes = p->st.text_in_bytes;
+        stats->text_out_bytes = p->st.text_out_bytes;
+        stats->gzip_bytes = p->st.gzip_bytes;
+        stats->rescans = p->st.rescans;
+    }
+    return rc;
+}
+
+int qd_pipe_destroy(qd_pipe* p) {
+    if (!p) return QD_OK;
+    (void)hipSetDevice(p->device);
+    if (p->cs) (void)hipStreamSynchronize(p->cs);
+    if (p->ds) (void)hipStreamSynchronize(p->ds);
+    for (qd_pipe::Window& w : p->win) {
+        for (DevBuf* b : {&w.buf[0], &w.buf[1], &w.tile_counts, &w.tile_base, &w.lines, &w.rec_tile, &w.recs, &w.status, &w.crc, &w.blk, &w.expect}) b->release();
+    }
+    for (DevBuf* b : {&p->d_res, &p->matches, &p->rows_seq[0], &p->rows_seq[1], &p->rows_qual[0], &p->rows_qual[1], &p->rows_len[0], &p->rows_len[1], &p->codes, &p->mol,
+                      &p->short_idx, &p->dest, &p->len1, &p->len2, &p->hist, &p->tmp, &p->perm, &p->sdest, &p->g1, &p->g2, &p->scan_tiles, &p->first, &p->g1_first,
+                      &p->g2_first, &p->subs, &p->first_sub, &p->ranges, &p->crc, &p->tokens, &p->sub_out, &p->sub_bytes, &p->base1, &p->base2})
+        b->release();
+    for (OutSet& o : p->out) {
+        for (DevBuf* b : {&o.text, &o.pieces, &o.members, &o.member_len, &o.member_off, &o.packed}) b->release();
+        o.h_packed.release();
+        o.h_len.release();
+        if (o.done) (void)hipEventDestroy(o.done);
+    }
+    p->h_res.release();
+    p->h_first.release();
+    if (p->sync_ev) (void)hipEventDestroy(p->sync_ev);
+    if (p->cs) (void)hipStreamDestroy(p->cs);
+    if (p->ds) (void)hipStreamDestroy(p->ds);
+    delete p;
+    return QD_OK;
+}
+
+}  // extern "C"

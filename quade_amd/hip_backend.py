@@ -57,6 +57,16 @@ class qd_slot_buffers(C.Structure):
                 ("short_idx", C.c_void_p * 2), ("short_cap", C.c_int64)]
 
 
+class qd_pipe_chunk(C.Structure):
+    _fields_ = [("r1", C.c_char_p), ("r2", C.c_char_p), ("i1", C.c_char_p), ("i2", C.c_char_p), ("sink", C.c_void_p),
+                ("begin_message", C.c_char_p), ("end_message", C.c_char_p)]
+
+
+class qd_pipe_stats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("pairs", "batches", "bgzf_blocks", "host_inflated_runs", "text_segments", "pieces",
+                                         "host_coded_pieces", "text_in_bytes", "text_out_bytes", "gzip_bytes", "rescans")]
+
+
 STREAM_CONTEXT = C.c_void_p(-1)  # QD_STREAM_CONTEXT: the context's own stream (None/0 = HIP's null stream)
 
 
@@ -145,6 +155,16 @@ SYMBOLS = [
     ("qd_sink_stats", C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("qd_sink_last_error", C.c_char_p, [_P]),
     ("qd_sink_close", C.c_int, [_P]),
+    ("qd_pipe_create", C.c_int, [_P, C.POINTER(_P)]),
+    ("qd_pipe_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
+    ("qd_pipe_run", C.c_int, [_P, C.POINTER(qd_pipe_chunk), C.c_int32, C.POINTER(qd_pipe_stats)]),
+    ("qd_pipe_last_error", C.c_char_p, [_P]),
+    ("qd_pipe_destroy", C.c_int, [_P]),
+    ("qd_dev_fastq_scan", C.c_int64, [C.c_int, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _P, C.c_int64, _P]),
+    ("qd_dev_crc32", C.c_int, [C.c_int, _P, C.c_int64, C.c_int64, C.POINTER(C.c_uint32)]),
+    ("qd_dev_sort_by_dest", C.c_int, [C.c_int, _P, C.c_int64, C.c_int32, _P, _P, _P]),
+    ("qd_get_plan", C.c_int, [_P, C.POINTER(qd_plan)]),
+    ("qd_context_device", C.c_int, [_P, C.POINTER(C.c_int32)]),
 ]
 
 _lib = None
@@ -569,3 +589,58 @@ class Inflater(object):
 
     def __exit__(self, *a):
         self.close()
+
+
+class Pipe(object):
+    """The device-resident chunk pipeline of one context (include/quade_hip.h, qd_pipe_*): whole chunks of fastq(.gz)
+    files in, routed fastq.gz members out, the text staying in HBM in between."""
+
+    def __init__(self, engine, batch_pairs=None):
+        self.lib = load_library()
+        self.engine = engine
+        h = _P()
+        r = self.lib.qd_pipe_create(engine._h, C.byref(h))
+        if r != QD_OK:
+            raise QuadeHipError(r, self.lib.qd_pipe_last_error(None).decode())
+        self._h = h
+        if batch_pairs:
+            self.set_option("batch_pairs", batch_pairs)
+
+    def set_option(self, name, value):
+        r = self.lib.qd_pipe_set_option(self._h, name.encode(), int(value))
+        if r != QD_OK:
+            raise QuadeHipError(r, self.lib.qd_pipe_last_error(self._h).decode())
+
+    def run(self, chunks):
+        """chunks: list of (r1, r2, i1, i2 or None, sink handle, begin message or None, end message or None).
+        Returns the statistics as a dict."""
+        def enc(x):
+            return None if x is None else (x if isinstance(x, bytes) else str(x).encode())
+        arr = (qd_pipe_chunk * max(len(chunks), 1))()
+        for i, (r1, r2, i1, i2, sink, m0, m1) in enumerate(chunks):
+            arr[i] = qd_pipe_chunk(enc(r1), enc(r2), enc(i1), enc(i2), sink, enc(m0), enc(m1))
+        st = qd_pipe_stats()
+        r = self.lib.qd_pipe_run(self._h, arr, len(chunks), C.byref(st))
+        if r != QD_OK:
+            msg = self.lib.qd_pipe_last_error(self._h).decode()
+            if r == QD_ERR_FORMAT:
+                raise IOError(msg)
+            raise QuadeHipError(r, msg)
+        return {n: getattr(st, n) for n, _ in qd_pipe_stats._fields_}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.qd_pipe_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -128,6 +128,12 @@ class Quade(object):
         my_chunks = [c for c in range(n_chunks) if c % self.world == self.rank]
         self.workers = max(1, min(cf.chunk_workers, len(my_chunks)))
         self.parts = self.world > 1 or self.workers > 1  # per-chunk part files, merged in chunk order
+        # The whole chunk loop on the device (qd_pipe_*): inflate -> record scan -> rows -> match -> scatter -> format -> code
+        # with the text resident in HBM; one context drives it.  Anything it does not cover (several devices or chunk
+        # workers in one process, gzip levels the device does not code, the device stages switched off) takes the batch
+        # pipeline over pinned slots below.
+        self.use_pipe = bool(cf.device_pipeline and cf.device_inflate and cf.device_deflate and cf.gzip_level in (-1, 1)
+                             and self.workers == 1 and len(devices) == 1)
         self.engine_groups = []
         for _ in range(self.workers):
             group = []
@@ -135,14 +141,16 @@ class Quade(object):
                 eng = hb.Engine(int(d))  # raises when libquade_hip.so or the GPU is missing: no fallback
                 eng.set_plan(plan)
                 eng.set_barcodes(Sample.BARCODES())
-                eng.slots_create(cf.slots, cf.batch_pairs)
+                if not self.use_pipe:
+                    eng.slots_create(cf.slots, cf.batch_pairs)
                 group.append(eng)
                 self.engines.append(eng)
             self.engine_groups.append(group)
         self.plan, self.layout = plan, self.engines[0].layout
         # output members made on the first device of this process ([gpu] device_deflate): gzip_level -1 (Huffman only) and
-        # 1 (LZ77 + Huffman) are the levels the device implements, the others stay with the host's pool
-        Sample.DEFLATE_DEVICE = self.engines[0].device_id if (cf.device_deflate and cf.gzip_level in (-1, 1)) else -1
+        # 1 (LZ77 + Huffman) are the levels the device implements, the others stay with the host's pool.  (The device
+        # pipeline codes its members itself: its sinks are file sets only.)
+        Sample.DEFLATE_DEVICE = self.engines[0].device_id if (cf.device_deflate and cf.gzip_level in (-1, 1) and not self.use_pipe) else -1
 
         # the communicator comes up before any chunk is touched: rank 0 clears stale part files, then
         # publishes the id the other ranks wait for, so nobody writes parts before the clean-up
@@ -248,6 +256,8 @@ class Quade(object):
         from .dist import chunk_owner, part_dir
         from .sample import WriterSet
         mine = [c for c in range(len(chunks)) if chunk_owner(c, self.world) == self.rank]
+        if self.use_pipe:
+            return self._run_chunks_on_device(chunks, mine, banner)
 
         def one_chunk(c, streams, engines):
             print(banner.format(c + 1, len(chunks)))
@@ -303,6 +313,35 @@ class Quade(object):
             t.join()
         if errors:
             raise errors[0]
+
+    def _run_chunks_on_device(self, chunks, mine, banner):
+        """This rank's chunks through the device-resident pipeline (include/quade_hip.h, qd_pipe_run): one native call
+        for all of them, so that the input of the next chunk is read and uploaded while the current one is worked on."""
+        from .dist import part_dir
+        from .sample import WriterSet
+        eng = self.engine_groups[0][0]
+        part_writers = []
+        args = []
+        for c in mine:
+            if self.parts:
+                d = part_dir(self.outdir, c)
+                os.makedirs(d, exist_ok=True)
+                ws = WriterSet(d, self.cf.gzip_level, deflate_device=-1)
+                part_writers.append(ws)
+            else:
+                if Sample.WRITERS is None:
+                    Sample.WRITERS = WriterSet(Sample.OUTDIR, Sample.GZIP_LEVEL, deflate_device=-1)
+                ws = Sample.WRITERS
+            f = list(chunks[c]) + [None] * (4 - len(chunks[c]))
+            args.append((f[0], f[1], f[2], f[3], ws.handle(), banner.format(c + 1, len(chunks)) + "\n",
+                         "\tEnd of chunk {}\n".format(c + 1)))
+        try:
+            with hb.Pipe(eng, self.cf.batch_pairs if self.cf.batch_pairs_given else 2000000) as pipe:
+                with _timed("device pipeline"):
+                    self.pipe_stats = pipe.run(args)
+        finally:
+            for ws in part_writers:
+                ws.close()
 
     # ~~~~~~~ PRIVATE METHODS ~~~~~~~ #
     def _parse_chunk(self, streams, engines, writers=None):

@@ -43,6 +43,10 @@ class WriterSet(object):
         destination the input order is kept."""
         self._sink.route_batches(batch.n, batch.codes, batch.r1, batch.r2, batch.tags, batch.tag_len)
 
+    def handle(self):
+        """The native sink (qd_sink*) for callers that route on the device (qd_pipe_run)."""
+        return self._sink._h
+
     def flush(self):
         self._sink.flush()
 

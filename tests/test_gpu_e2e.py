@@ -176,9 +176,14 @@ SCENARIOS = {
 }
 
 
+@pytest.mark.parametrize("path", ["device_pipeline", "pinned_slots"])
 @pytest.mark.parametrize("name", sorted(SCENARIOS))
-def test_generated_dataset_matches_oracle(tmp_path, name):
-    sc = SCENARIOS[name]
+def test_generated_dataset_matches_oracle(tmp_path, name, path):
+    """Every scenario twice: through the device-resident chunk pipeline (qd_pipe_run, the default wherever one context drives
+    one device) and through the batch pipeline over pinned slots ([gpu] device_pipeline : False)."""
+    sc = dict(SCENARIOS[name])
+    if path == "pinned_slots":
+        sc["gpu"] = (sc.get("gpu") or "[gpu]\n") + "device_pipeline : False\n"
     rng = np.random.default_rng(abs(hash(name)) % (2 ** 31))
     dual, idx_len = sc["dual"], sc["idx_len"]
     i1 = sc["pos"][0]
