@@ -464,6 +464,9 @@ typedef struct qd_pipe_stats {
     int64_t host_coded_pieces;   /* of them by the host (a member that did not fit its slot on the device) */
     int64_t text_in_bytes, text_out_bytes, gzip_bytes;
     int64_t rescans;             /* window scans repeated (line table too small, host-inflated text) */
+    /* wall seconds: the whole call; the driver waiting for input from the feeders, for its read-backs from the device, for an
+     * output set the collector still holds, in device allocations; the collector waiting for the device, downloading, appending */
+    double run_s, wait_input_s, wait_sync_s, wait_out_set_s, alloc_s, collector_wait_s, download_s, append_s;
 } qd_pipe_stats;
 int qd_pipe_create(qd_ctx* ctx, qd_pipe** out); /* the context holds plan and barcodes */
 /* "batch_pairs": pairs per batch at most (default 2 000 000; windows of text are sized from it, at most 1 GiB per stream);

@@ -2233,7 +2233,7 @@ void sink_account(qd_sink* s, int64_t members, int64_t device_members, int64_t t
 
 void sink_fail(qd_sink* s, const std::string& msg) { sink_error(s, msg); }
 
-void pool_submit(std::function<void()> fn) { pool().submit(std::move(fn)); }
+void pool_submit(std::function<void()> fn, bool urgent) { pool().submit(std::move(fn), urgent); }
 int pool_size() { return pool().size(); }
 
 }  // namespace qdio

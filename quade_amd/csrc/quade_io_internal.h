@@ -43,7 +43,7 @@ bool sink_append(qd_sink* s, void* file, const uint8_t* data, size_t n);
 void sink_account(qd_sink* s, int64_t members, int64_t device_members, int64_t text_bytes, int64_t gzip_bytes);
 void sink_fail(qd_sink* s, const std::string& msg);
 
-void pool_submit(std::function<void()> fn);
+void pool_submit(std::function<void()> fn, bool urgent = false);  // urgent: ahead of the jobs already queued
 int pool_size();
 
 }  // namespace qdio

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -50,6 +51,7 @@ constexpr uint32_t PIECE_BYTES = 1u << 20;       // text per gzip member
 constexpr size_t WINDOW_MAX = (size_t)1 << 30;   // text per stream and batch (offsets are 32 bit)
 constexpr uint32_t LAUNCH_BLOCKS = 8192;         // BGZF blocks per inflate launch at most (sizes the match scratch)
 constexpr size_t GROUP_SEGMENTS = 8;             // uploads gathered per inflate launch
+constexpr size_t READ_PART = 4u << 20;           // an upload buffer is filled by parallel reads of this much
 
 hipError_t wait_event_napping(hipEvent_t ev) {  // hipEventSynchronize spins on this runtime: poll, then nap
     for (int i = 0; i < 64; ++i) {
@@ -63,12 +65,21 @@ hipError_t wait_event_napping(hipEvent_t ev) {  // hipEventSynchronize spins on 
     }
 }
 
+struct Tick {  // adds the wall time of its scope to a counter
+    double& acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit Tick(double& a) : acc(a) {}
+    ~Tick() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+double g_alloc_seconds = 0;  // (driver thread only)
+
 struct DevBuf {  // grow-only device allocation
     uint8_t* p = nullptr;
     size_t cap = 0;
     // keep: the first `keep` bytes survive the growth (copied on `st`, which is then drained)
     hipError_t need(size_t n, size_t keep = 0, hipStream_t st = nullptr) {
         if (n <= cap) return hipSuccess;
+        Tick tick(g_alloc_seconds);
         const size_t want = n + n / 4 + (1u << 16);
         uint8_t* q = nullptr;
         hipError_t e = hipMalloc((void**)&q, want);
@@ -357,6 +368,7 @@ class Feeder {
         if (fd < 0) return fail(c, path + ": " + strerror(errno));
         std::vector<uint8_t> tail;  // the partial block behind the last whole one of the previous buffer
         int64_t file_pos = 0;       // file offset of the buffer's first byte
+        int64_t read_pos = 0;       // file offset of the next byte to read
         bool eof = false, first = true;
         int64_t switch_at = -1;     // >= 0: not (or no longer) BGZF from this file offset on
         while (!eof && switch_at < 0) {
@@ -369,16 +381,58 @@ class Feeder {
             size_t fill = tail.size();
             if (fill) memcpy(pin, tail.data(), fill);
             tail.clear();
-            while (fill < SEG_BYTES && !eof) {
-                const ssize_t g = read(fd, pin + fill, SEG_BYTES - fill);
-                if (g < 0) {
-                    if (errno == EINTR) continue;
-                    fail(c, path + ": " + strerror(errno));
-                    close(fd);
-                    return;
+            {
+                // one thread copies ~2.5 GB/s out of the page cache, less than the device inflates: the buffer's parts are
+                // read side by side on the library's pool (pread at known offsets; the blocks are cut afterwards)
+                const size_t want = SEG_BYTES - fill;
+                const int64_t from = read_pos;
+                const int parts = (int)((want + READ_PART - 1) / READ_PART);
+                std::vector<ssize_t> got((size_t)parts, 0);
+                struct {
+                    std::mutex m;
+                    std::condition_variable cv;
+                    int left;
+                } latch;
+                latch.left = parts;
+                for (int q = 0; q < parts; ++q) {
+                    uint8_t* dst = pin + fill + (size_t)q * READ_PART;
+                    const size_t len = std::min(READ_PART, want - (size_t)q * READ_PART);
+                    const int64_t at = from + (int64_t)q * (int64_t)READ_PART;
+                    auto job = [fd, dst, len, at, q, &got, &latch] {
+                        size_t n = 0;
+                        ssize_t r = 0;
+                        while (n < len && (r = pread(fd, dst + n, len - n, (off_t)(at + (int64_t)n))) != 0) {
+                            if (r < 0) {
+                                if (errno == EINTR) continue;
+                                break;
+                            }
+                            n += (size_t)r;
+                        }
+                        got[(size_t)q] = r < 0 ? -1 : (ssize_t)n;
+                        std::lock_guard<std::mutex> g(latch.m);
+                        if (--latch.left == 0) latch.cv.notify_all();
+                    };
+                    if (q + 1 < parts) qdio::pool_submit(job, true);
+                    else job();  // (the last part on this thread)
                 }
-                if (g == 0) eof = true;
-                fill += (size_t)g;
+                {
+                    std::unique_lock<std::mutex> g(latch.m);
+                    latch.cv.wait(g, [&] { return latch.left == 0; });
+                }
+                for (int q = 0; q < parts; ++q) {
+                    if (got[(size_t)q] < 0) {
+                        fail(c, path + ": read error");
+                        close(fd);
+                        return;
+                    }
+                    fill += (size_t)got[(size_t)q];
+                    read_pos += got[(size_t)q];
+                    const size_t len = std::min(READ_PART, want - (size_t)q * READ_PART);
+                    if ((size_t)got[(size_t)q] < len) {  // the file ends inside this part
+                        eof = true;
+                        break;
+                    }
+                }
             }
             if (first && !qdio::bgzf_block_size(pin, fill)) {  // ordinary gzip: the host's parallel inflater takes the file
                 switch_at = 0;
@@ -462,7 +516,7 @@ struct BatchOut {
 
 struct OutSet {  // per-batch output resources, two of them: the collector drains one while the device fills the other
     DevBuf text, pieces, members, member_len, member_off, packed;
-    PinBuf h_packed, h_len;
+    PinBuf h_len;
     hipEvent_t done = nullptr;
     bool busy = false;
 };
@@ -472,6 +526,8 @@ struct OutSet {  // per-batch output resources, two of them: the collector drain
 struct qd_pipe_stats_impl {
     int64_t pairs = 0, batches = 0, bgzf_blocks = 0, host_inflated_runs = 0, text_segments = 0, pieces = 0, host_coded_pieces = 0;
     int64_t text_in_bytes = 0, text_out_bytes = 0, gzip_bytes = 0, rescans = 0;
+    // where the driver's and the collector's wall time goes (seconds)
+    double wait_input = 0, wait_sync = 0, wait_out_set = 0, alloc = 0, collector_wait = 0, download = 0, append = 0, run = 0;
 };
 
 struct qd_pipe {
@@ -515,6 +571,11 @@ struct qd_pipe {
     // tables and scratch of the format / CRC / coder launches: read by kernels on the compute stream only, so one set serves every batch
     DevBuf subs, first_sub, ranges, crc, tokens, sub_out, sub_bytes, base1, base2;
     OutSet out[2];
+    PinBuf slab[3];                                // the collector's download ring
+    hipEvent_t slab_ev[3] = {nullptr, nullptr, nullptr};
+    bool reserved = false;                         // the buffers have been sized for batch_pairs (after the first scan)
+    int64_t max_r1_bytes = 0;                      // size of the run's largest seq_R1 file
+    bool r1_compressed = true;
     std::mutex om;
     std::condition_variable ocv;
     // collector
@@ -546,6 +607,7 @@ int pfail(qd_pipe* p, int code, const std::string& msg) {
 
 // waits until everything queued on the compute stream so far has run (the driver's read-backs)
 int sync_compute(qd_pipe* p) {
+    Tick tick(p->st.wait_sync);
     PCHK(p, hipEventRecord(p->sync_ev, p->cs));
     PCHK(p, wait_event_napping(p->sync_ev));
     return QD_OK;
@@ -563,7 +625,12 @@ void collector_fail(qd_pipe* p, const std::string& msg) {
 void collect_one(qd_pipe* p, BatchOut& b) {
     if (b.set >= 0 && b.n_pieces) {
         OutSet& o = p->out[b.set];
-        hipError_t e = wait_event_napping(b.done);
+        hipError_t e;
+        {
+            Tick tick(p->st.collector_wait);
+            e = wait_event_napping(b.done);
+        }
+        std::unique_ptr<Tick> dl(new Tick(p->st.download));
         uint64_t* off = nullptr;
         uint32_t* len = nullptr;
         if (e == hipSuccess) e = o.h_len.need((size_t)(b.n_pieces + 1) * 8 + (size_t)b.n_pieces * 4);
@@ -576,8 +643,6 @@ void collect_one(qd_pipe* p, BatchOut& b) {
         if (e == hipSuccess) e = hipEventRecord(o.done, p->ds);
         if (e == hipSuccess) e = wait_event_napping(o.done);
         const uint64_t total = e == hipSuccess ? off[b.n_pieces] : 0;
-        if (e == hipSuccess && total) e = o.h_packed.need(total);
-        if (e == hipSuccess && total) e = hipMemcpyAsync(o.h_packed.p, o.packed.p, total, hipMemcpyDeviceToHost, p->ds);
         // members the device gave up (they did not fit their slots: text that does not compress): their text comes back instead
         std::vector<std::vector<uint8_t>> rescue(b.n_pieces);
         std::vector<uint8_t> text;
@@ -592,49 +657,119 @@ void collect_one(qd_pipe* p, BatchOut& b) {
             }
             ++p->st.host_coded_pieces;
         }
-        if (e == hipSuccess) e = hipEventRecord(o.done, p->ds);
-        if (e == hipSuccess) e = wait_event_napping(o.done);
+        dl.reset();
+        // The packed members come back through a ring of page-locked slabs (a whole batch's worth of page-locked memory would cost
+        // ~1 ms per MB to make); a slab's bytes are appended to their files by jobs on the library's pool, one job per file, while
+        // the next slab is on its way.  Slabs are worked off strictly one after the other, so every file sees its bytes in order.
+        struct Item {  // the members of the batch in piece order: a run of device members = packed[a, b), or a piece the host coded
+            uint32_t file;
+            bool host;
+            uint64_t a, b;
+            uint32_t piece;
+        };
+        std::vector<Item> items;
+        std::vector<void*> files(b.files.size(), nullptr);
+        for (size_t fi = 0; e == hipSuccess && fi < b.files.size(); ++fi) {
+            const FileRun& f = b.files[fi];
+            files[fi] = qdio::sink_file(b.sink, f.code, f.k);  // (created in the order the reference would have: batch, destination)
+            for (uint32_t i = f.first; i < f.first + f.n; ++i) {
+                if (len[i] == 0) items.push_back(Item{(uint32_t)fi, true, 0, 0, i});
+                else if (!items.empty() && !items.back().host && items.back().file == fi && items.back().b == off[i]) items.back().b = off[i + 1];
+                else items.push_back(Item{(uint32_t)fi, false, off[i], off[i + 1], i});
+            }
+        }
+        struct Frag {
+            uint32_t file;
+            const uint8_t* p;
+            size_t n;
+        };
+        struct Latch {
+            std::mutex m;
+            std::condition_variable cv;
+            size_t n = 0;
+            void wait() {
+                std::unique_lock<std::mutex> g(m);
+                cv.wait(g, [this] { return n == 0; });
+            }
+        };
+        constexpr uint64_t SLAB = 32u << 20;
+        constexpr int NSLAB = 3;
+        const uint64_t n_slabs = std::max<uint64_t>(1, (total + SLAB - 1) / SLAB);
+        for (int k = 0; e == hipSuccess && k < NSLAB && (uint64_t)k < n_slabs; ++k) {
+            if (!p->slab[k].p) e = p->slab[k].need(SLAB);
+            if (e == hipSuccess && !p->slab_ev[k]) e = hipEventCreateWithFlags(&p->slab_ev[k], hipEventDisableTiming);
+        }
+        auto fetch = [&](uint64_t i) -> hipError_t {
+            const uint64_t A = i * SLAB, B = std::min(total, A + SLAB);
+            hipError_t r = hipSuccess;
+            if (B > A) r = hipMemcpyAsync(p->slab[i % NSLAB].p, o.packed.p + A, (size_t)(B - A), hipMemcpyDeviceToHost, p->ds);
+            if (r == hipSuccess) r = hipEventRecord(p->slab_ev[i % NSLAB], p->ds);
+            return r;
+        };
+        std::unique_ptr<Latch> prev;
+        size_t it = 0;
+        uint64_t gz_bytes = 0;
+        if (e == hipSuccess) e = fetch(0);
+        for (uint64_t i = 0; e == hipSuccess && i < n_slabs; ++i) {
+            if (i + 1 < n_slabs) e = fetch(i + 1);  // (its slab's jobs -- slab i - 2 -- were waited for below)
+            {
+                Tick tick(p->st.download);
+                if (e == hipSuccess) e = wait_event_napping(p->slab_ev[i % NSLAB]);
+            }
+            if (e != hipSuccess) break;
+            const uint64_t A = i * SLAB, B = std::min(total, A + SLAB);
+            const uint8_t* base = p->slab[i % NSLAB].p;
+            std::vector<Frag> frags;
+            while (it < items.size()) {
+                Item& x = items[it];
+                if (x.host) {
+                    frags.push_back(Frag{x.file, rescue[x.piece].data(), rescue[x.piece].size()});
+                    ++it;
+                    continue;
+                }
+                if (x.a >= B && i + 1 < n_slabs) break;  // a later slab's
+                const uint64_t lo = std::max(x.a, A), hi = std::min(x.b, B);
+                if (hi > lo) frags.push_back(Frag{x.file, base + (lo - A), (size_t)(hi - lo)});
+                if (x.b <= B) {
+                    ++it;
+                } else {
+                    x.a = B;
+                    break;
+                }
+            }
+            Tick tick(p->st.append);
+            if (prev) prev->wait();
+            std::unique_ptr<Latch> cur(new Latch());
+            std::vector<std::vector<Frag>> jobs;
+            for (const Frag& f : frags) {
+                if (jobs.empty() || jobs.back().back().file != f.file) jobs.emplace_back();
+                jobs.back().push_back(f);
+                gz_bytes += f.n;
+            }
+            cur->n = jobs.size();
+            Latch* L = cur.get();
+            qd_sink* sink = b.sink;
+            for (std::vector<Frag>& j : jobs) {
+                void* file = files[j[0].file];
+                qdio::pool_submit([file, sink, L, j = std::move(j)] {
+                    if (file)
+                        for (const Frag& f : j) qdio::sink_append(sink, file, f.p, f.n);
+                    std::lock_guard<std::mutex> g(L->m);
+                    if (--L->n == 0) L->cv.notify_all();
+                });
+            }
+            prev = std::move(cur);
+        }
+        if (prev) {
+            Tick tick(p->st.append);
+            prev->wait();
+        }
         if (e != hipSuccess) {
             collector_fail(p, std::string("download of the members: ") + hipGetErrorString(e));
         } else {
-            // one job per output file: its members in order; files in the order the reference would have created them
-            struct Latch {
-                std::mutex m;
-                std::condition_variable cv;
-                size_t n;
-            } latch;
-            latch.n = b.files.size();
-            for (const FileRun& f : b.files) {
-                void* file = qdio::sink_file(b.sink, f.code, f.k);
-                const uint8_t* packed = o.h_packed.p;
-                qd_sink* sink = b.sink;
-                auto job = [file, f, off, len, packed, sink, &rescue, &latch] {
-                    if (file) {
-                        uint64_t gz = 0;
-                        uint32_t i = f.first;
-                        while (i < f.first + f.n) {  // runs of device members are contiguous in the packed stream
-                            if (len[i] == 0) {
-                                qdio::sink_append(sink, file, rescue[i].data(), rescue[i].size());
-                                gz += rescue[i].size();
-                                ++i;
-                                continue;
-                            }
-                            uint32_t j = i;
-                            while (j < f.first + f.n && len[j] != 0) ++j;
-                            qdio::sink_append(sink, file, packed + off[i], (size_t)(off[j] - off[i]));
-                            gz += off[j] - off[i];
-                            i = j;
-                        }
-                        qdio::sink_account(sink, f.n, f.n, (int64_t)f.text_bytes, (int64_t)gz);
-                    }
-                    std::lock_guard<std::mutex> g(latch.m);
-                    if (--latch.n == 0) latch.cv.notify_all();
-                };
-                qdio::pool_submit(job);
-            }
-            std::unique_lock<std::mutex> g(latch.m);
-            latch.cv.wait(g, [&] { return latch.n == 0; });
-            p->st.gzip_bytes += (int64_t)total;
+            for (const FileRun& f : b.files) qdio::sink_account(b.sink, f.n, f.n, (int64_t)f.text_bytes, 0);
+            qdio::sink_account(b.sink, 0, 0, 0, (int64_t)gz_bytes);
+            p->st.gzip_bytes += (int64_t)gz_bytes;
         }
         {
             std::lock_guard<std::mutex> g(p->om);
@@ -748,7 +883,11 @@ int launch_inflate(qd_pipe* p, Feeder& f, Window& w, int stream_index) {
 // more input for one window until it holds `want` bytes of text or its stream ends
 int top_up(qd_pipe* p, Feeder& f, Window& w, int stream_index, int chunk, size_t want) {
     while (!w.eof && (size_t)w.len + w.pending_text < want) {
-        Segment s = f.pop();
+        Segment s;
+        {
+            Tick tick(p->st.wait_input);
+            s = f.pop();
+        }
         if (s.kind == SEG_ERROR) return pfail(p, QD_ERR_FORMAT, s.err);
         if (s.kind == SEG_END) {
             if (s.chunk != chunk) return pfail(p, QD_ERR_STATE, "feeder out of step with the driver");
@@ -863,9 +1002,70 @@ int host_inflate_window(qd_pipe* p, Window& w) {
     return rc;
 }
 
+// Every buffer at the size a full batch needs, in one go, once the first scan has told what a record of every stream weighs:
+// growing them one by one as the first batches arrive drains the compute stream each time (a quarter of a 16 M-pair run).
+int reserve_buffers(qd_pipe* p, uint32_t B, uint32_t n_dest) {
+    const qd_layout& L = p->lay;
+    double out_text = 0;
+    for (int s = 0; s < p->n_streams; ++s) {
+        Window& w = p->win[s];
+        const double avg = w.avg > 0 ? w.avg : (s < 2 ? 400.0 : 64.0);
+        const size_t text = std::min<size_t>((size_t)((double)B * avg * 1.08) + (96u << 20), WINDOW_MAX + (64u << 20));
+        for (int k = 0; k < 2; ++k) PCHK(p, w.buf[k].need(text + 2 * QD_TEXT_TILE, k == w.cur ? w.len : 0, p->cs));
+        const size_t lines = (size_t)((double)text / avg * 4.4 * 1.25) + 65536;
+        PCHK(p, w.tile_counts.need((text / QD_TEXT_TILE + 3) * 4, 0, p->cs));
+        PCHK(p, w.tile_base.need((text / QD_TEXT_TILE + 3) * 4, 0, p->cs));
+        PCHK(p, w.lines.need(lines * 4 + 64, 0, p->cs));
+        PCHK(p, w.rec_tile.need((lines / 4 / 1024 + 4) * 4, 0, p->cs));
+        PCHK(p, w.recs.need((lines / 4 + 1) * sizeof(qd_rec), 0, p->cs));
+        const size_t blocks = text / 16384 + 1024;  // (bgzip fills its blocks: ~64 KiB of text each)
+        PCHK(p, w.blk.need(blocks * sizeof(qd_inflate_block), 0, p->cs));
+        PCHK(p, w.expect.need(blocks * 4, 0, p->cs));
+        PCHK(p, w.status.need(blocks * 4, 0, p->cs));
+        PCHK(p, w.crc.need(blocks * 4, 0, p->cs));
+        if (s < 2) out_text += (double)B * avg * 1.06;
+    }
+    PCHK(p, p->matches.need((size_t)LAUNCH_BLOCKS * QD_INFLATE_MATCHES_PER_BLOCK * 8, 0, p->cs));
+    const size_t n = B;
+    for (int k = 0; k < L.n_streams; ++k) {
+        PCHK(p, p->rows_seq[k].need(n * L.seq_stride[k] + 64, 0, p->cs));
+        PCHK(p, p->rows_qual[k].need(n * L.qual_stride[k] + 64, 0, p->cs));
+        PCHK(p, p->rows_len[k].need(n + 64, 0, p->cs));
+    }
+    PCHK(p, p->codes.need(n * 2 + 64, 0, p->cs));
+    if (L.mol_width) PCHK(p, p->mol.need(n * L.mol_width + 64, 0, p->cs));
+    PCHK(p, p->short_idx.need((n / 2 + 64) * 4, 0, p->cs));
+    const size_t H = 256 * ((n + 1023) / 1024);
+    PCHK(p, p->hist.need((H + H / 4096 + 8) * 4, 0, p->cs));
+    for (DevBuf* b : {&p->len1, &p->len2, &p->tmp, &p->perm, &p->g1, &p->g2}) PCHK(p, b->need((n + 1) * 4 + 64, 0, p->cs));
+    PCHK(p, p->dest.need(n * 2 + 64, 0, p->cs));
+    PCHK(p, p->sdest.need(n * 2 + 64, 0, p->cs));
+    PCHK(p, p->scan_tiles.need((n / 4096 + 4) * 4, 0, p->cs));
+    const size_t T = (size_t)out_text + (size_t)n_dest * 64;
+    const size_t n_pieces = T / PIECE_BYTES + 2 * (size_t)n_dest + 2, n_subs = T / QD_LZ_SUB + n_pieces;
+    const size_t out_stride = (size_t)qd_huffman_member_bound(PIECE_BYTES), sub_stride = (size_t)qd_huffman_member_bound(QD_LZ_SUB);
+    for (OutSet& o : p->out) {
+        PCHK(p, o.text.need(T + 64, 0, p->cs));
+        PCHK(p, o.pieces.need(n_pieces * sizeof(qd_deflate_piece), 0, p->cs));
+        PCHK(p, o.members.need(n_pieces * out_stride, 0, p->cs));
+        PCHK(p, o.member_len.need(n_pieces * 4, 0, p->cs));
+        PCHK(p, o.member_off.need((n_pieces + 1) * 8, 0, p->cs));
+        PCHK(p, o.packed.need(n_pieces * out_stride, 0, p->cs));
+    }
+    PCHK(p, p->subs.need((n_subs + 1) * sizeof(qd_lz_sub), 0, p->cs));
+    PCHK(p, p->ranges.need((n_subs + 1) * sizeof(qd_crc_range), 0, p->cs));
+    PCHK(p, p->crc.need((n_subs + 1) * 4, 0, p->cs));
+    PCHK(p, p->first_sub.need((n_pieces + 1) * 4, 0, p->cs));
+    PCHK(p, p->tokens.need(n_subs * QD_LZ_SUB * 4, 0, p->cs));
+    PCHK(p, p->sub_out.need(n_subs * sub_stride, 0, p->cs));
+    PCHK(p, p->sub_bytes.need(n_subs * 4, 0, p->cs));
+    return QD_OK;
+}
+
 // an output set the collector is done with
 int take_out_set(qd_pipe* p, int b) {
     OutSet& o = p->out[b];
+    Tick tick(p->st.wait_out_set);
     std::unique_lock<std::mutex> g(p->om);
     p->ocv.wait(g, [&] { return !o.busy; });
     o.busy = true;
@@ -1157,6 +1357,14 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
             }
             if (again) continue;
         }
+        if (!p->reserved) {  // every stream's record size is known now
+            p->reserved = true;
+            // (not for more pairs than the run's largest seq_R1 file can hold: gzip at its best makes 1 byte of 8)
+            const double avg1 = p->win[0].avg > 0 ? p->win[0].avg : 400.0;
+            const uint32_t most = (uint32_t)std::min<double>((double)B, (double)p->max_r1_bytes * (p->r1_compressed ? 8.0 : 1.0) / avg1 + 1024.0);
+            const int rc = reserve_buffers(p, most, 2 * qdio::sink_info(sink).n_samples + 1);
+            if (rc != QD_OK) return rc;
+        }
         // 3. a stream short of records that has more input: top it up (its window is scanned again)
         bool short_of = false;
         for (int s = 0; s < ns; ++s) {
@@ -1251,12 +1459,23 @@ int qd_pipe_run(qd_pipe* p, const qd_pipe_chunk* chunks, int32_t n_chunks, qd_pi
     if (!p || n_chunks < 0 || (n_chunks && !chunks)) return pfail(p, QD_ERR_INVALID, "bad arguments");
     p->err.clear();
     PCHK(p, hipSetDevice(p->device));
+    const auto run_t0 = std::chrono::steady_clock::now();
+    g_alloc_seconds = 0;
     const int ns = p->n_streams;
     for (int c = 0; c < n_chunks; ++c) {
         if (!chunks[c].r1 || !chunks[c].r2 || !chunks[c].i1 || (ns == 4 && !chunks[c].i2) || !chunks[c].sink) return pfail(p, QD_ERR_INVALID, "chunk without files or sink");
         const int level = qdio::sink_info(chunks[c].sink).level;
         if (level != 1 && level != -1) return pfail(p, QD_ERR_UNSUPPORTED, "the device codes gzip_level 1 and -1; other levels run on the host's pool");
     }
+    p->max_r1_bytes = 0;
+    p->r1_compressed = false;
+    for (int c = 0; c < n_chunks; ++c) {
+        struct stat sb;
+        if (stat(chunks[c].r1, &sb) == 0) p->max_r1_bytes = std::max<int64_t>(p->max_r1_bytes, (int64_t)sb.st_size);
+        const size_t n = strlen(chunks[c].r1);
+        p->r1_compressed = p->r1_compressed || (n >= 3 && strcmp(chunks[c].r1 + n - 3, ".gz") == 0) || (n >= 3 && strcmp(chunks[c].r1 + n - 3, ".GZ") == 0);
+    }
+    p->reserved = false;
     std::vector<std::unique_ptr<Feeder>> feeders;
     for (int s = 0; s < ns; ++s) {
         std::vector<std::string> paths;
@@ -1311,6 +1530,14 @@ int qd_pipe_run(qd_pipe* p, const qd_pipe_chunk* chunks, int32_t n_chunks, qd_pi
         stats->text_out_bytes = p->st.text_out_bytes;
         stats->gzip_bytes = p->st.gzip_bytes;
         stats->rescans = p->st.rescans;
+        stats->wait_input_s = p->st.wait_input;
+        stats->wait_sync_s = p->st.wait_sync;
+        stats->wait_out_set_s = p->st.wait_out_set;
+        stats->alloc_s = g_alloc_seconds;
+        stats->collector_wait_s = p->st.collector_wait;
+        stats->download_s = p->st.download;
+        stats->append_s = p->st.append;
+        stats->run_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - run_t0).count();
     }
     return rc;
 }
@@ -1329,12 +1556,15 @@ int qd_pipe_destroy(qd_pipe* p) {
         b->release();
     for (OutSet& o : p->out) {
         for (DevBuf* b : {&o.text, &o.pieces, &o.members, &o.member_len, &o.member_off, &o.packed}) b->release();
-        o.h_packed.release();
         o.h_len.release();
         if (o.done) (void)hipEventDestroy(o.done);
     }
     p->h_res.release();
     p->h_first.release();
+    for (int k = 0; k < 3; ++k) {
+        p->slab[k].release();
+        if (p->slab_ev[k]) (void)hipEventDestroy(p->slab_ev[k]);
+    }
     if (p->sync_ev) (void)hipEventDestroy(p->sync_ev);
     if (p->cs) (void)hipStreamDestroy(p->cs);
     if (p->ds) (void)hipStreamDestroy(p->ds);

@@ -64,7 +64,8 @@ class qd_pipe_chunk(C.Structure):
 
 class qd_pipe_stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("pairs", "batches", "bgzf_blocks", "host_inflated_runs", "text_segments", "pieces",
-                                         "host_coded_pieces", "text_in_bytes", "text_out_bytes", "gzip_bytes", "rescans")]
+                                         "host_coded_pieces", "text_in_bytes", "text_out_bytes", "gzip_bytes", "rescans")] + \
+               [(n, C.c_double) for n in ("run_s", "wait_input_s", "wait_sync_s", "wait_out_set_s", "alloc_s", "collector_wait_s", "download_s", "append_s")]
 
 
 STREAM_CONTEXT = C.c_void_p(-1)  # QD_STREAM_CONTEXT: the context's own stream (None/0 = HIP's null stream)

@@ -3,7 +3,7 @@
 the CLI driver.  Host bound (gunzip, scan, format, gzip); printed as one JSON line.
 usage: python tools/e2e_bench.py [pairs] [gzip level] [chunks] [--single-member | --members] [--binned] [--ranks N]
 input files: BGZF (bgzip layout) by default, --members = 8 MB gzip members, --single-member = one gzip member
-env: E2E_PARALLEL_GUNZIP (1; 0 = ordinary gzip files on one thread each), E2E_GUNZIP_CHUNK, E2E_GUNZIP_IN_FLIGHT, E2E_DEVICE_INFLATE (0; 1 = BGZF inflate on the GPU), E2E_DEVICE_DEFLATE (0; 1 = Huffman-only members made on the GPU, level -1), E2E_WORKERS (chunk_workers), E2E_IO_THREADS, E2E_SAMPLES (96), E2E_BATCH (500000), QUADE_PROFILE=1 (stage timers)"""
+env: E2E_PARALLEL_GUNZIP (1; 0 = ordinary gzip files on one thread each), E2E_GUNZIP_CHUNK, E2E_GUNZIP_IN_FLIGHT, E2E_DEVICE_INFLATE (0; 1 = BGZF inflate on the GPU), E2E_DEVICE_DEFLATE (0; 1 = Huffman-only members made on the GPU, level -1), E2E_WORKERS (chunk_workers), E2E_IO_THREADS, E2E_SAMPLES (96), E2E_BATCH (the driver's default), E2E_DEVICE_PIPELINE (1; 0 = batch pipeline over pinned slots), QUADE_PROFILE=1 (stage timers)"""
 import json
 import os
 import shutil
@@ -26,7 +26,8 @@ ranks = int(sys.argv[sys.argv.index("--ranks") + 1]) if "--ranks" in sys.argv el
 workers = int(os.environ.get("E2E_WORKERS", "1"))
 io_thr = int(os.environ.get("E2E_IO_THREADS", "0"))
 n_samples = int(os.environ.get("E2E_SAMPLES", "96"))
-batch = int(os.environ.get("E2E_BATCH", "500000"))
+batch = int(os.environ.get("E2E_BATCH", "0"))  # 0: the driver's default (2 M pairs through the device pipeline, 500 k over pinned slots)
+dev_pipe = os.environ.get("E2E_DEVICE_PIPELINE", "1") not in ("0", "false", "False")
 work = tempfile.mkdtemp(prefix="quade_e2e_")
 from quade_amd import hip_backend as _hb  # noqa: E402
 for _name, _env in (("parallel_gunzip", "E2E_PARALLEL_GUNZIP"), ("gunzip_chunk_bytes", "E2E_GUNZIP_CHUNK"), ("gunzip_in_flight", "E2E_GUNZIP_IN_FLIGHT"),
@@ -42,11 +43,12 @@ try:
     conf = os.path.join(work, "conf.txt")
     dev_inflate = os.environ.get("E2E_DEVICE_INFLATE", "0") not in ("0", "false", "False")
     dev_deflate = os.environ.get("E2E_DEVICE_DEFLATE", "0") not in ("0", "false", "False")  # gzip level -1 only
-    synth.write_conf(conf, paths, bcs, n_chunks, gpu="[gpu]\nbatch_pairs : %d\ngzip_level : %d\nchunk_workers : %d\nio_threads : %d\ndevice_inflate : %s\ndevice_deflate : %s\n"
-                     % (batch, level, workers, io_thr, dev_inflate, dev_deflate))
+    synth.write_conf(conf, paths, bcs, n_chunks, gpu="[gpu]\n%sgzip_level : %d\nchunk_workers : %d\nio_threads : %d\ndevice_inflate : %s\ndevice_deflate : %s\ndevice_pipeline : %s\n"
+                     % ("batch_pairs : %d\n" % batch if batch else "", level, workers, io_thr, dev_inflate, dev_deflate, dev_pipe))
     out = os.path.join(work, "out")
     os.mkdir(out)
     os.chdir(out)
+    pipe_stats = None
     if ranks > 1:  # one process per GPU; on a 1-GPU box all ranks share GPU 0 and the counts go through files
         env = dict(os.environ, PYTHONPATH=ROOT)
         if os.environ.get("E2E_SHARE_GPU0"):
@@ -68,7 +70,8 @@ try:
         _lib.qd_io_stage_seconds(None, None, 0, 1)  # reset: the dataset was written through the same pool
         c0 = os.times()
         t0 = time.perf_counter()
-        Quade(conf_file=conf)()
+        _q = Quade(conf_file=conf)
+        _q()
         dt = time.perf_counter() - t0
         c1 = os.times()
         if os.environ.get("QUADE_PROFILE"):  # thread-CPU seconds of the library's stages (all threads)
@@ -89,10 +92,11 @@ try:
         cpu_s = (c1.user - c0.user) + (c1.system - c0.system)  # every thread of this process (readers, pool, main)
         cpu_user, cpu_sys = c1.user - c0.user, c1.system - c0.system
         counts = Sample.COUNTS()[:4]
+        pipe_stats = getattr(_q, "pipe_stats", None)
     from quade_amd.fastq_writer import host_cores, io_backend, io_threads
     print(json.dumps({"mode": "end-to-end fastq.gz -> fastq.gz", "chunks": n_chunks, "pairs": n * n_chunks, "seconds": dt,
                       "pairs_per_s": n * n_chunks / dt, "gzip_level": level, "counts": counts, "chunk_workers": workers,
-                      "ranks": ranks, "qualities": quals, "device_inflate": dev_inflate, "device_deflate": dev_deflate, "parallel_gunzip": os.environ.get("E2E_PARALLEL_GUNZIP", "1") != "0", "samples": n_samples, "batch_pairs": batch, "input": {0: "single gzip member", "bgzf": "BGZF"}.get(fmt, "8 MB gzip members"), "gzip_backend": io_backend(),
+                      "ranks": ranks, "qualities": quals, "device_inflate": dev_inflate, "device_deflate": dev_deflate, "device_pipeline": dev_pipe and ranks == 1 and pipe_stats is not None, "pipeline": pipe_stats if ranks == 1 else None, "parallel_gunzip": os.environ.get("E2E_PARALLEL_GUNZIP", "1") != "0", "samples": n_samples, "batch_pairs": batch, "input": {0: "single gzip member", "bgzf": "BGZF"}.get(fmt, "8 MB gzip members"), "gzip_backend": io_backend(),
                       "io_threads": io_threads(), "host_cores": host_cores(), "host_logical_cpus": os.cpu_count(), "dataset_seconds": round(t_gen, 1),
                       "cpu_seconds": cpu_s, "cpu_user_sys": [round(cpu_user, 2), round(cpu_sys, 2)] if cpu_s else None, "cpu_seconds_per_M_pairs": cpu_s / (n * n_chunks / 1e6) if cpu_s else None,
                       "core_utilisation": cpu_s / (dt * host_cores()) if cpu_s else None}))
