@@ -28,3 +28,11 @@ struct qd_lz_sub {
 hipError_t qd_launch_lz(const uint8_t* text, const qd_deflate_piece* pieces, uint32_t n_pieces, const qd_lz_sub* subs, const uint32_t* first_sub,
                         uint32_t n_subs, uint32_t* tokens, uint8_t* sub_out, int64_t sub_stride, uint32_t* sub_bytes, uint8_t* out,
                         int64_t out_stride, uint32_t* out_bytes, hipStream_t st);
+// The two stages on their own, for a caller that has the members' CRC-32s made on the device in between: the sub-block kernel
+// leaves every sub-block's CRC-32 in sub_crc (taken while the text is staged; NULL: not wanted), the caller combines them per
+// piece into qd_deflate_piece::crc32 (quade_text.h, qd_text_crc32_combine) before the members are strung together.
+hipError_t qd_launch_lz_subblocks(const uint8_t* text, const qd_lz_sub* subs, uint32_t n_subs, uint32_t* tokens, uint8_t* sub_out, int64_t sub_stride,
+                                  uint32_t* sub_bytes, uint32_t* sub_crc, hipStream_t st);
+hipError_t qd_launch_lz_members(const qd_deflate_piece* pieces, uint32_t n_pieces, const qd_lz_sub* subs, const uint32_t* first_sub, uint32_t n_subs,
+                                const uint8_t* sub_out, int64_t sub_stride, const uint32_t* sub_bytes, uint8_t* out, int64_t out_stride, uint32_t* out_bytes,
+                                hipStream_t st);

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "crc_lds.h"
 #include "quade_deflate.h"
 
 namespace {
@@ -455,7 +456,7 @@ __device__ void canonical_lut(const uint8_t* len, int n, uint32_t* lut) {
 }
 
 __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, const qd_lz_sub* subs, uint32_t* tokens, uint8_t* sub_out,
-                                                         int64_t sub_stride, uint32_t* sub_bytes) {
+                                                         int64_t sub_stride, uint32_t* sub_bytes, uint32_t* sub_crc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lz_lds[];
     uint32_t* tw = reinterpret_cast<uint32_t*>(lz_lds);                                   // LZ_TEXT_WORDS
     uint32_t* table = reinterpret_cast<uint32_t*>(lz_lds + (size_t)LZ_TEXT_WORDS * 4);     // 1 << LZ_HASH_BITS buckets of 2 x 16 bit
@@ -504,6 +505,13 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
         bcost[tid] = (uint8_t)(c < 1 ? 1 : (c > 12 ? 12 : c));
     }
     __syncthreads();
+    if (sub_crc) {  // the sub-block's CRC-32 while its text is at hand (the tables borrow the hash table's space, which is not in use yet)
+        static_assert((4u << LZ_HASH_BITS) >= 4096 + 64 && (size_t)LZ_BLOCK * 65 * 4 >= (size_t)LZ_SUB, "the CRC stage's tables and slices");
+        qdcrc::stage_tables<LZ_BLOCK>(table);
+        __syncthreads();
+        const uint32_t crc = qdcrc::crc32_lds<LZ_BLOCK, 65>(tw, L, table, table + 1024);
+        if (tid == 0) sub_crc[blockIdx.x] = crc;
+    }
     for (uint32_t i = tid; i < (1u << LZ_HASH_BITS); i += LZ_BLOCK) table[i] = 0;
     __syncthreads();
 
@@ -856,16 +864,31 @@ __global__ __launch_bounds__(256) void lz_members(const qd_deflate_piece* pieces
 }
 }  // namespace
 
-hipError_t qd_launch_lz(const uint8_t* text, const qd_deflate_piece* pieces, uint32_t n_pieces, const qd_lz_sub* subs, const uint32_t* first_sub,
-                        uint32_t n_subs, uint32_t* tokens, uint8_t* sub_out, int64_t sub_stride, uint32_t* sub_bytes, uint8_t* out,
-                        int64_t out_stride, uint32_t* out_bytes, hipStream_t st) {
-    if (n_pieces == 0) return hipSuccess;
+hipError_t qd_launch_lz_subblocks(const uint8_t* text, const qd_lz_sub* subs, uint32_t n_subs, uint32_t* tokens, uint8_t* sub_out, int64_t sub_stride,
+                                  uint32_t* sub_bytes, uint32_t* sub_crc, hipStream_t st) {
+    if (n_subs == 0) return hipSuccess;
     constexpr size_t lds = (size_t)LZ_TEXT_WORDS * 4 + (4u << LZ_HASH_BITS);
     static_assert(LZ_TEXT_WORDS % 4 == 0, "the text is staged 16 bytes at a time");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lz_subblocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (n_subs) hipLaunchKernelGGL(lz_subblocks, dim3(n_subs), dim3(LZ_BLOCK), lds, st, text, subs, tokens, sub_out, sub_stride, sub_bytes);
+    hipLaunchKernelGGL(lz_subblocks, dim3(n_subs), dim3(LZ_BLOCK), lds, st, text, subs, tokens, sub_out, sub_stride, sub_bytes, sub_crc);
+    return hipGetLastError();
+}
+
+hipError_t qd_launch_lz_members(const qd_deflate_piece* pieces, uint32_t n_pieces, const qd_lz_sub* subs, const uint32_t* first_sub, uint32_t n_subs,
+                                const uint8_t* sub_out, int64_t sub_stride, const uint32_t* sub_bytes, uint8_t* out, int64_t out_stride, uint32_t* out_bytes,
+                                hipStream_t st) {
+    if (n_pieces == 0) return hipSuccess;
     hipLaunchKernelGGL(lz_members, dim3(n_subs + n_pieces), dim3(256), 0, st, pieces, subs, first_sub, n_subs, sub_out, sub_stride, sub_bytes,
                        out, out_stride, out_bytes);
     return hipGetLastError();
+}
+
+hipError_t qd_launch_lz(const uint8_t* text, const qd_deflate_piece* pieces, uint32_t n_pieces, const qd_lz_sub* subs, const uint32_t* first_sub,
+                        uint32_t n_subs, uint32_t* tokens, uint8_t* sub_out, int64_t sub_stride, uint32_t* sub_bytes, uint8_t* out,
+                        int64_t out_stride, uint32_t* out_bytes, hipStream_t st) {
+    if (n_pieces == 0) return hipSuccess;
+    const hipError_t e = qd_launch_lz_subblocks(text, subs, n_subs, tokens, sub_out, sub_stride, sub_bytes, nullptr, st);
+    if (e != hipSuccess) return e;
+    return qd_launch_lz_members(pieces, n_pieces, subs, first_sub, n_subs, sub_out, sub_stride, sub_bytes, out, out_stride, out_bytes, st);
 }

@@ -12,6 +12,7 @@
 #define QD_INFLATE_BAD_DISTANCE 6  /* a match reaching behind the start of the block                  */
 #define QD_INFLATE_OVERRUN 7       /* more output than the block's ISIZE                              */
 #define QD_INFLATE_LENGTH 8        /* less output than the block's ISIZE                              */
+#define QD_INFLATE_CRC 9           /* the text's CRC-32 is not the one in the block's trailer (checked on the device when asked) */
 
 struct qd_inflate_block {
     uint32_t in_off, in_len;    // raw deflate payload of the block inside the compressed buffer
@@ -27,4 +28,5 @@ hipError_t qd_launch_inflate(const uint8_t* comp, const qd_inflate_block* blocks
 size_t qd_inflate2_lds(uint32_t max_in_len);  // LDS a workgroup of the second form needs; above 160 KB (payloads beyond ~52 KB: stored blocks) use the first
 hipError_t qd_launch_inflate2(const uint8_t* comp, const qd_inflate_block* blocks, uint32_t n_blocks, uint8_t* out, int32_t* status,
                               unsigned long long* matches, uint32_t matches_per_block, uint32_t max_in_len, hipStream_t st,
-                              uint32_t* rounds_out = nullptr);  // rounds_out (measurement): per block, rounds | deflate blocks << 16
+                              uint32_t* rounds_out = nullptr,           // rounds_out (measurement): per block, rounds | deflate blocks << 16
+                              const uint32_t* expect_crc = nullptr);    // per block, the CRC-32 of its trailer: checked while the text is in LDS (QD_INFLATE_CRC)

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "crc_lds.h"
 #include "quade_inflate.h"
 
 namespace {
@@ -242,9 +243,12 @@ namespace v2 {
 #define QD_INFLATE2_Q 16384 /* positions per window of the match stage (2 bytes of LDS each) */
 #endif
 constexpr int NT = QD_INFLATE2_THREADS;
+constexpr int CRC_SW = NT >= 1024 ? 17 : (NT >= 512 ? 33 : 65);  // words per lane of the CRC stage: NT slices cover a 64 KiB block
+static_assert((size_t)NT * CRC_SW * 4 >= 65536 && 2 * QD_INFLATE2_Q >= 4096 + 64, "the CRC stage's slices and tables");
 struct Lds2 {
     Lds t;
     uint32_t start[NT], exitp[NT], nout[NT], nmat[NT], flag[NT];
+    uint32_t start_sum[2 * (NT / 64)];  // the waves' totals of the span scan
     uint32_t ctl[8];
 };
 enum { F_EOB = 1, F_ERR_CODE = 2, F_ERR_TRUNC = 4 };
@@ -355,7 +359,7 @@ __device__ __forceinline__ void decode_span(const uint32_t* pw, uint32_t total_b
 
 __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, const qd_inflate_block* blocks, uint32_t n_blocks, uint8_t* out,
                                                            int32_t* status, unsigned long long* matches, uint32_t mcap, uint32_t pay_words,
-                                                           uint32_t* rounds_out) {
+                                                           uint32_t* rounds_out, const uint32_t* expect_crc) {
     uint32_t rounds_used = 0, dblocks = 0;
     uint64_t tm[8] = {(uint64_t)wall_clock64(), 0, 0, 0, 0, 0, 0, 0};  // measurement: where a block's time goes (100 MHz ticks), summed over its deflate blocks
     auto stamp = [&](int k, uint64_t& since) {
@@ -534,11 +538,15 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
         S.start[tid] = bitpos + tid * span;
         __syncthreads();
         uint32_t eob_lane = NT;
+        uint32_t ex = 0, no = 0, nm = 0, fl = 0, decoded_from = 0xFFFFFFFFu;
 #pragma unroll 1
         for (int round = 0; round <= QD_INFLATE2_MAX_ROUNDS; ++round) {
-            uint32_t ex, no, nm, fl;
             const uint32_t st = S.start[tid];
-            decode_span<false>(pw, total_bits, L, lit_codes, dist_codes, st, my_limit, ob, 0, olen, list, 0, mcap, ex, no, nm, fl);
+            // (a lane whose start did not move keeps what it found: the confirming rounds decode only the spans that still change)
+            if (st != decoded_from) {
+                decode_span<false>(pw, total_bits, L, lit_codes, dist_codes, st, my_limit, ob, 0, olen, list, 0, mcap, ex, no, nm, fl);
+                decoded_from = st;
+            }
             S.exitp[tid] = ex;
             S.nout[tid] = no;
             S.nmat[tid] = nm;
@@ -573,18 +581,43 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
             err = (S.flag[eob_lane] & F_ERR_TRUNC) ? QD_INFLATE_TRUNCATED : QD_INFLATE_BAD_CODE;
             break;
         }
-        // where every span's bytes and matches go (one lane sums 256 counts)
-        if (tid == 0) {
-            uint32_t o = opos, m = 0;
-            for (uint32_t k = 0; k <= eob_lane; ++k) {
-                const uint32_t no = S.nout[k], nm = S.nmat[k];
-                S.nout[k] = o;
-                S.nmat[k] = m;
-                o += no;
-                m += nm;
+        // where every span's bytes and matches go: exclusive sums over the spans up to the one that ends the block (wave scans, then
+        // the waves' totals; one lane summing NT counts took ~20 us of a block's ~500)
+        {
+            const uint32_t lane = tid & 63u, wave = tid >> 6;
+            uint32_t vo = tid <= eob_lane ? S.nout[tid] : 0u, vm = tid <= eob_lane ? S.nmat[tid] : 0u;
+            const uint32_t o0 = vo, m0 = vm;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t yo = __shfl_up(vo, d, 64), ym = __shfl_up(vm, d, 64);
+                if (lane >= (uint32_t)d) {
+                    vo += yo;
+                    vm += ym;
+                }
             }
-            S.ctl[2] = o;
-            S.ctl[3] = m;
+            __syncthreads();
+            if (lane == 63) {
+                S.start_sum[wave] = vo;
+                S.start_sum[NT / 64 + wave] = vm;
+            }
+            __syncthreads();
+            uint32_t bo = opos, bm = 0, to = opos, tmm = 0;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) {
+                const uint32_t so = S.start_sum[w], sm = S.start_sum[NT / 64 + w];
+                if ((uint32_t)w < wave) {
+                    bo += so;
+                    bm += sm;
+                }
+                to += so;
+                tmm += sm;
+            }
+            S.nout[tid] = bo + vo - o0;
+            S.nmat[tid] = bm + vm - m0;
+            if (tid == 0) {
+                S.ctl[2] = to;
+                S.ctl[3] = tmm;
+            }
         }
         __syncthreads();
         const uint32_t new_opos = S.ctl[2], n_matches = S.ctl[3];
@@ -684,6 +717,14 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
     if (!err && !last) err = QD_INFLATE_BAD_TYPE;
     if (!err && opos != olen) err = QD_INFLATE_LENGTH;
     __syncthreads();
+    // the block's CRC-32 against its trailer while the text is still in LDS (the tables go where the match stage kept its parents)
+    if (expect_crc) {
+        uint32_t* crc_t = ow + 16384 + 4;
+        qdcrc::stage_tables<NT>(crc_t);
+        __syncthreads();
+        const uint32_t crc = qdcrc::crc32_lds<NT, CRC_SW>(ow, err ? 0u : olen, crc_t, crc_t + 1024);
+        if (!err && crc != expect_crc[i]) err = QD_INFLATE_CRC;
+    }
     if (!err) {  // the text leaves: bytes up to the first 4-byte boundary of the destination, dwords, the tail
         uint8_t* const o = out + blk.out_off;
         const uint32_t head = min(olen, (uint32_t)((4u - ((uintptr_t)o & 3u)) & 3u));
@@ -863,7 +904,8 @@ size_t qd_inflate2_lds(uint32_t max_in_len) {
 }
 
 hipError_t qd_launch_inflate2(const uint8_t* comp, const qd_inflate_block* blocks, uint32_t n_blocks, uint8_t* out, int32_t* status,
-                              unsigned long long* matches, uint32_t matches_per_block, uint32_t max_in_len, hipStream_t st, uint32_t* rounds_out) {
+                              unsigned long long* matches, uint32_t matches_per_block, uint32_t max_in_len, hipStream_t st, uint32_t* rounds_out,
+                              const uint32_t* expect_crc) {
     if (n_blocks == 0) return hipSuccess;
     const uint32_t pay_words = (max_in_len + 3) / 4;
     const size_t lds = qd_inflate2_lds(max_in_len);
@@ -871,7 +913,7 @@ hipError_t qd_launch_inflate2(const uint8_t* comp, const qd_inflate_block* block
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::inflate_bgzf_blocks2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(v2::inflate_bgzf_blocks2, dim3(n_blocks), dim3(v2::NT), lds, st, comp, blocks, n_blocks, out, status, matches,
-                       matches_per_block, pay_words, rounds_out);
+                       matches_per_block, pay_words, rounds_out, expect_crc);
     return hipGetLastError();
 }
 

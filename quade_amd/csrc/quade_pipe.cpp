@@ -45,7 +45,7 @@
 namespace {
 
 constexpr size_t SEG_BYTES = 16u << 20;  // bytes per upload (compressed blocks or text)
-constexpr int RING_SLOTS = 24;           // device ring per stream: how far a feeder runs ahead of the kernels
+constexpr int RING_SLOTS = 48;           // device ring per stream: how far a feeder runs ahead of the kernels
 constexpr int PIN_SLOTS = 3;             // page-locked upload buffers per stream
 constexpr uint32_t PIECE_BYTES = 1u << 20;       // text per gzip member
 constexpr size_t WINDOW_MAX = (size_t)1 << 30;   // text per stream and batch (offsets are 32 bit)
@@ -862,16 +862,20 @@ int launch_inflate(qd_pipe* p, Feeder& f, Window& w, int stream_index) {
         const uint32_t n = (uint32_t)std::min<size_t>(LAUNCH_BLOCKS, nb - at);
         if (form2) {
             PCHK(p, p->matches.need((size_t)std::min<size_t>(nb, LAUNCH_BLOCKS) * QD_INFLATE_MATCHES_PER_BLOCK * 8, 0, p->cs));
+            // (every block's CRC-32 against its trailer is checked by the kernel, while the text is in LDS)
             PCHK(p, qd_launch_inflate2(f.ring(), d_blk + at, n, w.buf[w.cur].p, d_status + at, p->matches.as<unsigned long long>(), QD_INFLATE_MATCHES_PER_BLOCK,
-                                       longest, p->cs));
+                                       longest, p->cs, nullptr, d_expect + at));
         } else {
             PCHK(p, qd_launch_inflate(f.ring(), d_blk + at, n, w.buf[w.cur].p, d_status + at, p->cs));
         }
     }
     for (Segment& s : w.pending) PCHK(p, f.consumed(s.slot, p->cs));
-    // every block's CRC-32 against its trailer, on the device: one range per block
-    PCHK(p, qd_text_crc32_blocks(w.buf[w.cur].p, d_blk, (uint32_t)nb, d_crc, p->cs));
-    PCHK(p, qd_text_check_blocks(d_status, d_crc, d_expect, (uint32_t)nb, w.n_blocks, first_bad, p->cs));
+    if (form2) {
+        PCHK(p, qd_text_check_blocks(d_status, d_expect, d_expect, (uint32_t)nb, w.n_blocks, first_bad, p->cs));  // (the statuses say it all)
+    } else {  // the one-wave form does not check: a CRC-32 pass over the text, one range per block
+        PCHK(p, qd_text_crc32_blocks(w.buf[w.cur].p, d_blk, (uint32_t)nb, d_crc, p->cs));
+        PCHK(p, qd_text_check_blocks(d_status, d_crc, d_expect, (uint32_t)nb, w.n_blocks, first_bad, p->cs));
+    }
     w.n_blocks += (uint32_t)nb;
     p->st.bgzf_blocks += (int64_t)nb;
     w.pending.clear();
@@ -1277,17 +1281,21 @@ int process_batch(qd_pipe* p, uint32_t n, qd_sink* sink, int64_t batch_index) {
     fa.out1 = o.text.p;
     fa.out2 = o.text.p;
     PCHK(p, qd_text_format(p->plan, S, si.write_pass, si.write_fail, si.write_undet, n, fa, p->cs));
-    PCHK(p, qd_text_crc32(o.text.p, p->ranges.as<qd_crc_range>(), n_subs, p->crc.as<uint32_t>(), p->cs));
-    PCHK(p, qd_text_crc32_combine(p->ranges.as<qd_crc_range>(), p->crc.as<uint32_t>(), p->first_sub.as<uint32_t>(), n_pieces,
-                                  reinterpret_cast<uint32_t*>(o.pieces.p) + 3, 4, p->cs));
     static_assert(sizeof(qd_deflate_piece) == 16 && offsetof(qd_deflate_piece, crc32) == 12, "the combined CRCs land in the piece table");
+    uint32_t* piece_crc = reinterpret_cast<uint32_t*>(o.pieces.p) + 3;
     if (si.level == 1) {
         PCHK(p, p->tokens.need((size_t)n_subs * QD_LZ_SUB * 4, 0, p->cs));
         PCHK(p, p->sub_out.need((size_t)n_subs * (size_t)sub_stride, 0, p->cs));
         PCHK(p, p->sub_bytes.need((size_t)n_subs * 4, 0, p->cs));
-        PCHK(p, qd_launch_lz(o.text.p, o.pieces.as<qd_deflate_piece>(), n_pieces, p->subs.as<qd_lz_sub>(), p->first_sub.as<uint32_t>(), n_subs, p->tokens.as<uint32_t>(),
-                             p->sub_out.p, sub_stride, p->sub_bytes.as<uint32_t>(), o.members.p, out_stride, o.member_len.as<uint32_t>(), p->cs));
+        // the sub-blocks' CRC-32s come out of the coder (taken while a sub-block's text is staged), the pieces' are combined from them
+        PCHK(p, qd_launch_lz_subblocks(o.text.p, p->subs.as<qd_lz_sub>(), n_subs, p->tokens.as<uint32_t>(), p->sub_out.p, sub_stride, p->sub_bytes.as<uint32_t>(),
+                                       p->crc.as<uint32_t>(), p->cs));
+        PCHK(p, qd_text_crc32_combine(p->ranges.as<qd_crc_range>(), p->crc.as<uint32_t>(), p->first_sub.as<uint32_t>(), n_pieces, piece_crc, 4, p->cs));
+        PCHK(p, qd_launch_lz_members(o.pieces.as<qd_deflate_piece>(), n_pieces, p->subs.as<qd_lz_sub>(), p->first_sub.as<uint32_t>(), n_subs, p->sub_out.p, sub_stride,
+                                     p->sub_bytes.as<uint32_t>(), o.members.p, out_stride, o.member_len.as<uint32_t>(), p->cs));
     } else {
+        PCHK(p, qd_text_crc32(o.text.p, p->ranges.as<qd_crc_range>(), n_subs, p->crc.as<uint32_t>(), p->cs));
+        PCHK(p, qd_text_crc32_combine(p->ranges.as<qd_crc_range>(), p->crc.as<uint32_t>(), p->first_sub.as<uint32_t>(), n_pieces, piece_crc, 4, p->cs));
         PCHK(p, qd_launch_huffman(o.text.p, o.pieces.as<qd_deflate_piece>(), n_pieces, o.members.p, out_stride, o.member_len.as<uint32_t>(), p->cs));
     }
     PCHK(p, qd_text_pack_members(o.members.p, out_stride, o.member_len.as<uint32_t>(), n_pieces, o.member_off.as<uint64_t>(), o.packed.p, p->cs));
@@ -1364,6 +1372,8 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
             const uint32_t most = (uint32_t)std::min<double>((double)B, (double)p->max_r1_bytes * (p->r1_compressed ? 8.0 : 1.0) / avg1 + 1024.0);
             const int rc = reserve_buffers(p, most, 2 * qdio::sink_info(sink).n_samples + 1);
             if (rc != QD_OK) return rc;
+            for (int s = 0; s < ns; ++s) p->win[s].dirty = true;  // (the scans' tables moved: once more, over these first small windows)
+            continue;
         }
         // 3. a stream short of records that has more input: top it up (its window is scanned again)
         bool short_of = false;
