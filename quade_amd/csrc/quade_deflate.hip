@@ -310,8 +310,12 @@ hipError_t qd_launch_huffman(const uint8_t* text, const qd_deflate_piece* pieces
 // that would not fit its slot is reported with length 0 and the host makes that member itself.
 // ------------------------------------------------------------------------------------------------------------------------
 namespace {
-constexpr int LZ_SUB = QD_LZ_SUB, LZ_WAVES = 4, LZ_BLOCK = 64 * LZ_WAVES, LZ_REG = LZ_SUB / LZ_WAVES;
+#ifndef QD_LZ_WAVES
+#define QD_LZ_WAVES 8 /* waves per sub-block: candidate rounds of 64 x this many positions, the parse in as many stretches (8 against 4: the coder 1.25 x faster, files 0.3-0.8 % larger: profiles/r04_ab_lz_waves.txt) */
+#endif
+constexpr int LZ_SUB = QD_LZ_SUB, LZ_WAVES = QD_LZ_WAVES, LZ_BLOCK = 64 * LZ_WAVES, LZ_REG = LZ_SUB / LZ_WAVES;
 constexpr int LZ_HASH_BITS = 11, LZ_NICE = 32, LZ_DNA_MIN = 12, LZ_MATCH_BITS = 13, LZ_MAXLEN = 256;
+constexpr int LZ_CRC_SW = LZ_WAVES >= 16 ? 17 : (LZ_WAVES >= 8 ? 33 : 65);  // words per lane of the CRC stage
 constexpr int LZ_TEXT_WORDS = (LZ_SUB + 320) / 4;  // the text and what the widest compare may read behind it
 constexpr int LZ_NL = 286, LZ_ND = 30;
 static_assert(LZ_SUB <= 65536 && LZ_SUB % 256 == 0, "table entries are 16-bit positions inside the sub-block");
@@ -506,10 +510,10 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
     }
     __syncthreads();
     if (sub_crc) {  // the sub-block's CRC-32 while its text is at hand (the tables borrow the hash table's space, which is not in use yet)
-        static_assert((4u << LZ_HASH_BITS) >= 4096 + 64 && (size_t)LZ_BLOCK * 65 * 4 >= (size_t)LZ_SUB, "the CRC stage's tables and slices");
+        static_assert((4u << LZ_HASH_BITS) >= 4096 + 64 && (size_t)LZ_BLOCK * LZ_CRC_SW * 4 >= (size_t)LZ_SUB, "the CRC stage's tables and slices");
         qdcrc::stage_tables<LZ_BLOCK>(table);
         __syncthreads();
-        const uint32_t crc = qdcrc::crc32_lds<LZ_BLOCK, 65>(tw, L, table, table + 1024);
+        const uint32_t crc = qdcrc::crc32_lds<LZ_BLOCK, LZ_CRC_SW>(tw, L, table, table + 1024);
         if (tid == 0) sub_crc[blockIdx.x] = crc;
     }
     for (uint32_t i = tid; i < (1u << LZ_HASH_BITS); i += LZ_BLOCK) table[i] = 0;

@@ -7,6 +7,6 @@ for name in "$@"; do
   [ "$name" != default ] && lib=quade_amd/lib/variants/libq_$name.so
   for rep in 1 2; do
     QUADE_HIP_LIB=$PWD/$lib E2E_DEVICE_INFLATE=1 E2E_DEVICE_DEFLATE=1 timeout -k 10 300 python3 tools/e2e_bench.py $args 2>&1 | grep -v "Create " | tail -1 |
-      python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); p=d["pipeline"]; print("%-10s %6.2f M pairs/s  run %.3f s (input wait %.2f, sync wait %.2f, alloc %.2f)  %.2f core-s per M pairs" % (sys.argv[1], d["pairs_per_s"]/1e6, p["run_s"], p["wait_input_s"], p["wait_sync_s"], p["alloc_s"], d["cpu_seconds_per_M_pairs"]))' $name
+      python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); p=d["pipeline"]; print("%-10s %6.2f M pairs/s  run %.3f s (input wait %.2f, sync wait %.2f, alloc %.2f)  %.2f core-s per M pairs  gzip %.4f of the text" % (sys.argv[1], d["pairs_per_s"]/1e6, p["run_s"], p["wait_input_s"], p["wait_sync_s"], p["alloc_s"], d["cpu_seconds_per_M_pairs"], p["gzip_bytes"]/p["text_out_bytes"]))' $name
   done
 done
