@@ -180,6 +180,8 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
         from quade_amd.sample import Sample
         n = n_pairs * n_chunks
 
+        pipe_stats = {}
+
         def run(level, tag, more=""):
             conf = os.path.join(work, "conf_%s.txt" % tag)
             synth.write_conf(conf, paths, bcs, n_chunks, gpu="[gpu]\ngzip_level : %d\n%s" % (level, more))
@@ -191,9 +193,11 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
                 with stdout_to_stderr():  # the driver and the native sink print progress lines; stdout carries one JSON line
                     c0 = os.times()
                     t0 = time.perf_counter()
-                    Quade(conf_file=conf)()
+                    q = Quade(conf_file=conf)
+                    q()
                     dt = time.perf_counter() - t0
                     c1 = os.times()
+                pipe_stats[tag] = getattr(q, "pipe_stats", None)  # not None: the chunks went through the device-resident pipeline
                 cpu_s = (c1.user - c0.user) + (c1.system - c0.system)  # all threads of this process: readers, pool, main
                 counts = Sample.COUNTS()[:4]
             finally:
@@ -206,6 +210,8 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
         # ~0.8 GB of page-locked buffers, device scratch, the pool's threads) are not a rate
         run(gzip_level, "warm")
         dt, cpu_s, counts, out_bytes = run(gzip_level, "lvl")  # (level 1: its members are made on the GPU -- LZ77 + Huffman, quade_deflate.hip)
+        # ... the same job through r03's path: batches over pinned slots, the text crossing PCIe between the device stages
+        dt_ps, cpu_ps, counts_ps, out_bytes_ps = run(gzip_level, "slots", "device_pipeline : False\n")
         dt_1h, cpu_1h, counts_1h, out_bytes_1h = run(gzip_level, "lvlhost", "device_deflate : False\n")  # ... and by the host's pool alone
         # the same job with gzip_level -1: output members are one dynamic-Huffman block of literals (no string matching)
         dt_h, cpu_h, counts_h, out_bytes_h = run(-1, "huff")  # (its members are made on the GPU: [gpu] device_deflate, the default)
@@ -256,8 +262,17 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
         binned["counts_equal"] = counts_b[0] == counts[0]  # (another draw of reads: the totals agree, the split need not)
         host1 = sub(dt_1h, cpu_1h, counts_1h, gzip_level, "same input and level, [gpu] device_deflate : False (libdeflate on the pool's threads)",
                     output_gz_bytes=out_bytes_1h)
-        return {"value": n / dt, "untimed_warmup_runs": 1, "host_pool_only": host1,
-                "members_made_by": "the GPU (quade_deflate.hip: LZ77 + dynamic Huffman) while page-locked buffers last, the host's pool otherwise",
+        slots = sub(dt_ps, cpu_ps, counts_ps, gzip_level, "same input and level, [gpu] device_pipeline : False: batches over pinned slots, device inflate and "
+                    "device coder as separate lanes with the text crossing PCIe between them (r03's default path)", output_gz_bytes=out_bytes_ps)
+        # the reference's own path beside it: the oracle's restatement of src/Quade.py:169-254 -- per-read objects,
+        # dict match, min() gate, FastqWriter with gzip.open's default level -- on one core, on a bounded sample of the same workload,
+        # and the device pipeline's outputs for that sample compared with it byte for byte
+        cpu_ref = e2e_cpu_baseline(work, synth, Quade, n_sample=200_000)
+        return {"value": n / dt, "untimed_warmup_runs": 1, "host_pool_only": host1, "pinned_slots_path": slots, "cpu_baseline": cpu_ref,
+                "path": "device-resident chunk pipeline (qd_pipe_run): inflate -> record scan -> rows -> match -> scatter -> format -> CRC-32 -> coder on the GPU"
+                        if pipe_stats.get("lvl") else "batches over pinned slots",
+                "pipeline": pipe_stats.get("lvl"),
+                "members_made_by": "the GPU (quade_deflate.hip: LZ77 + dynamic Huffman)",
                 "huffman_only": huff, "single_member_gzip": single, "binned_qualities": binned, "host_level6": lvl6, "default_level": gzip_level, "unit": "read-pairs/s", "pairs": n, "chunks": n_chunks, "seconds": dt, "gzip_level": gzip_level,
                 "samples": len(bcs), "gzip_backend": io_backend(), "io_threads": io_threads(), "host_cores": host_cores(),
                 "input_gz_bytes": in_bytes, "output_gz_bytes": out_bytes, "counts_total_pass_fail_undetermined": counts,
@@ -270,6 +285,49 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
                         "report through quade_amd.quade (CLI driver), one process, one GPU" % len(bcs)}
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def e2e_cpu_baseline(work, synth, Quade, n_sample):
+    """The reference's end-to-end path on the host: oracle.run_quade (the restated src/Quade.py:169-254 + src/Sample.py:56-91 +
+    src/FastqWriter.py:48-90, pure Python, one thread) timed on n_sample pairs of the same generator's records, and the device
+    pipeline's files for the same inputs compared with the oracle's, decompressed, byte for byte."""
+    import gzip
+    from oracle import quade_oracle as qo
+    d = os.path.join(work, "cpu_sample")
+    os.mkdir(d)
+    paths, bcs = synth.write_fastq_dataset(d, n_sample)
+    conf = os.path.join(d, "conf.txt")
+    synth.write_conf(conf, paths, bcs, 1, gpu="[gpu]\ngzip_level : 1\n")
+    ref_dir, my_dir = os.path.join(d, "ref"), os.path.join(d, "mine")
+    os.mkdir(ref_dir)
+    os.mkdir(my_dir)
+    with stdout_to_stderr():
+        c0 = os.times()
+        t0 = time.perf_counter()
+        sset, _ = qo.run_quade(conf, outdir=ref_dir)
+        dt = time.perf_counter() - t0
+        c1 = os.times()
+        cwd = os.getcwd()
+        os.chdir(my_dir)
+        try:
+            q = Quade(conf_file=conf)
+            q()
+        finally:
+            os.chdir(cwd)
+    names = sorted(f for f in os.listdir(ref_dir) if f.endswith(".fastq.gz"))
+    same = names == sorted(f for f in os.listdir(my_dir) if f.endswith(".fastq.gz"))
+    for f in names:
+        if not same:
+            break
+        with gzip.open(os.path.join(ref_dir, f), "rb") as a, gzip.open(os.path.join(my_dir, f), "rb") as b:
+            same = a.read() == b.read()
+    from quade_amd.sample import Sample
+    return {"value": n_sample / dt, "unit": "read-pairs/s", "cores": 1, "kind": "port", "seconds": dt,
+            "cpu_seconds": (c1.user - c0.user) + (c1.system - c0.system),
+            "sample": "%d pairs of the same generator (2x150 bp + dual 8 bp index, BGZF inputs, %d samples): oracle.run_quade = the reference's "
+                      "loop, per-read objects and FastqWriter with gzip.open's default level, one thread" % (n_sample, len(bcs)),
+            "outputs_equal_device_pipeline": bool(same), "counts_equal": Sample.COUNTS() == sset.counts(),
+            "device_path_was_the_pipeline": getattr(q, "pipe_stats", None) is not None}
 
 
 def mapped_libraries(word):

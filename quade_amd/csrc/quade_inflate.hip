@@ -236,15 +236,15 @@ __device__ int codes(Bits& b, Lds& L, uint8_t* o, uint32_t& opos, uint32_t olen,
 #define QD_INFLATE2_MAX_ROUNDS (1024 + 1) /* every round confirms at least one more lane (A/B: a small bound shows how many rounds real blocks need) */
 #endif
 #ifndef QD_INFLATE2_THREADS
-#define QD_INFLATE2_THREADS 512 /* lanes (= spans) per block: 0.58 ms per block against 0.83 with 256 (rounds 211 vs 298 us, write 98 vs 155, matches 136 vs 235) */
+#define QD_INFLATE2_THREADS 0 /* lanes (= spans) per block: 0 = 1 024 where the payload leaves the LDS for it, else 512 (512 against 256: 0.58 vs 0.83 ms per block;
+                                  1 024 against 512: the end-to-end job 9 % faster, profiles/r04_ab_inflate_threads.txt); 256 / 512 / 1024 fix it */
 #endif
 namespace v2 {
 #ifndef QD_INFLATE2_Q
 #define QD_INFLATE2_Q 16384 /* positions per window of the match stage (2 bytes of LDS each) */
 #endif
-constexpr int NT = QD_INFLATE2_THREADS;
-constexpr int CRC_SW = NT >= 1024 ? 17 : (NT >= 512 ? 33 : 65);  // words per lane of the CRC stage: NT slices cover a 64 KiB block
-static_assert((size_t)NT * CRC_SW * 4 >= 65536 && 2 * QD_INFLATE2_Q >= 4096 + 64, "the CRC stage's slices and tables");
+static_assert(2 * QD_INFLATE2_Q >= 4096 + 64, "the CRC stage's tables lie where the match stage keeps its parents");
+template <int NT>
 struct Lds2 {
     Lds t;
     uint32_t start[NT], exitp[NT], nout[NT], nmat[NT], flag[NT];
@@ -357,6 +357,7 @@ __device__ __forceinline__ void decode_span(const uint32_t* pw, uint32_t total_b
     flag = fl;
 }
 
+template <int NT>
 __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, const qd_inflate_block* blocks, uint32_t n_blocks, uint8_t* out,
                                                            int32_t* status, unsigned long long* matches, uint32_t mcap, uint32_t pay_words,
                                                            uint32_t* rounds_out, const uint32_t* expect_crc) {
@@ -369,9 +370,11 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
     };
     uint64_t since = tm[0];
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    Lds2& S = *reinterpret_cast<Lds2*>(lds_raw);
+    constexpr int CRC_SW = NT >= 1024 ? 17 : (NT >= 512 ? 33 : 65);  // words per lane of the CRC stage: NT slices cover a 64 KiB block
+    static_assert((size_t)NT * CRC_SW * 4 >= 65536, "the CRC stage's slices");
+    Lds2<NT>& S = *reinterpret_cast<Lds2<NT>*>(lds_raw);
     Lds& L = S.t;
-    uint32_t* pw = reinterpret_cast<uint32_t*>(lds_raw + ((sizeof(Lds2) + 15) & ~(size_t)15));  // the payload, pay_words + 4 words
+    uint32_t* pw = reinterpret_cast<uint32_t*>(lds_raw + ((sizeof(Lds2<NT>) + 15) & ~(size_t)15));  // the payload, pay_words + 4 words
     uint32_t* ow = pw + pay_words + 4;                                                          // the text, 64 KiB + 16 bytes
     uint8_t* ob = reinterpret_cast<uint8_t*>(ow);
     const uint32_t i = blockIdx.x, tid = threadIdx.x;
@@ -899,22 +902,42 @@ __global__ __launch_bounds__(64) void inflate_bgzf_blocks(const uint8_t* comp, c
 }
 
 // dynamic LDS of the second form's workgroups for a launch whose longest payload is max_in_len bytes: tables | payload | text | parents
-size_t qd_inflate2_lds(uint32_t max_in_len) {
-    return ((sizeof(v2::Lds2) + 15) & ~(size_t)15) + ((size_t)((max_in_len + 3) / 4) + 4) * 4 + 65536 + 16 + 2 * QD_INFLATE2_Q;
+template <int NT>
+static size_t inflate2_lds(uint32_t max_in_len) {
+    return ((sizeof(v2::Lds2<NT>) + 15) & ~(size_t)15) + ((size_t)((max_in_len + 3) / 4) + 4) * 4 + 65536 + 16 + 2 * QD_INFLATE2_Q;
+}
+// (what the narrowest instantiation needs: a launch that fits no form is the one-wave kernel's)
+size_t qd_inflate2_lds(uint32_t max_in_len) { return inflate2_lds<512>(max_in_len); }
+
+template <int NT>
+static hipError_t launch_inflate2(const uint8_t* comp, const qd_inflate_block* blocks, uint32_t n_blocks, uint8_t* out, int32_t* status,
+                                  unsigned long long* matches, uint32_t matches_per_block, uint32_t max_in_len, hipStream_t st, uint32_t* rounds_out,
+                                  const uint32_t* expect_crc) {
+    const uint32_t pay_words = (max_in_len + 3) / 4;
+    const size_t lds = inflate2_lds<NT>(max_in_len);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::inflate_bgzf_blocks2<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(v2::inflate_bgzf_blocks2<NT>, dim3(n_blocks), dim3(NT), lds, st, comp, blocks, n_blocks, out, status, matches,
+                       matches_per_block, pay_words, rounds_out, expect_crc);
+    return hipGetLastError();
 }
 
+// 1 024 lanes per block while the launch's longest payload leaves room for their bookkeeping in LDS (up to ~40 KB: every block of fastq
+// text bgzip makes), 512 beyond that (up to ~52 KB); QD_INFLATE2_THREADS fixes the count (measurement builds).
 hipError_t qd_launch_inflate2(const uint8_t* comp, const qd_inflate_block* blocks, uint32_t n_blocks, uint8_t* out, int32_t* status,
                               unsigned long long* matches, uint32_t matches_per_block, uint32_t max_in_len, hipStream_t st, uint32_t* rounds_out,
                               const uint32_t* expect_crc) {
     if (n_blocks == 0) return hipSuccess;
-    const uint32_t pay_words = (max_in_len + 3) / 4;
-    const size_t lds = qd_inflate2_lds(max_in_len);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::inflate_bgzf_blocks2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(v2::inflate_bgzf_blocks2, dim3(n_blocks), dim3(v2::NT), lds, st, comp, blocks, n_blocks, out, status, matches,
-                       matches_per_block, pay_words, rounds_out, expect_crc);
-    return hipGetLastError();
+#if QD_INFLATE2_THREADS == 1024 || QD_INFLATE2_THREADS == 0
+    if (inflate2_lds<1024>(max_in_len) <= 160 * 1024)
+        return launch_inflate2<1024>(comp, blocks, n_blocks, out, status, matches, matches_per_block, max_in_len, st, rounds_out, expect_crc);
+#endif
+#if QD_INFLATE2_THREADS == 256
+    if (inflate2_lds<256>(max_in_len) <= 160 * 1024)
+        return launch_inflate2<256>(comp, blocks, n_blocks, out, status, matches, matches_per_block, max_in_len, st, rounds_out, expect_crc);
+#endif
+    if (inflate2_lds<512>(max_in_len) > 160 * 1024) return hipErrorInvalidValue;
+    return launch_inflate2<512>(comp, blocks, n_blocks, out, status, matches, matches_per_block, max_in_len, st, rounds_out, expect_crc);
 }
 
 hipError_t qd_launch_inflate(const uint8_t* comp, const qd_inflate_block* blocks, uint32_t n_blocks, uint8_t* out,
