@@ -161,8 +161,6 @@ int qd_kernel_kind(const qd_ctx* ctx, int has_len);
  *   "mol_strips"              1 = stage molecular bytes through LDS for 16-byte stores (default), 0 = off
  *   "force_generic"           1 = always launch the generic kernel
  *   "kernel"                  0 = automatic (default), 1 = fast (when the plan is eligible), 2 = generic
- *   "work_queue"              fast kernel, dual-index forms: 1 = a persistent grid whose waves draw their work from counters
- *                             in global memory; 0 (default, automatic: currently never) and 2 = static split / oversubscribed grid
  *   "fold_pairs"              the device counts into 32-bit per-workgroup rows that are folded into 64-bit totals
  *                             before this many pairs have been launched since the last fold (default and
  *                             maximum 2^32 - 1; tests lower it) */
@@ -361,7 +359,9 @@ const char* qd_reader_last_error(const qd_reader* reader); /* reader == NULL: wh
  *   "parallel_gunzip"        1 (default) / 0 = one thread per file (libdeflate per member, streaming zlib beyond 32 MB)
  *   "gunzip_chunk_bytes"     compressed bytes per chunk (default 4 MiB, at least 64 KiB)
  *   "gunzip_min_file_bytes"  smaller files are inflated by one thread (default 8 MiB)
- *   "gunzip_in_flight"       chunks in flight per file, 0 (default) = half the pool's threads, at least 4 */
+ *   "gunzip_in_flight"       chunks in flight per file, 0 (default) = half the pool's threads, at least 4
+ *   "test_deflate_fail_after" / "test_inflate_fail_after"  tests: a device lane of the sink / of a reader treats the device as
+ *                            failed after this many batches / runs (-1, the default: never) */
 int qd_io_set_option(const char* name, int64_t value);
 /* Chunks of this reader's file that were inflated speculatively and proven / inflated by the coordinator itself. */
 int qd_reader_gunzip_stats(const qd_reader* reader, int64_t* parallel_chunks, int64_t* serial_chunks);

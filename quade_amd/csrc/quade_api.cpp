@@ -78,9 +78,6 @@ struct qd_ctx {
     int opt_block = 0;        // 0 = automatic
     int opt_mol_strips = 1;   // LDS-staged molecular stores in the fast kernel
     int opt_kernel = 0;       // 0 = automatic, K_FAST / K_GENERIC
-    int opt_work_queue = 0;   // fast kernel, dual-index forms: 1 = waves draw their runs from a work queue; 0 (automatic) and 2 = static split
-    uint32_t* d_wq = nullptr; // ring of QD_WQ_SETS counter sets of the work queue; one per launch in flight
-    uint32_t wq_next = 0;
     QdKernelCache kcache;     // per-context launch memo (attribute set, occupancy)
     // streams this context has work on (its own, its slots', the caller's) with an event recorded after
     // the last operation issued on each: waits are scoped to the context, never the whole device
@@ -97,10 +94,6 @@ struct qd_ctx {
     uint64_t fold_limit = 0xFFFFFFFFull;    // option "fold_pairs": fold before pairs_in_rows would pass this
     uint64_t folds = 0;
 
-#ifdef QD_DEBUG_TIMES
-    uint64_t* d_dbg = nullptr;  // [65536][3] per workgroup {start, end, hardware id} of the last fast launch
-    unsigned last_grid_hint = 0;
-#endif
     std::vector<Slot> slots;
     int64_t slot_pairs = 0;
     // One upload stream for all slots: their H2D copies run one after the other at the full link rate and a
@@ -455,31 +448,30 @@ int launch(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* 
     p.mol = mol;
     p.n = n;
     hipError_t e;
-#ifdef QD_DEBUG_TIMES
-    if (!c->d_dbg) {
-        HIPCHK(c, hipMalloc(&c->d_dbg, (size_t)65536 * 3 * 8));
-    }
-    HIPCHK(c, hipMemsetAsync(c->d_dbg, 0, (size_t)65536 * 3 * 8, st));
-    p.dbg = c->d_dbg;
-#endif
+    bool fast_done = false;
     if (kind == K_FAST) {
-        // (automatic = never: the form measured 1 % behind the static persistent grid on a large table image and 12 %
-        // behind the oversubscribed grid on small ones, profiles/r03_work_queue_*.txt; it stays selectable)
-        if (c->opt_work_queue == 1) {
-            if (!c->d_wq) {  // zero once: every launch leaves its set zeroed behind it
-                HIPCHK(c, hipMalloc(&c->d_wq, (size_t)QD_WQ_SETS * QD_WQ_SET_WORDS * 4));
-                HIPCHK(c, hipMemset(c->d_wq, 0, (size_t)QD_WQ_SETS * QD_WQ_SET_WORDS * 4));
-            }
-            p.wq = c->d_wq + (size_t)(c->wq_next++ % QD_WQ_SETS) * QD_WQ_SET_WORDS;
-        }
         e = qd_launch_fast(p, c->kcache, c->cu, c->opt_wg_per_cu, c->opt_block, c->lds_bytes, c->lds_strip_bytes, st);
-    } else {
+        fast_done = e == hipSuccess;
+        if (e == hipErrorInvalidValue) {  // no instantiation for this layout in this build (tuning builds leave static shapes out): the generic kernel takes it
+            (void)hipGetLastError();
+            fill_params(c, p, false);
+            for (int k = 0; k < L.n_streams; ++k) {
+                p.seq[k] = rows->seq[k];
+                p.qual[k] = rows->qual[k];
+                p.len[k] = rows->len[k];
+            }
+            p.codes = codes;
+            p.mol = mol;
+            p.n = n;
+        }
+    }
+    if (!fast_done && (kind != K_FAST || e == hipErrorInvalidValue)) {
         const int64_t nb = (n + QD_GEN_BLOCK - 1) / QD_GEN_BLOCK;
         const int grid = (int)std::min<int64_t>(nb, (int64_t)c->cu * 8);
         e = qd_launch_generic(p, grid, st);
     }
     if (e != hipSuccess) return fail(c, QD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    if (kind != K_GENERIC && sparse && n_short > 0) {
+    if (fast_done && sparse && n_short > 0) {
         p.exc = short_idx;
         p.n_exc = (uint32_t)n_short;
         for (int k = 0; k < L.n_streams; ++k) p.exc_len[k] = short_len ? short_len[k] : nullptr;
@@ -562,10 +554,6 @@ int qd_destroy(qd_ctx* c) {
     (void)wait_all(c);
     qd_slots_destroy(c);
     free_table(c);
-    if (c->d_wq) (void)hipFree(c->d_wq);
-#ifdef QD_DEBUG_TIMES
-    if (c->d_dbg) (void)hipFree(c->d_dbg);
-#endif
     for (auto& t : c->tracked) (void)hipEventDestroy(t.second);
     c->tracked.clear();
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -654,11 +642,6 @@ int qd_set_option(qd_ctx* c, const char* name, int64_t value) {
         c->opt_force_generic = value != 0;
         return QD_OK;
     }
-    if (!strcmp(name, "work_queue")) {
-        if (value < 0 || value > 2) return fail(c, QD_ERR_INVALID, "work_queue must be 0 (automatic), 1 (always) or 2 (never)");
-        c->opt_work_queue = (int)value;
-        return QD_OK;
-    }
     if (!strcmp(name, "kernel")) {
         if (value < 0 || value > 2) return fail(c, QD_ERR_INVALID, "kernel must be 0 (automatic), 1 (fast) or 2 (generic)");
         c->opt_kernel = (int)value;
@@ -672,16 +655,6 @@ int qd_set_option(qd_ctx* c, const char* name, int64_t value) {
     return fail(c, QD_ERR_INVALID, std::string("unknown option ") + name);
 }
 
-#ifdef QD_DEBUG_TIMES
-// measurement builds only: {start, end (100 MHz wall clock), hardware id} of the workgroups of the last fast launch
-int qd_debug_times(qd_ctx* c, uint64_t* out, int64_t n_workgroups) {
-    if (!c || !out || !c->d_dbg || n_workgroups < 1 || n_workgroups > 65536) return QD_ERR_INVALID;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, wait_all(c));
-    HIPCHK(c, hipMemcpy(out, c->d_dbg, (size_t)n_workgroups * 3 * 8, hipMemcpyDeviceToHost));
-    return QD_OK;
-}
-#endif
 
 int qd_demux_device(qd_ctx* c, int64_t n, const qd_rows* rows, uint16_t* codes, uint8_t* mol, void* stream) {
     if (!c || !rows || n < 0) return fail(c, QD_ERR_INVALID, "bad arguments");

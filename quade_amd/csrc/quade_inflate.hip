@@ -649,6 +649,8 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
         // A window of the text (QD_INFLATE2_Q positions: a quarter by default) at a time: that many 16-bit parents lie in LDS beside the text.
         {
             constexpr uint32_t Q = QD_INFLATE2_Q;
+            static_assert(Q <= 65536, "the parents are 16-bit positions inside the window");
+            constexpr int MATCH_ROUNDS = 20;  // >= log2(Q) + 3: a chain of Q links is resolved in log2(Q) + 1 rounds
             // (volatile: a lane reads a parent's state, then -- only if that is final -- its byte; the two reads stay in that order,
             //  as the writes "byte, then final" of the lane that owns the parent do)
             volatile uint16_t* par = reinterpret_cast<volatile uint16_t*>(ow + 16384 + 4);
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
                 }
                 __syncthreads();
 #pragma unroll 1
-                for (int round = 0; round < 20; ++round) {
+                for (int round = 0; round < MATCH_ROUNDS; ++round) {
                     if (tid == 0) S.ctl[5] = 0;
                     __syncthreads();
                     uint32_t pending = 0;
@@ -690,6 +692,7 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
                     if (pending) S.ctl[5] = 1;
                     __syncthreads();
                     if (S.ctl[5] == 0) break;
+                    if (round == MATCH_ROUNDS - 1 && tid == 0) S.ctl[4] = 1;  // (chains halve every round: cannot happen; a block that did is not shipped)
                     __syncthreads();
                 }
             }

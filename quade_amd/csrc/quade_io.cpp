@@ -594,6 +594,8 @@ void finish_piece(qd_sink* s, OutFile* f, uint64_t seq, int64_t text_bytes, int6
 // deflater: one batch uploads and codes while the other's members come back) and the page-locked text buffers.
 // Pool jobs format a piece straight into such a buffer and queue it here; when no buffer is free the job codes its
 // piece on its own core as before -- the host and the device share the work by whoever is free.
+std::atomic<int64_t> g_test_deflate_fail_after{-1}, g_test_inflate_fail_after{-1};  // qd_io_set_option "test_*_fail_after" (tests only)
+
 class DeflateService {
   public:
     static constexpr size_t BUF_BYTES = (size_t)JOB_BYTES + (JOB_BYTES >> 2) + (256u << 10);  // a piece, its tags, slack
@@ -660,14 +662,8 @@ class DeflateService {
     void lane() {
         qd_deflater* def = nullptr;
         bool usable = qd_deflater_create && qd_deflater_run && qd_huffman_member_bound && qd_deflater_create(device_, &def) == QD_OK;
-        const char* fa = getenv("QUADE_TEST_DEFLATE_FAIL_AFTER");  // test hook: the device "fails" after this many batches
-        const int64_t fail_after = fa && *fa ? atoll(fa) : -1;
         int64_t batches = 0;
-        if (usable) {  // this lane's share now: a lane that is never idle would not get round to more later
-            add_slab(12);
-            add_slab(36);
-            add_slab();
-        }
+        if (usable) add_slab(12);  // a first small slab; more are made as pieces ask for them (want_slab_), up to MAX_BUFS
         for (;;) {
             std::vector<DevPiece> b;
             bool slab = false;
@@ -695,6 +691,7 @@ class DeflateService {
                 crc[i] = b[i].crc;
                 longest = std::max(longest, b[i].len);
             }
+            const int64_t fail_after = g_test_deflate_fail_after.load();  // test option: the device "fails" after this many batches of a lane
             bool ok = usable && !(fail_after >= 0 && batches >= fail_after);
             int64_t stride = 0;
             StageTimer lane_timer(ST_LANE);
@@ -1551,8 +1548,7 @@ void device_lane(qd_reader* r) {
     }
     // test hook: pretend the device fails once the reader has inflated this many runs on it (the fall-back to the
     // host pool in the middle of a file is otherwise unreachable without breaking a GPU)
-    const char* fa = getenv("QUADE_TEST_INFLATE_FAIL_AFTER");
-    const int64_t fail_after = fa && *fa ? atoll(fa) : -1;
+    const int64_t fail_after = g_test_inflate_fail_after.load();
     for (;;) {
         std::shared_ptr<BgzfRun> run;
         {
@@ -2042,6 +2038,8 @@ int qd_io_set_option(const char* name, int64_t value) {
     else if (n == "gunzip_chunk_bytes" && value >= (64 << 10)) g_pgz_chunk_bytes = value;
     else if (n == "gunzip_min_file_bytes" && value >= 0) g_pgz_min_file_bytes = value;
     else if (n == "gunzip_in_flight" && value >= 0 && value <= 256) g_pgz_in_flight = value;
+    else if (n == "test_deflate_fail_after") g_test_deflate_fail_after = value;
+    else if (n == "test_inflate_fail_after") g_test_inflate_fail_after = value;
     else if (n == "bgzf_in_flight" && value >= 1 && value <= 256) g_bgzf_in_flight = value;
     else if (n == "bgzf_device_lanes" && value >= 1 && value <= 16) g_bgzf_device_lanes = value;
     else if (n == "bgzf_device_run_bytes" && value >= (1 << 20) && value <= (16 << 20)) g_bgzf_device_run_bytes = value;

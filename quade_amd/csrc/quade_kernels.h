@@ -6,8 +6,6 @@
 #include <map>
 
 #define QD_CODE_UNDET 0xFFFFu
-#define QD_WQ_SET_WORDS (16 * 32) /* one counter set of the work queue: 16 x 128 bytes (9 used)                  */
-#define QD_WQ_SETS 64             /* ring of sets: one per launch in flight                                     */
 #define QD_MAX_KEY_BYTES 32
 
 #ifndef QD_FAST_BLOCK
@@ -31,17 +29,11 @@
 #ifndef QD_FAST_SMALL_BATCH
 #define QD_FAST_SMALL_BATCH (16ll << 20) /* pairs: at most this many -> 256-thread workgroups               */
 #endif
-#ifndef QD_GENERIC_BYTEWISE
-#define QD_GENERIC_BYTEWISE 0 /* A/B: the generic path's byte-at-a-time slice loops (r01)                   */
-#endif
 #ifndef QD_GENERIC_SPECIAL
 #define QD_GENERIC_SPECIAL 1 /* full-length batches on the generic path run its specialised forms (A/B: 0 = the catch-all) */
 #endif
 #ifndef QD_GENERIC_ALIGNED
 #define QD_GENERIC_ALIGNED 1 /* the specialised generic forms load 4- / 8-byte aligned slices without shifts (A/B: 0)       */
-#endif
-#ifndef QD_WIDE_CONFIRM_GLOBAL
-#define QD_WIDE_CONFIRM_GLOBAL 0 /* A/B: wide plans confirm a packed hit against the barcode's bytes in global memory (r02) instead of checking the key's alphabet in registers */
 #endif
 #ifndef QD_WIDE_PREFETCH
 #define QD_WIDE_PREFETCH 0 /* A/B: register double buffering for the static wide shapes */
@@ -60,12 +52,6 @@
 #endif
 #ifndef QD_FAST_CODE_STRIPS
 #define QD_FAST_CODE_STRIPS 1 /* with runs: codes leave through the wave's LDS strip, 16 B per lane          */
-#endif
-#ifndef QD_WORK_QUEUE
-#define QD_WORK_QUEUE 1 /* the persistent launch form deals wave runs out at run time (see demux_fast)        */
-#endif
-#ifndef QD_WQ_MAXTAKE
-#define QD_WQ_MAXTAKE 8 /* work queue: most runs a wave takes with one atomic (fewer at the end of the batch)       */
 #endif
 #ifndef QD_MOL_RUN_STRIPS
 #define QD_MOL_RUN_STRIPS 1 /* with runs: the molecular bytes of a whole run leave in one burst (else: per step)   */
@@ -138,11 +124,6 @@ struct DemuxParams {
     const uint32_t* gslots;
     uint32_t gmask, gseed;
     // exception pairs (reads shorter than their window) redone by demux_fixup after a fast launch
-    uint32_t* wq;  // work queue of the persistent launch form: 8 run counters + 1 exit counter, 128 bytes apart, zero at launch (the
-                   // last workgroup to leave zeroes them again); NULL = static split
-#ifdef QD_DEBUG_TIMES  // measurement builds only (tools/wg_times.py): per workgroup {start, end, hardware id}
-    uint64_t* dbg;
-#endif
     const uint32_t* exc;
     const uint8_t* exc_len[2];  // lengths of the exception pairs' reads, compact (NULL: taken from len[k][pair])
     uint32_t n_exc;

@@ -263,20 +263,14 @@ __device__ __forceinline__ uint32_t match_pair(const DemuxParams& p, const LdsTa
     klo = qd_fold8(klo);
     khi = qd_fold8(khi);
     // a4: exact match (Sample.py:65-67)
-#ifdef QD_ABLATE_PROBE  // timing-only build: no table probe (wrong results)
-    const uint32_t id = (uint32_t)(klo ^ khi) & 63u;
-#else
     const uint32_t id = probe_lds(t, klo, khi, (uint32_t)p.K, p.seed, p.slot_mask);
-#endif
     if (id == QD_CODE_UNDET) return QD_CODE_UNDET;
     // a5: min-phred gate over the barcode positions (Sample.py:70)
     uint32_t pass = qd_all_ge8(q1, p.thr);
     if (DUAL) pass &= qd_all_ge8(q2, p.thr);
     const uint32_t code = id * 2u + (pass ^ 1u);
     // a6: per-sample counters (Sample.py:71-72,79-80)
-#ifndef QD_ABLATE_HIST
     atomicAdd(&t.hist[code], 1u);
-#endif
     return code;
 }
 
@@ -295,8 +289,8 @@ __device__ __forceinline__ bool qd_bases8(u64 x, u64 mask) {
 // folded, nibble-packed and fused into a 16-byte key for the same LDS table probe.  The packing is injective on the
 // alphabet only ('Q' shares its low nibble with 'A'), so a packed hit proves equality only for a read whose key bytes are
 // all letters of the alphabet -- checked in registers (r03; before: a hit was confirmed against the barcode's own bytes in
-// global memory, one dependent L2 round trip per matched pair behind the tile's row loads; QD_WIDE_CONFIRM_GLOBAL=1
-// restores that form for A/B).  The table of a wide plan holds ACGTN-only barcodes (any other sends the plan to the generic
+// global memory, one dependent L2 round trip per matched pair behind the tile's row loads: profiles/r03_wide_alphabet_check.txt).
+// The table of a wide plan holds ACGTN-only barcodes (any other sends the plan to the generic
 // kernel), so a key with a foreign byte equals none of them.
 template <bool DUAL>
 __device__ __forceinline__ uint32_t match_pair_wide(const DemuxParams& p, const LdsTable& t, const u64 (&k1)[2],
@@ -313,19 +307,11 @@ __device__ __forceinline__ uint32_t match_pair_wide(const DemuxParams& p, const 
     u64 klo, khi;
     qd_wide_key(f1lo, f1hi, f2lo, f2hi, p.idx_w[0], &klo, &khi);
     // a4: packed lookup + what makes it exact
-#if QD_WIDE_CONFIRM_GLOBAL
-    const uint32_t id = probe_lds(t, klo, khi, (uint32_t)p.K, p.seed, p.slot_mask);
-    if (id == QD_CODE_UNDET) return QD_CODE_UNDET;
-    const ulong2* bv = reinterpret_cast<const ulong2*>(p.bkv) + 2 * (size_t)id;
-    const ulong2 b1 = bv[0], b2 = bv[1];
-    if (b1.x != f1lo || b1.y != f1hi || b2.x != f2lo || b2.y != f2hi) return QD_CODE_UNDET;
-#else
     bool letters = qd_bases8(f1lo, p.idx_mask[0]) && qd_bases8(f1hi, p.idx_mask_hi[0]);
     if (DUAL) letters = letters && qd_bases8(f2lo, p.idx_mask[1]) && qd_bases8(f2hi, p.idx_mask_hi[1]);
     if (!letters) return QD_CODE_UNDET;
     const uint32_t id = probe_lds(t, klo, khi, (uint32_t)p.K, p.seed, p.slot_mask);
     if (id == QD_CODE_UNDET) return QD_CODE_UNDET;
-#endif
     // a5: min-phred gate over the barcode positions
     uint32_t pass = qd_all_ge8(q1[0], p.thr) & qd_all_ge8(q1[1], p.thr);
     if (DUAL) pass &= qd_all_ge8(q2[0], p.thr) & qd_all_ge8(q2[1], p.thr);
@@ -1028,14 +1014,9 @@ struct RowsU {
 #else
 #define QD_FAST_BOUNDS __launch_bounds__(OPS::BLOCK)
 #endif
-// QUEUED: the persistent form whose waves draw their runs from the work queue (its own instantiation: both loops in
-// one kernel cost the static one 17 VGPRs and an occupancy step)
-template <class OPS, bool QUEUED>
+template <class OPS>
 __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
     DemuxParams p = p_in;
-#ifdef QD_DEBUG_TIMES
-    const uint64_t dbg_t0 = wall_clock64();
-#endif
     OPS::Shape::apply(p);  // a static shape overwrites the layout fields with its constants
     constexpr int BLOCK = OPS::BLOCK;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -1086,8 +1067,7 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
     const CodeOut direct{nullptr, 0, false};
     int64_t it = 0;
     TileT A, B;
-    constexpr bool queued = QD_WORK_QUEUE && QUEUED && RUNS > 0;
-    if (!queued && live(0)) OPS::template load<true>(A, p, base_of(0), tid);
+    if (live(0)) OPS::template load<true>(A, p, base_of(0), tid);
 
     // stage the table: global (L2) -> LDS, once per workgroup
     for (uint32_t i = tid; i <= p.slot_mask; i += BLOCK) slots[i] = p.slots[i];
@@ -1097,124 +1077,6 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
     const LdsTable t{slots, bk, hist, lds_raw + p.mol_strip_off};
 
     uint32_t undet = 0;
-#if QD_WORK_QUEUE
-    // ---- persistent grid, runs dealt out at run time (p.wq != nullptr; dual-index forms) ------------------------
-    // Measured on cfg3 with a truly persistent grid (tools/wg_times.py, profiles/r03_wg_times_*.txt): of the two
-    // workgroups that share a CU the OLDER one wins the arbitration -- it ends after 460 us, the younger after 640 --
-    // so with a static split the CU runs half empty for the last 28 %; an oversubscribed grid hides that behind
-    // workgroup turnover (7 % of the slot time idle, and a table image restaged per workgroup, which a large image
-    // cannot afford).  Here every WAVE draws its next wave runs (512 consecutive pairs each) from counters in
-    // global memory: one counter per XCD-sized shard (blockIdx & 7), blocks of 8 runs interleaved over the shards
-    // so that the chip still sweeps the arrays as one window; a wave takes up to 8 runs per atomic while plenty
-    // are left and single runs at the end (guided self-scheduling), asks for its next granule while it works on the
-    // last run of the current one, and helps the other shards out when its own is empty.  Whatever the arbitration
-    // does, every wave is busy until the batch is.
-    if constexpr (QUEUED && RUNS > 0) {
-        constexpr int R = RUNS > 0 ? RUNS : 1;
-        constexpr int64_t RUN_PAIRS = 128 * R;
-        const int64_t nrun = (OPS::GUARD_LAST ? (p.n >= 8 ? p.n - 8 : 0) : p.n) / RUN_PAIRS;  // full runs, dealt out below
-        const int64_t nblk = (nrun + 7) >> 3;                                                // blocks of 8 runs
-        const uint32_t lane = tid & 63u;
-        const int64_t wave_off = (int64_t)(tid >> 6) * 128;  // base + 2 * tid = run * 512 + step * 128 + 2 * lane
-        const uint32_t waves_per_shard = (gridDim.x * (BLOCK / 64) + 7) >> 3;
-        uint32_t shard = blockIdx.x & 7u, tried = 0;
-        auto shard_runs = [&](uint32_t x) -> uint32_t { return (uint32_t)(((nblk > x ? (nblk - 1 - x) / 8 + 1 : 0)) << 3); };
-        auto take_size = [&](uint32_t seen, uint32_t total) -> uint32_t {  // runs to ask for, given how far the shard was
-            const uint32_t left = total > seen ? total - seen : 0, k = left / (4 * waves_per_shard);
-            return k < 1 ? 1u : (k > QD_WQ_MAXTAKE ? (uint32_t)QD_WQ_MAXTAKE : k);
-        };
-        auto ask = [&](uint32_t x, uint32_t k) -> uint32_t {  // this wave's ticket: lane 0 adds, everybody learns
-            uint32_t v = 0;
-            if (lane == 0) v = atomicAdd(p.wq + x * 32, k);
-            return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-        };
-        uint32_t pend_k = take_size(0, shard_runs(shard)), pend_v = ask(shard, pend_k);  // in flight while the table is staged
-        uint32_t cur = 0, cur_end = 0;  // shard-local runs [cur, cur_end) in hand
-        // next run of this wave -> its global index, or -1 when every shard is empty
-        auto next_run = [&]() -> int64_t {
-            for (;;) {
-                if (cur < cur_end) {
-                    const uint32_t r = cur++;
-                    if (cur == cur_end) {  // the last run of the granule: ask for the next one now
-                        pend_k = take_size(cur_end, shard_runs(shard));
-                        pend_v = ask(shard, pend_k);
-                    }
-                    const int64_t g = ((int64_t)(r >> 3) * 8 + shard) * 8 + (r & 7);
-                    if (g < nrun) return g;
-                    continue;  // (only inside the batch's last block of 8)
-                }
-                const uint32_t total = shard_runs(shard);
-                if (pend_v < total) {
-                    cur = pend_v;
-                    cur_end = pend_v + pend_k < total ? pend_v + pend_k : total;
-                    if (cur_end - cur > 1) continue;  // (a single run asks for its successor above)
-                    continue;
-                }
-                if (++tried >= 8) return -1;  // this shard is empty: help the next one
-                shard = (shard + 1) & 7u;
-                pend_k = 1;  // a guest takes single runs: the shard is about as far as the one that just ran dry
-                pend_v = ask(shard, pend_k);
-            }
-        };
-        struct Pos {
-            int64_t base;
-            int step;
-        };
-        int64_t run = next_run();
-        auto pos_of = [&](int64_t g, int step) -> Pos { return Pos{g * RUN_PAIRS + (int64_t)step * 128 - wave_off, step}; };
-        auto advance = [&](Pos& ps) -> bool {  // the position after ps; false: nothing left
-            if (ps.step + 1 < R) {
-                ps = Pos{ps.base + 128, ps.step + 1};
-                return true;
-            }
-            run = next_run();
-            if (run < 0) return false;
-            ps = pos_of(run, 0);
-            return true;
-        };
-        auto out_at = [&](const Pos& ps) -> CodeOut { return CodeOut{code_strip, ps.step, ps.step == R - 1}; };
-        if (run >= 0) {
-            Pos pa = pos_of(run, 0), pb;
-            OPS::template load<true>(A, p, pa.base, tid);
-            if (OPS::PREFETCH) {
-                for (;;) {
-                    pb = pa;
-                    if (!advance(pb)) {
-                        undet += OPS::template compute<true, 6>(A, p, t, pa.base, tid, out_at(pa));
-                        break;
-                    }
-                    OPS::template load<true>(B, p, pb.base, tid);
-                    undet += OPS::template compute<true, 7>(A, p, t, pa.base, tid, out_at(pa));
-#ifdef QD_WQ_SLEEP  // experiment: idle cycles in the persistent form
-                    __builtin_amdgcn_s_sleep(QD_WQ_SLEEP);
-#endif
-                    pa = pb;
-                    if (!advance(pa)) {
-                        undet += OPS::template compute<true, 8>(B, p, t, pb.base, tid, out_at(pb));
-                        break;
-                    }
-                    OPS::template load<true>(A, p, pa.base, tid);
-                    undet += OPS::template compute<true, 9>(B, p, t, pb.base, tid, out_at(pb));
-#ifdef QD_WQ_SLEEP
-                    __builtin_amdgcn_s_sleep(QD_WQ_SLEEP);
-#endif
-                }
-            } else {
-                for (;;) {
-                    undet += OPS::template compute<true, 10>(A, p, t, pa.base, tid, out_at(pa));
-                    if (!advance(pa)) break;
-                    OPS::template load<true>(A, p, pa.base, tid);
-                }
-            }
-        }
-        // what no run covers: the last < 512 (+ 8) pairs of the batch, lane-guarded, by workgroup 0
-        if (blockIdx.x == 0)
-            for (int64_t base = nrun * RUN_PAIRS; base < p.n; base += TILE) {
-                OPS::template load<false>(A, p, base, tid);
-                undet += OPS::template compute<false, 11>(A, p, t, base, tid, direct);
-            }
-    } else
-#endif
     {
     // Register double buffering (tile k+1 in flight while tile k is matched) when a tile is 64 B per
     // lane; wider tiles run single-buffered.  Every "load next, then match current" pair is
@@ -1251,7 +1113,7 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
     }
     // what is left: the lane-guarded tiles at the end of the batch (at most two) and, with runs, the full
     // tiles behind the last whole super-tile
-    for (int64_t last = queued ? ntiles : (RUNS ? nunits * RUNS : nfull); last < ntiles; ++last) {
+    for (int64_t last = RUNS ? nunits * RUNS : nfull; last < ntiles; ++last) {
         if ((int64_t)blockIdx.x != last % G) continue;
         OPS::template load<false>(A, p, last * TILE, tid);
         undet += OPS::template compute<false, 5>(A, p, t, last * TILE, tid, direct);
@@ -1267,414 +1129,9 @@ __global__ QD_FAST_BOUNDS void demux_fast(const DemuxParams p_in) {
     // molecular-index config flushes ~3 M of them; the host folds the rows into 64-bit totals before any
     // row counter could pass 2^32, see fold_rows() in quade_api.cpp)
     qd_row_t* row = p.partial + (size_t)(blockIdx.x % p.partial_rows) * p.cnt_stride;
-#ifndef QD_ABLATE_FLUSH
     for (uint32_t i = tid; i < 2 * S + 1; i += BLOCK) {
         const uint32_t v = hist[i];
         if (v) atomicAdd(&row[i], (qd_row_t)v);
-    }
-#endif
-#if QD_WORK_QUEUE
-    // the workgroup that leaves last puts the queue's counters back to zero for the launch that uses this set next
-    // (no wave of this launch asks again: every workgroup passed its last barrier above before it ticks `done`)
-    if (QUEUED && RUNS > 0 && tid == 0) {
-        __threadfence();
-        if (atomicAdd(p.wq + 8 * 32, 1u) == gridDim.x - 1) {
-#pragma unroll
-            for (int x = 0; x < 9; ++x) __hip_atomic_store(p.wq + x * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-#endif
-#ifdef QD_DEBUG_TIMES
-    if (p.dbg && tid == 0 && blockIdx.x < 65536) {
-        uint32_t hw = 0, xcc = 0;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        p.dbg[3 * blockIdx.x] = dbg_t0;
-        p.dbg[3 * blockIdx.x + 1] = wall_clock64();
-        p.dbg[3 * blockIdx.x + 2] = (uint64_t)hw | ((uint64_t)xcc << 32);
-    }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// Generic path: one pair per lane, byte-granular, per-read lengths honoured (Python slice clamping
-// of a short index read: src/Quade.py:217-218 on a read shorter than `end`).  generic_pair() is the
-// whole of it for one pair; it serves the generic kernel (any plan inside the envelope) and the
-// exception pairs (short reads) redone after a fast launch.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-// nbytes (0..32, per lane) bytes at p (any alignment) -> little-endian words w[0..3], zero padded.  wmax = the
-// wave-uniform upper bound of nbytes (the slice width of the plan; nbytes is smaller only for a short read).
-// Aligned dword loads, and NO per-lane branches around them: the number of loads follows from wmax alone
-// (a scalar condition), a lane that needs fewer words re-reads its last needed word instead of skipping --
-// with a guard per load every load sat in its own exec-masked block and their latencies added up (~10 us
-// per pair and lane).  No word is read that holds no byte of the lane's slice, so the end of an array is
-// passed by at most the 1-3 bytes that share a word (and a page) with its last byte.
-template <int NW>  // NW 64-bit words of output: nbytes, wmax <= 8 * NW
-__device__ __forceinline__ void load_bytes(const uint8_t* p, int nbytes, int wmax, u64 (&w)[NW]) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
-    const int sh = (int)(a & 3), need = sh + nbytes;
-    const int ju = wmax > 0 ? (wmax + 6) >> 2 : 0;    // dwords that can hold 3 + wmax bytes (uniform)
-    const int jl = need > 0 ? (need - 1) >> 2 : 0;    // the lane's last needed dword
-    uint32_t d[2 * NW + 1];
-#pragma unroll
-    for (int j = 0; j < 2 * NW + 1; ++j) d[j] = (j < ju) ? q[j < jl ? j : jl] : 0u;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        const u64 lo = (u64)d[2 * i] | ((u64)d[2 * i + 1] << 32), nx = d[2 * i + 2];
-        const u64 v = sh ? (lo >> (8 * sh)) | (nx << (64 - 8 * sh)) : lo;
-        const int left = nbytes - 8 * i;  // wanted bytes of this word
-        w[i] = left >= 8 ? v : (left <= 0 ? 0 : v & ((1ull << (8 * left)) - 1));
-    }
-}
-
-// w |= v << (8 * off) over the 64 * NW bits (off = 0 .. 8 * NW bytes; what leaves the top is dropped)
-template <int NW>
-__device__ __forceinline__ void or_shifted(u64 (&w)[NW], const u64 (&v)[NW], int off) {
-    const int ws = off >> 3, bs = (off & 7) * 8;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        u64 cur = 0, prev = 0;
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            cur = (j == i - ws) ? v[j] : cur;
-            prev = (j == i - ws - 1) ? v[j] : prev;
-        }
-        w[i] |= bs ? (cur << bs) | (prev >> (64 - bs)) : cur;
-    }
-}
-
-// Writes codes[r] (and mol[r]); returns the routing code.  Counters are the caller's business.
-// len0 / len1: the reads' lengths (0x7FFFFFFF = covers its window).
-__device__ __forceinline__ uint32_t generic_pair(const DemuxParams& p, int64_t r, int len0, int len1) {
-    // slice lengths after clamping to the read length
-    int a[2] = {0, 0}, ma[2] = {0, 0};
-    const uint8_t* srow[2] = {nullptr, nullptr};
-    const uint8_t* qrow[2] = {nullptr, nullptr};
-    for (int k = 0; k < p.n_streams; ++k) {
-        const int len = k ? len1 : len0;
-        // columns [start, min(end, len)) -> bytes available
-        a[k] = clampi((p.idx_col[k] + p.idx_w[k] < len ? p.idx_col[k] + p.idx_w[k] : len) - p.idx_col[k], 0, p.idx_w[k]);
-        ma[k] = clampi((p.mol_col[k] + p.mol_w[k] < len ? p.mol_col[k] + p.mol_w[k] : len) - p.mol_col[k], 0, p.mol_w[k]);
-        srow[k] = p.seq[k] + r * p.seq_stride[k];
-        qrow[k] = p.qual[k] + r * p.qual_stride[k];
-    }
-    const int klen = a[0] + a[1];
-    // canonical key: fused bytes, little-endian packed, zero padded
-    u64 w[QD_KEY_WORDS] = {0, 0, 0, 0};
-    uint32_t pass = 1;
-#if QD_GENERIC_BYTEWISE  // the r01 form: one global byte load per key byte and per quality byte
-#pragma unroll
-    for (int i = 0; i < QD_MAX_KEY_BYTES; ++i) {
-        if (i < klen) {
-            uint8_t b, q;
-            if (i < a[0]) {
-                b = srow[0][p.idx_off[0] + i];
-                q = qrow[0][i];
-            } else {
-                b = srow[1][p.idx_off[1] + (i - a[0])];
-                q = qrow[1][i - a[0]];
-            }
-            if (b >= 'a' && b <= 'z') b -= 0x20;      // a3
-            w[i >> 3] |= (u64)b << (8 * (i & 7));
-            pass &= (q >= p.thr) ? 1u : 0u;            // a5
-        }
-    }
-#else
-    // slices as words: aligned dword loads + byte shifts, SWAR fold (a3) and gate (a5) as in the fast kernels
-    {
-        int at = 0;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (k >= p.n_streams) break;
-            u64 v[4], qv[4];
-            load_bytes<4>(srow[k] + p.idx_off[k], a[k], p.idx_w[k], v);
-            load_bytes<4>(qrow[k], a[k], p.idx_w[k], qv);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i] = qd_fold8(v[i]);
-                const int left = a[k] - 8 * i;  // quality bytes of this word that count; the others read as 0xFF
-                pass &= qd_all_ge8(left >= 8 ? qv[i] : (left <= 0 ? ~0ull : qv[i] | (~0ull << (8 * left))), p.thr);
-            }
-            or_shifted<4>(w, v, at);
-            at += a[k];
-        }
-    }
-#endif
-    // a4: probe the global table of every barcode
-    uint32_t code = QD_CODE_UNDET;
-    if (klen <= QD_MAX_KEY_BYTES) {
-        const uint32_t h = qd_hash_key(w, (uint32_t)klen, p.gseed);
-        const uint32_t fp = h >> 16;
-        uint32_t s = h & p.gmask;
-        for (;;) {
-            const uint32_t e = p.gslots[s];
-            if (e == QD_EMPTY_SLOT) break;
-            if ((e >> 16) == fp) {
-                const uint32_t id = e & 0xFFFFu;
-                const u64* b = p.bk32 + (size_t)id * QD_KEY_WORDS;
-                if (p.blen[id] == (uint8_t)klen && b[0] == w[0] && b[1] == w[1] && b[2] == w[2] && b[3] == w[3]) {
-                    code = id * 2u + (pass ^ 1u);
-                    break;
-                }
-            }
-            s = (s + 1) & p.gmask;
-        }
-    }
-    p.codes[r] = (uint16_t)code;
-    // a2: molecular bytes, I1 part then I2 part, zero padded to M
-    if (p.M > 0) {
-        uint8_t* d = p.mol + r * p.M;
-        if (QD_GENERIC_BYTEWISE || p.M > 32) {  // molecular slices may be as wide as the window (64 B each): bytes
-            int o = 0;
-            for (int k = 0; k < p.n_streams; ++k)
-                for (int i = 0; i < ma[k]; ++i) d[o++] = srow[k][p.mol_off[k] + i];
-            for (; o < p.M; ++o) d[o] = 0;
-            return code;
-        }
-        u64 m[4] = {0, 0, 0, 0};
-        int at = 0;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (k >= p.n_streams) break;
-            u64 v[4];
-            load_bytes<4>(srow[k] + p.mol_off[k], ma[k], p.mol_w[k], v);
-            or_shifted<4>(m, v, at);
-            at += ma[k];
-        }
-        if ((p.M & 3) == 0) {  // r * M is a multiple of 4 then: dword stores
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (4 * j < p.M) reinterpret_cast<uint32_t*>(d)[j] = (uint32_t)(m[j >> 1] >> (32 * (j & 1)));
-        } else {
-#pragma unroll
-            for (int o = 0; o < 32; ++o)
-                if (o < p.M) d[o] = (uint8_t)(m[o >> 3] >> (8 * (o & 7)));
-        }
-    }
-    return code;
-}
-
-// lengths from the per-pair len rows (absent: every read covers its window)
-__device__ __forceinline__ uint32_t generic_pair(const DemuxParams& p, int64_t r) {
-    return generic_pair(p, r, p.len[0] ? (int)p.len[0][r] : 0x7FFFFFFF, p.len[1] ? (int)p.len[1][r] : 0x7FFFFFFF);
-}
-
-// ---- the generic path specialised by what a plan fixes for a whole launch --------------------------------------
-// Every read covers its window (no len rows), NS index reads, keys of at most 8 * KW bytes, molecular bytes of at
-// most 8 * MWORDS (0: none).  Same steps as generic_pair(); what changes is what the compiler knows: the word
-// arrays have the size the plan needs (a 16-byte key is two words, not four), the slice widths are wave-uniform (no
-// per-lane clamping), and the stream loop has a constant bound -- the catch-all keeps ~160 scalars alive and spills
-// them through VGPR lanes (158 SGPR spills, 942 VALU per pair).
-// A slice whose address is a multiple of ALIGN (4 or 8) for EVERY pair of the launch -- every stride and offset of the
-// plan is: no shift, no spare word, and 8-byte loads where the plan allows them (the one-pair-per-lane kernels are bound
-// by the number of vector memory instructions: three dword loads per 8-byte slice, each using half of the lines it
-// touches, against one).  nbytes (wave-uniform) <= 8 * NW; bytes beyond it read as zero.
-template <int NW, int ALIGN>
-__device__ __forceinline__ void load_aligned(const uint8_t* p, int nbytes, u64 (&w)[NW]) {
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        const int left = nbytes - 8 * i;  // wanted bytes of this word
-        u64 v = 0;
-        if (left > 0) {
-            if (ALIGN >= 8) {
-                v = *reinterpret_cast<const u64*>(p + 8 * i);  // (may read up to 7 bytes behind the slice, inside its aligned word)
-            } else {
-                v = *reinterpret_cast<const uint32_t*>(p + 8 * i);
-                if (left > 4) v |= (u64) * reinterpret_cast<const uint32_t*>(p + 8 * i + 4) << 32;
-            }
-            if (left < 8) v &= (1ull << (8 * left)) - 1;
-        }
-        w[i] = v;
-    }
-}
-template <int NW, int ALIGN>
-__device__ __forceinline__ void load_slice(const uint8_t* p, int nbytes, u64 (&w)[NW]) {
-    if (ALIGN >= 4)
-        load_aligned<NW, ALIGN>(p, nbytes, w);
-    else
-        load_bytes<NW>(p, nbytes, nbytes, w);
-}
-
-// tslots / tkeys / tlens: the table of every barcode -- in global memory (keys QD_KEY_WORDS words apart) or, LT, the workgroup's
-// copy in LDS (keys KW words apart)
-template <int NS, int KW, int MWORDS, int ALIGN, bool LT>
-__device__ __forceinline__ uint32_t special_pair(const DemuxParams& p, int64_t r, const uint32_t* tslots, const u64* tkeys,
-                                                 const uint8_t* tlens) {
-    u64 w[KW];
-#pragma unroll
-    for (int i = 0; i < KW; ++i) w[i] = 0;
-    uint32_t pass = 1;
-    int at = 0;
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        const int iw = p.idx_w[k];
-        u64 v[KW], qv[KW];
-        load_slice<KW, ALIGN>(p.seq[k] + r * p.seq_stride[k] + p.idx_off[k], iw, v);
-        load_slice<KW, ALIGN>(p.qual[k] + r * p.qual_stride[k], iw, qv);
-#pragma unroll
-        for (int i = 0; i < KW; ++i) {
-            v[i] = qd_fold8(v[i]);                                                    // a3
-            const int left = iw - 8 * i;  // quality bytes of this word that count; the others read as 0xFF
-            pass &= qd_all_ge8(left >= 8 ? qv[i] : (left <= 0 ? ~0ull : qv[i] | (~0ull << (8 * left))), p.thr);  // a5
-        }
-        or_shifted<KW>(w, v, at);                                                     // a1
-        at += iw;
-    }
-    // a4: the table of every barcode (a K-long key can only equal a K-long barcode)
-    uint32_t code = QD_CODE_UNDET;
-    {
-        uint32_t h = qd_hash_init((uint32_t)at, p.gseed);
-#pragma unroll
-        for (int i = 0; i < KW; ++i)
-            if (8 * i < at) h = qd_hash_step(h, w[i]);
-        h = qd_hash_fini(h);
-        const uint32_t fp = h >> 16;
-        uint32_t s = h & p.gmask;
-        for (;;) {
-            const uint32_t e = tslots[s];
-            if (e == QD_EMPTY_SLOT) break;
-            if ((e >> 16) == fp) {
-                const uint32_t id = e & 0xFFFFu;
-                const u64* b = tkeys + (size_t)id * (LT ? KW : QD_KEY_WORDS);
-                bool same = tlens[id] == (uint8_t)at;
-#pragma unroll
-                for (int i = 0; i < KW; ++i) same = same && b[i] == w[i];
-                if (same) {
-                    code = id * 2u + (pass ^ 1u);
-                    break;
-                }
-            }
-            s = (s + 1) & p.gmask;
-        }
-    }
-    p.codes[r] = (uint16_t)code;
-    if (MWORDS > 0) {  // a2: molecular bytes, I1 part then I2 part
-        constexpr int MW_ = MWORDS > 0 ? MWORDS : 1;
-        u64 m[MW_];
-#pragma unroll
-        for (int i = 0; i < MW_; ++i) m[i] = 0;
-        int mat = 0;
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            u64 v[MW_];
-            load_slice<MW_, ALIGN>(p.seq[k] + r * p.seq_stride[k] + p.mol_off[k], p.mol_w[k], v);
-            or_shifted<MW_>(m, v, mat);
-            mat += p.mol_w[k];
-        }
-        uint8_t* d = p.mol + r * p.M;
-        if ((p.M & 3) == 0) {
-#pragma unroll
-            for (int j = 0; j < 2 * MW_; ++j)
-                if (4 * j < p.M) reinterpret_cast<uint32_t*>(d)[j] = (uint32_t)(m[j >> 1] >> (32 * (j & 1)));
-        } else {
-#pragma unroll
-            for (int o = 0; o < 8 * MW_; ++o)
-                if (o < p.M) d[o] = (uint8_t)(m[o >> 3] >> (8 * (o & 7)));
-        }
-    }
-    return code;
-}
-
-// LT: the workgroup stages the table of every barcode in LDS behind its histogram (slots | keys, KW words each | lengths) and
-// probes it there: the two dependent trips to global memory per pair (slot, then key) were most of what the one-pair-per-lane
-// kernels waited for; the launcher picks it while the copy is small (a few workgroups per CU must still fit).
-template <int NS, int KW, int MWORDS, int ALIGN, bool LT>
-__global__ __launch_bounds__(QD_GEN_BLOCK) void demux_special(const DemuxParams p, uint32_t hist_entries) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw);
-    const int64_t stride = (int64_t)gridDim.x * QD_GEN_BLOCK;
-    const uint32_t S = p.n_samples;
-    qd_row_t* row = p.partial + (size_t)(blockIdx.x % p.partial_rows) * p.cnt_stride;
-    for (uint32_t i = threadIdx.x; i < hist_entries; i += QD_GEN_BLOCK) hist[i] = 0;
-    const uint32_t* tslots = p.gslots;
-    const u64* tkeys = p.bk32;
-    const uint8_t* tlens = p.blen;
-    if (LT) {
-        uint32_t* ls = reinterpret_cast<uint32_t*>(lds_raw + (((size_t)hist_entries * 4 + 15) & ~(size_t)15));
-        u64* lk = reinterpret_cast<u64*>(ls + (p.gmask + 1));
-        uint8_t* ll = reinterpret_cast<uint8_t*>(lk + (size_t)S * KW);
-        for (uint32_t i = threadIdx.x; i <= p.gmask; i += QD_GEN_BLOCK) ls[i] = p.gslots[i];
-        for (uint32_t i = threadIdx.x; i < S * KW; i += QD_GEN_BLOCK) lk[i] = p.bk32[(size_t)(i / KW) * QD_KEY_WORDS + (i % KW)];
-        for (uint32_t i = threadIdx.x; i < S; i += QD_GEN_BLOCK) ll[i] = p.blen[i];
-        tslots = ls;
-        tkeys = lk;
-        tlens = ll;
-    }
-    if (hist_entries || LT) __syncthreads();
-    uint32_t undet = 0;
-    for (int64_t r = (int64_t)blockIdx.x * QD_GEN_BLOCK + threadIdx.x; r < p.n; r += stride) {
-        const uint32_t code = special_pair<NS, KW, MWORDS, ALIGN, LT>(p, r, tslots, tkeys, tlens);
-        if (code == QD_CODE_UNDET)
-            ++undet;
-        else if (hist_entries)
-            atomicAdd(&hist[code], 1u);
-        else
-            atomicAdd(&row[code], (qd_row_t)1);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) undet += __shfl_xor(undet, o, 64);
-    if ((threadIdx.x & 63) == 0 && undet) atomicAdd(&row[2 * S], (qd_row_t)undet);
-    if (hist_entries) {
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < hist_entries; i += QD_GEN_BLOCK) {
-            const uint32_t v = hist[i];
-            if (v) atomicAdd(&row[i], (qd_row_t)v);
-        }
-    }
-}
-
-// hist_entries = 2S+1 when the per-sample counters fit the workgroup's LDS (dynamic, 4 B each): one LDS
-// add per matched pair and one global add per non-zero counter per workgroup; 0 for sample tables too
-// large for that (global 64-bit adds per pair, as before).
-__global__ __launch_bounds__(QD_GEN_BLOCK) void demux_generic(const DemuxParams p, uint32_t hist_entries) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw);
-    const int64_t stride = (int64_t)gridDim.x * QD_GEN_BLOCK;
-    const uint32_t S = p.n_samples;
-    qd_row_t* row = p.partial + (size_t)(blockIdx.x % p.partial_rows) * p.cnt_stride;
-    for (uint32_t i = threadIdx.x; i < hist_entries; i += QD_GEN_BLOCK) hist[i] = 0;
-    if (hist_entries) __syncthreads();
-    uint32_t undet = 0;
-    for (int64_t r = (int64_t)blockIdx.x * QD_GEN_BLOCK + threadIdx.x; r < p.n; r += stride) {
-        const uint32_t code = generic_pair(p, r);
-        if (code == QD_CODE_UNDET)
-            ++undet;
-        else if (hist_entries)
-            atomicAdd(&hist[code], 1u);
-        else
-            atomicAdd(&row[code], (qd_row_t)1);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) undet += __shfl_xor(undet, o, 64);
-    if ((threadIdx.x & 63) == 0 && undet) atomicAdd(&row[2 * S], (qd_row_t)undet);
-    if (hist_entries) {
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < hist_entries; i += QD_GEN_BLOCK) {
-            const uint32_t v = hist[i];
-            if (v) atomicAdd(&row[i], (qd_row_t)v);
-        }
-    }
-}
-
-// Exception pairs after a fast launch on the same stream: the reads of p.exc[0..n_exc) (unique pair
-// indices) are shorter than their window, so the fast kernel matched their zero-padded rows; redo
-// them with the generic semantics and move one count from the old code's counter to the new one.
-__global__ __launch_bounds__(QD_GEN_BLOCK) void demux_fixup(const DemuxParams p) {
-    const uint32_t S = p.n_samples;
-    u64* row = p.adjust;  // signed moves go to the 64-bit totals (a -1 in a 32-bit row of its own would not cancel)
-    for (uint32_t i = blockIdx.x * QD_GEN_BLOCK + threadIdx.x; i < p.n_exc; i += gridDim.x * QD_GEN_BLOCK) {
-        const int64_t r = p.exc[i];
-        if (r >= p.n) continue;
-        const uint32_t old = p.codes[r];
-        const uint32_t code = p.exc_len[0] ? generic_pair(p, r, p.exc_len[0][i], p.exc_len[1] ? (int)p.exc_len[1][i] : 0x7FFFFFFF)
-                                           : generic_pair(p, r);
-        if (code != old) {
-            atomicAdd(reinterpret_cast<unsigned long long*>(&row[old == QD_CODE_UNDET ? 2 * S : old]), ~0ull);  // -1
-            atomicAdd(reinterpret_cast<unsigned long long*>(&row[code == QD_CODE_UNDET ? 2 * S : code]), 1ull);
-        }
     }
 }
 
@@ -1699,8 +1156,7 @@ template <class OPS>
 hipError_t launch_fast_t(const DemuxParams& p_launch, QdKernelCache& cache, int cus, int wg_per_cu, size_t table_lds, size_t strip_bytes_per_wave,
                          hipStream_t st) {
     constexpr int BLOCK = OPS::BLOCK;
-    const bool queued = QD_WORK_QUEUE && OPS::RUNS > 0 && p_launch.wq;
-    auto k = queued ? demux_fast<OPS, (QD_WORK_QUEUE && OPS::RUNS > 0)> : demux_fast<OPS, false>;
+    auto k = demux_fast<OPS>;
     // dynamic LDS: table image + histogram | molecular strips (per wave: one step's 128 x M bytes, or a whole run's
     // with QD_MOL_RUN_STRIPS while two workgroups of this size still fit a CU) | code strips
     size_t lds = table_lds;
@@ -1746,11 +1202,8 @@ hipError_t launch_fast_t(const DemuxParams& p_launch, QdKernelCache& cache, int 
     //  * large table image: a persistent grid of at most 2 co-resident workgroups per CU (staging
     //    tens of KB and flushing thousands of counters per workgroup is not free).
     int64_t grid;
-    if (!queued) p.wq = nullptr;
     if (wg_per_cu > 0) {
         grid = (int64_t)cus * wg_per_cu;
-    } else if (queued) {
-        grid = (int64_t)cus * occ_blocks;  // the resident set: every wave draws its runs from the queue
     } else if (table_lds > 24 * 1024) {
         // two rounds of the resident set: of two workgroups that share a CU the older one wins the arbitration and ends
         // early (profiles/r03_wg_times_cfg3_persistent2.txt); a second round fills the slots it leaves, and restaging a
@@ -1872,68 +1325,6 @@ hipError_t qd_launch_fast(const DemuxParams& p, QdKernelCache& cache, int cus, i
     if (block == 1024) return launch_fast_b<1024>(p, cache, cus, wg_per_cu, lds_bytes, strip_bytes_per_wave, st);
     if (block == 256) return launch_fast_b<256>(p, cache, cus, wg_per_cu, lds_bytes, strip_bytes_per_wave, st);
     return launch_fast_b<512>(p, cache, cus, wg_per_cu, lds_bytes, strip_bytes_per_wave, st);
-}
-
-namespace {
-template <int NS, int KW, int ALIGN, bool LT>
-void launch_special_t(const DemuxParams& p, int grid, size_t lds, uint32_t entries, hipStream_t st) {
-    if (p.M == 0) hipLaunchKernelGGL((demux_special<NS, KW, 0, ALIGN, LT>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
-    else if (p.M <= 16) hipLaunchKernelGGL((demux_special<NS, KW, 2, ALIGN, LT>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
-    else hipLaunchKernelGGL((demux_special<NS, KW, 4, ALIGN, LT>), dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
-}
-template <int NS, int KW, int ALIGN>
-void launch_special_a(const DemuxParams& p, int grid, size_t lds, uint32_t entries, hipStream_t st) {
-    // the table in LDS while histogram + slots + keys + lengths stay within QD_GENERIC_LDS_TABLE bytes (needs the histogram there too)
-    const size_t tbl = (((size_t)entries * 4 + 15) & ~(size_t)15) + ((size_t)p.gmask + 1) * 4 + (size_t)p.n_samples * KW * 8 + p.n_samples;
-    if (QD_GENERIC_LDS_TABLE && entries && tbl <= (size_t)QD_GENERIC_LDS_TABLE) launch_special_t<NS, KW, ALIGN, true>(p, grid, (tbl + 15) & ~(size_t)15, entries, st);
-    else launch_special_t<NS, KW, ALIGN, false>(p, grid, lds, entries, st);
-}
-// what every slice address of the launch is a multiple of: 8, 4 or nothing in particular (row arrays are 16-byte aligned)
-int slice_alignment(const DemuxParams& p) {
-    int a = 8;
-    for (int k = 0; k < p.n_streams; ++k) {
-        const int v[5] = {p.seq_stride[k], p.qual_stride[k], p.idx_w[k] ? p.idx_off[k] : 0, p.mol_w[k] ? p.mol_off[k] : 0, 0};
-        for (int x : v)
-            while (a > 1 && x % a) a >>= 1;
-    }
-    return a >= 4 ? a : 1;
-}
-template <int NS, int KW>
-void launch_special_m(const DemuxParams& p, int grid, size_t lds, uint32_t entries, hipStream_t st) {
-    const int a = QD_GENERIC_ALIGNED ? slice_alignment(p) : 1;
-    if (a == 8) launch_special_a<NS, KW, 8>(p, grid, lds, entries, st);
-    else if (a == 4) launch_special_a<NS, KW, 4>(p, grid, lds, entries, st);
-    else launch_special_a<NS, KW, 1>(p, grid, lds, entries, st);
-}
-}  // namespace
-
-hipError_t qd_launch_generic(const DemuxParams& p, int grid, hipStream_t st) {
-    const uint32_t entries = 2 * p.n_samples + 1 <= 16000 ? 2 * p.n_samples + 1 : 0;  // <= 64 KB of LDS (the default limit)
-    const size_t lds = (size_t)entries * 4;
-    // every read covers its window and the plan fits the specialised forms (key <= 32 bytes -- always --, at most 16 /
-    // 32 key and 32 molecular bytes, every slice inside the words of its form): NS x KW x molecular words
-    bool special = QD_GENERIC_SPECIAL && !p.len[0] && !p.len[1] && p.M <= 32 && p.K <= 32;
-    const int kw = p.K <= 16 ? 2 : 4, mwords = p.M == 0 ? 0 : (p.M <= 16 ? 2 : 4);
-    for (int k = 0; k < p.n_streams; ++k) special = special && p.idx_w[k] <= 8 * kw && p.mol_w[k] <= 8 * (mwords ? mwords : 1);
-    if (special) {
-        if (p.n_streams == 1) {
-            if (kw == 2) launch_special_m<1, 2>(p, grid, lds, entries, st);
-            else launch_special_m<1, 4>(p, grid, lds, entries, st);
-        } else {
-            if (kw == 2) launch_special_m<2, 2>(p, grid, lds, entries, st);
-            else launch_special_m<2, 4>(p, grid, lds, entries, st);
-        }
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(demux_generic, dim3(grid), dim3(QD_GEN_BLOCK), lds, st, p, entries);
-    return hipGetLastError();
-}
-
-hipError_t qd_launch_fixup(const DemuxParams& p, hipStream_t st) {
-    if (p.n_exc == 0) return hipSuccess;
-    const unsigned grid = (p.n_exc + QD_GEN_BLOCK - 1) / QD_GEN_BLOCK;
-    hipLaunchKernelGGL(demux_fixup, dim3(grid > 1024 ? 1024 : grid), dim3(QD_GEN_BLOCK), 0, st, p);
-    return hipGetLastError();
 }
 
 // out[0..ncnt) = base[0..ncnt) + the sum of the partial rows (out == base: the rows are added in place)

@@ -1,5 +1,5 @@
 // Host-buffer entry points over the device text stages (quade_text.hip): what qd_pipe_run chains on the device, one stage
-// at a time, for bindings that hold text in host memory and for the tests (each stage against the CPU oracle).
+// at a time, for bindings that hold text in host memory and for the tests (each stage on its own).
 #include <hip/hip_runtime.h>
 
 #include <cstring>

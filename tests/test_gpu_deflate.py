@@ -143,7 +143,7 @@ def _unzip_dir(d):
 
 
 @pytest.mark.parametrize("fail_after,level", [(None, -1), ("1", -1), (None, 1), ("1", 1)])
-def test_cli_with_device_deflate_writes_the_same_files(tmp_path, monkeypatch, fail_after, level):
+def test_cli_with_device_deflate_writes_the_same_files(tmp_path, fail_after, level, request):
     """`[gpu] gzip_level : -1` (or 1) + `device_deflate : True` through the command line driver: same decompressed files and
     report as with the host's coder, and the GPU really made members.  fail_after: the device "fails" after its
     first batch (test hook) -- the pieces already queued and all later ones are coded by the host, nothing is lost."""
@@ -153,12 +153,13 @@ def test_cli_with_device_deflate_writes_the_same_files(tmp_path, monkeypatch, fa
     work = str(tmp_path)
     # (level 1 without the failure: records with binned qualities -- long runs, matches across quality lines -- the others uniform ones)
     paths, bcs = synth.write_fastq_dataset(work, 120_000, n_samples=24, qualities="binned" if (level == 1 and not fail_after) else "uniform")
-    if fail_after:
-        monkeypatch.setenv("QUADE_TEST_DEFLATE_FAIL_AFTER", fail_after)
+    from quade_amd import hip_backend as hb
+    assert hb.load_library().qd_io_set_option(b"test_deflate_fail_after", int(fail_after) if fail_after else -1) == hb.QD_OK
+    request.addfinalizer(lambda: hb.load_library().qd_io_set_option(b"test_deflate_fail_after", -1))
     outs = {}
     for mode in ("False", "True"):
         conf = os.path.join(work, "conf_%s.txt" % mode)
-        synth.write_conf(conf, paths, bcs, 2, gpu="[gpu]\nbatch_pairs : 50000\ngzip_level : %d\ndevice_deflate : %s\n" % (level, mode))
+        synth.write_conf(conf, paths, bcs, 2, gpu="[gpu]\nbatch_pairs : 50000\ngzip_level : %d\ndevice_deflate : %s\ndevice_pipeline : False\n" % (level, mode))
         out = os.path.join(work, "out_" + mode)
         os.mkdir(out)
         cwd = os.getcwd()

@@ -140,7 +140,7 @@ def test_reader_with_device_inflate_equals_host_reader(tmp_path):
         assert got[-1][2][0] == 0 and got[0][2][0] > 0, got[0][2]   # the device really took runs
 
 
-def test_reader_survives_a_device_that_fails_mid_file(tmp_path, monkeypatch):
+def test_reader_survives_a_device_that_fails_mid_file(tmp_path, request):
     """once the device lanes give up (`dev_failed`), the run under construction may already hold one of the
     reader's page-locked buffers; it must go to the host pool with ordinary memory, not with an empty `out`.  The
     hook makes every device run after the first fail like a HIP error would."""
@@ -154,7 +154,8 @@ def test_reader_survives_a_device_that_fails_mid_file(tmp_path, monkeypatch):
     src = np.frombuffer(text, dtype=np.uint8)
     bg = str(tmp_path / "b.fastq.gz")
     assert lib.qd_write_gzip_file(bg.encode(), hb._ptr(src), len(src), 1, -1) == hb.QD_OK
-    monkeypatch.setenv("QUADE_TEST_INFLATE_FAIL_AFTER", "1")
+    assert lib.qd_io_set_option(b"test_inflate_fail_after", 1) == hb.QD_OK
+    request.addfinalizer(lambda: lib.qd_io_set_option(b"test_inflate_fail_after", -1))
     st = FastqStream(bg, 200_000, inflate_device=0)
     chunks, n = [], 0
     while True:
@@ -182,7 +183,7 @@ def test_cli_run_with_device_inflate_equals_host_inflate(tmp_path):
     outs = {}
     for mode in ("False", "True"):
         conf = os.path.join(work, "conf_%s.txt" % mode)
-        synth.write_conf(conf, paths, bcs, 2, gpu="[gpu]\nbatch_pairs : 25000\ngzip_level : 1\ndevice_inflate : %s\n" % mode)
+        synth.write_conf(conf, paths, bcs, 2, gpu="[gpu]\nbatch_pairs : 25000\ngzip_level : 1\ndevice_inflate : %s\ndevice_pipeline : False\n" % mode)
         out = os.path.join(work, "out_" + mode)
         os.mkdir(out)
         cwd = os.getcwd()

@@ -53,23 +53,6 @@ def test_fast_kernel_vs_oracle(torch_cuda, engine, name, n):
     _check_workload(torch_cuda, engine, synth.generate(name, n, seed=1000 + n))
 
 
-@pytest.mark.parametrize("name", ["cfg3", "cfg4", "cfg5", "wide10"])
-@pytest.mark.parametrize("n", [0, 1, 2, 511, 512, 513, 519, 520, 1023, 4097, 30001, 70003, 300007])
-def test_work_queue_form_vs_oracle(torch_cuda, engine, name, n):
-    """The persistent launch form whose waves draw their runs of 512 pairs from counters in global memory (option
-    work_queue = 1; not the default: it measured behind the static forms): sizes around one run, the guard of the exact-width rows (8 pairs),
-    a block of 8 runs and many blocks; launched twice in a row, so a second launch finds its counters at zero."""
-    from quade_amd import synth
-    engine.set_option("work_queue", 1)
-    w = synth.generate(name, n, seed=5000 + n)
-    _check_workload(torch_cuda, engine, w)
-    engine.reset_counts()
-    _check_workload(torch_cuda, engine, w)
-    engine.set_option("work_queue", 2)  # and the static split, whatever the image size
-    engine.reset_counts()
-    _check_workload(torch_cuda, engine, w)
-
-
 @pytest.mark.parametrize("name", ["kit6", "kit8u8", "kit12", "kit10u6", "kit8u9", "kit8u12"])
 @pytest.mark.parametrize("n", [0, 1, 2, 7, 8, 9, 511, 1023, 4097, 30001, 70003])
 def test_kit_layouts_on_their_static_shapes(torch_cuda, engine, name, n):
