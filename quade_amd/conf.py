@@ -20,22 +20,27 @@ GPU_SECTION_HELP = """\
 Optional [gpu] section (not in Quade 0.3.2; a conf file without it runs with the defaults):
   [gpu]
   devices : 0            GPUs to use: "all" or a blank separated list of device ids
-  batch_pairs : 500000   read pairs per device batch (host memory in flight grows with it: ~3 GB at 2x150 bp)
-  slots : 3              pinned staging slots per device (H2D / kernel / D2H overlap)
+  device_pipeline : True the whole chunk loop on the GPU (libquade_hip qd_pipe_run): BGZF blocks inflated, records found, index rows
+                         packed and matched, records scattered by routing code, formatted, CRC-32'd and coded into gzip members with
+                         the fastq text staying in device memory; only compressed bytes cross PCIe (17-21 M pairs/s at 0.06-0.12
+                         core-s per M pairs on one MI355X).  Needs device_inflate, device_deflate, gzip_level 1 or -1, one device and
+                         one chunk worker per process; anything else runs the batch pipeline over pinned slots (7 M pairs/s at 1.5).
+                         Inputs that are not BGZF are inflated by the host's threads and join the device path as text
+  batch_pairs : 2000000  read pairs per device batch (device pipeline; its buffers are sized from it: ~25 GB of the GPU's 288 at
+                         2x150 bp); 500000 over pinned slots (host memory in flight grows with it: ~3 GB at 2x150 bp)
+  slots : 3              pinned staging slots per device (pinned-slots path: H2D / kernel / D2H overlap)
   gzip_level : 1         deflate level of the output fastq.gz files (0-9; -1 = Huffman coding only).  1, the default, is
-                         the level the GPU codes itself (device_deflate): 4.9 M pairs/s end to end against 3.0 on a 16-core
-                         host's pool, files smaller than libdeflate's level 6 on records with binned qualities (19.1 % of
-                         the text; level 6: 19.2 %, level 1: 20.9 %), between its levels 6 and 1 on uniformly random ones (41.7 %; 40.3 / 43.2 %); levels
-                         2-9 are libdeflate on the host's pool (level 6: 1.3 M pairs/s).  The reference writes with
-                         Python's gzip default (9); only the decompressed bytes are its format
-  chunk_workers : 1      chunks processed concurrently by host threads (outputs identical)
-  io_threads : 0         threads of the native gunzip / gzip pool (0 = one per core)
-  device_deflate : True  with gzip_level -1 or 1: the output members are made on the GPU (-1: one workgroup per ~2 MB piece of
-                         formatted text, Huffman coding only; 1: LZ77 + Huffman, one workgroup per 64 KiB of it) while
-                         page-locked buffers last, on the host's pool otherwise; no effect at the other levels
-  device_inflate : True  BGZF (bgzip) input files are inflated on the GPU, one workgroup of 512 lanes per block (every block's
-                         CRC-32 is checked on the host, a run that fails is inflated there): on a 16-core host + 16 % end to end
-                         on records with random qualities, level on binned ones, 20-30 % less CPU either way; ordinary gzip
+                         the level the GPU codes itself: files about the size of libdeflate's level 6 on records with binned
+                         qualities (21.0 % of the text; level 6: 19.2 %, level 1: 20.9 %), between its levels 6 and 1 on uniformly
+                         random ones (41.9 %; 40.3 / 43.2 %); levels 2-9 are libdeflate on the host's pool (level 6: 1.6 M pairs/s).
+                         The device's level-1 files are not byte-reproducible from run to run (their decompressed content is).
+                         The reference writes with Python's gzip default (9); only the decompressed bytes are its format
+  chunk_workers : 1      chunks processed concurrently by host threads (pinned-slots path; outputs identical)
+  io_threads : 0         threads of the native I/O pool (0 = one per core)
+  device_deflate : True  with gzip_level -1 or 1: the output members are made on the GPU (-1: Huffman coding only; 1: LZ77 + Huffman,
+                         one workgroup per 64 KiB of formatted text); no effect at the other levels
+  device_inflate : True  BGZF (bgzip) input files are inflated on the GPU, one workgroup of 512-1024 lanes per block (every block's
+                         CRC-32 is checked against its trailer; a block the device refuses is inflated by the host); ordinary gzip
                          files are inflated by the host's threads whatever this says
 """
 
