@@ -454,6 +454,13 @@ typedef struct qd_pipe_chunk {
     qd_sink* sink;   /* where the chunk's records go (one sink for the run, or one per chunk part directory) */
     const char* begin_message;
     const char* end_message;
+    /* One part of a chunk that several ranks share (all zero: the whole chunk).  Stream s (r1, r2, i1, i2) is read from file offset
+     * start_offset[s] on -- a BGZF block boundary --, the first skip_bytes[s] bytes of its text and then its first skip_kept[s] kept
+     * records are dropped, and the part is over after max_pairs pairs (0: at the first exhausted stream).  qd_pipe_index gives the numbers. */
+    int64_t start_offset[4];
+    int64_t skip_bytes[4];
+    int64_t skip_kept[4];
+    int64_t max_pairs;
 } qd_pipe_chunk;
 typedef struct qd_pipe_stats {
     int64_t pairs, batches;
@@ -469,6 +476,25 @@ typedef struct qd_pipe_stats {
     double run_s, wait_input_s, wait_sync_s, wait_out_set_s, alloc_s, collector_wait_s, download_s, append_s;
 } qd_pipe_stats;
 int qd_pipe_create(qd_ctx* ctx, qd_pipe** out); /* the context holds plan and barcodes */
+/* A chunk that several ranks share ("large single chunks are split into contiguous row ranges").  The reference pairs
+ * record j of every stream counted from the start of the chunk (src/Quade.py:210-221), and a dropped record shifts its stream, so a
+ * rank cannot start in the middle of a file without knowing how many lines and kept records lie before.  qd_pipe_index is the first
+ * pass: the BGZF file `path` is cut into world x grains_per_rank grains at block boundaries, this rank inflates its grains on the
+ * device and reports, for each and for each residue of (lines before the grain) mod 4: the kept records that start in it, and how
+ * many bytes into the grain the first of them starts (0xFFFFFFFF: none).  The ranks exchange these tables (any transport: they are a
+ * few hundred bytes per grain), add the line counts up -- which fixes every grain's residue -- and the kept counts, and derive the
+ * start_offset / skip_bytes / skip_kept / max_pairs of every rank's part (quade_amd/dist.py: plan_parts).  incomplete[q] != 0: a record
+ * of the grain reaches beyond the text this rank looked at -- the caller falls back to one rank per chunk.  QD_ERR_UNSUPPORTED: the
+ * file is not BGZF throughout, or a rank's share exceeds one window. */
+typedef struct qd_grain_info {
+    int64_t file_offset;   /* of the grain's first BGZF block */
+    uint32_t n_lines;      /* newlines inside the grain */
+    uint32_t kept[4];      /* kept records whose header line starts in the grain, by residue */
+    uint32_t skip_bytes[4]; /* from the grain's first byte of text to its first kept record's header */
+    uint32_t incomplete[4];
+} qd_grain_info;
+int qd_pipe_index(qd_pipe* pipe, const char* path, int32_t world, int32_t rank, int32_t grains_per_rank, qd_grain_info* out, int32_t cap,
+                  int32_t* n_out);
 /* "batch_pairs": pairs per batch at most (default 2 000 000; windows of text are sized from it, at most 1 GiB per stream);
  * "test_fail_inflate_batch": tests -- the device's BGZF result of that batch is treated as refused */
 int qd_pipe_set_option(qd_pipe* pipe, const char* name, int64_t value);

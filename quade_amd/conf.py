@@ -26,6 +26,10 @@ Optional [gpu] section (not in Quade 0.3.2; a conf file without it runs with the
                          core-s per M pairs on one MI355X).  Needs device_inflate, device_deflate, gzip_level 1 or -1, one device and
                          one chunk worker per process; anything else runs the batch pipeline over pinned slots (7 M pairs/s at 1.5).
                          Inputs that are not BGZF are inflated by the host's threads and join the device path as text
+  shard_chunks : auto    under a launcher (one process per GPU): a chunk is cut into pair ranges over ALL ranks -- auto: when there are
+                         fewer chunks than ranks, True: always, False: never (chunk c belongs to rank c mod N).  Needs the device
+                         pipeline and BGZF inputs (an index pass counts lines and kept records per block range, so that pair j is
+                         still record j of every stream); other chunks stay with one rank
   batch_pairs : 2000000  read pairs per device batch (device pipeline; its buffers are sized from it: ~25 GB of the GPU's 288 at
                          2x150 bp); 500000 over pinned slots (host memory in flight grows with it: ~3 GB at 2x150 bp)
   slots : 3              pinned staging slots per device (pinned-slots path: H2D / kernel / D2H overlap)
@@ -124,6 +128,12 @@ class QuadeConf(object):
         # inflate and deflate stages and a gzip level the device codes (1, -1); batch_pairs then defaults to 2 000 000
         self.device_pipeline = opt("device_pipeline", "True", str).strip().lower() in ("true", "1", "yes", "on")
         self.batch_pairs_given = cp.has_section("gpu") and cp.has_option("gpu", "batch_pairs")
+        # one chunk across several ranks: auto (fewer chunks than ranks), True, False
+        self.shard_chunks = opt("shard_chunks", "auto", str).strip().lower()
+        if self.shard_chunks in ("1", "yes", "on"):
+            self.shard_chunks = "true"
+        if self.shard_chunks in ("0", "no", "off"):
+            self.shard_chunks = "false"
 
         self._test_values()
 

@@ -180,14 +180,21 @@ struct Segment {
     size_t text_bytes = 0;  // BGZF: what the blocks inflate to
     std::vector<qd_inflate_block> blocks;  // in_off inside the slot, out_off inside the segment's text
     std::vector<uint32_t> crcs;
+    std::vector<uint32_t> starts;  // where every block starts in the slot (its file offset = file_off + that)
     uint32_t longest = 0;
     int64_t file_off = 0;   // BGZF: where the blocks start in the file (a run the device refuses is read again by the host)
     std::string err;
 };
 
+struct FileSpec {
+    std::string path;
+    int64_t start = 0;  // > 0: BGZF blocks from this file offset on (a chunk that several ranks share)
+    int64_t end = -1;   // >= 0: up to this offset (a block boundary)
+};
+
 class Feeder {
   public:
-    Feeder(int device, std::vector<std::string> paths) : device_(device), paths_(std::move(paths)) {}
+    Feeder(int device, std::vector<FileSpec> files) : device_(device), files_(std::move(files)) {}
     ~Feeder() { stop(); }
     hipError_t start() {
         hipError_t e = hipSetDevice(device_);
@@ -316,7 +323,7 @@ class Feeder {
 
     void run() {
         (void)hipSetDevice(device_);
-        for (int c = 0; c < (int)paths_.size(); ++c) {
+        for (int c = 0; c < (int)files_.size(); ++c) {
             if (stopping()) return;
             if (skip_.load() <= c) one_file(c);
             Segment end;
@@ -362,13 +369,18 @@ class Feeder {
     }
 
     void one_file(int c) {
-        const std::string& path = paths_[c];
-        if (!ends_gz(path)) return text_from(c, path, 0);
+        const std::string& path = files_[c].path;
+        const int64_t range_start = files_[c].start, range_end = files_[c].end;
+        const bool ranged = range_start > 0 || range_end >= 0;
+        if (!ends_gz(path)) {
+            if (ranged) return fail(c, path + ": a byte range needs a BGZF file");
+            return text_from(c, path, 0);
+        }
         const int fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
         if (fd < 0) return fail(c, path + ": " + strerror(errno));
         std::vector<uint8_t> tail;  // the partial block behind the last whole one of the previous buffer
-        int64_t file_pos = 0;       // file offset of the buffer's first byte
-        int64_t read_pos = 0;       // file offset of the next byte to read
+        int64_t file_pos = range_start;  // file offset of the buffer's first byte
+        int64_t read_pos = range_start;  // file offset of the next byte to read
         bool eof = false, first = true;
         int64_t switch_at = -1;     // >= 0: not (or no longer) BGZF from this file offset on
         while (!eof && switch_at < 0) {
@@ -384,7 +396,11 @@ class Feeder {
             {
                 // one thread copies ~2.5 GB/s out of the page cache, less than the device inflates: the buffer's parts are
                 // read side by side on the library's pool (pread at known offsets; the blocks are cut afterwards)
-                const size_t want = SEG_BYTES - fill;
+                size_t want = SEG_BYTES - fill;
+                if (range_end >= 0) {
+                    want = (size_t)std::min<int64_t>((int64_t)want, std::max<int64_t>(range_end - read_pos, 0));
+                    if (want == 0) eof = true;
+                }
                 const int64_t from = read_pos;
                 const int parts = (int)((want + READ_PART - 1) / READ_PART);
                 std::vector<ssize_t> got((size_t)parts, 0);
@@ -433,8 +449,14 @@ class Feeder {
                         break;
                     }
                 }
+                if (range_end >= 0 && read_pos >= range_end) eof = true;
             }
             if (first && !qdio::bgzf_block_size(pin, fill)) {  // ordinary gzip: the host's parallel inflater takes the file
+                if (ranged) {
+                    fail(c, path + ": no BGZF block at the start of the byte range");
+                    close(fd);
+                    return;
+                }
                 switch_at = 0;
                 break;
             }
@@ -466,6 +488,7 @@ class Feeder {
                 const uint32_t in_len = (uint32_t)(bs - 12 - xlen - 8);
                 seg.blocks.push_back(qd_inflate_block{(uint32_t)(pos + 12 + xlen), in_len, (uint32_t)seg.text_bytes, isize});
                 seg.crcs.push_back(crc);
+                seg.starts.push_back((uint32_t)pos);
                 seg.longest = std::max(seg.longest, in_len);
                 seg.text_bytes += isize;
                 pos += bs;
@@ -475,11 +498,12 @@ class Feeder {
             if (!seg.blocks.empty() && !upload(seg, pin, pos)) break;
         }
         close(fd);
+        if (switch_at >= 0 && ranged) return fail(c, path + ": the byte range is not BGZF blocks throughout");
         if (switch_at >= 0 && skip_.load() <= c && !stopping()) text_from(c, path, switch_at);
     }
 
     int device_;
-    std::vector<std::string> paths_;
+    std::vector<FileSpec> files_;
     hipStream_t up_ = nullptr;
     uint8_t* ring_ = nullptr;
     hipEvent_t ready_[RING_SLOTS] = {nullptr}, consumed_[RING_SLOTS] = {nullptr};
@@ -573,6 +597,7 @@ struct qd_pipe {
     OutSet out[2];
     PinBuf slab[3];                                // the collector's download ring
     hipEvent_t slab_ev[3] = {nullptr, nullptr, nullptr};
+    size_t window_max = WINDOW_MAX;                // text a window may hold (the index pass of a shared chunk raises it for its one window)
     bool reserved = false;                         // the buffers have been sized for batch_pairs (after the first scan)
     int64_t max_r1_bytes = 0;                      // size of the run's largest seq_R1 file
     bool r1_compressed = true;
@@ -817,7 +842,7 @@ using Window = qd_pipe::Window;
 // room for `extra` more bytes of text in the window (the line kernels read whole tiles: padding behind the text)
 int window_room(qd_pipe* p, Window& w, size_t extra) {
     const size_t need = (size_t)w.len + extra + 2 * QD_TEXT_TILE;
-    if ((size_t)w.len + extra > WINDOW_MAX) return pfail(p, QD_ERR_UNSUPPORTED, w.path + ": more than 1 GiB of text in one batch (lower batch_pairs)");
+    if ((size_t)w.len + extra > p->window_max) return pfail(p, QD_ERR_UNSUPPORTED, w.path + ": more text in one window than its 32-bit offsets reach (lower batch_pairs)");
     PCHK(p, w.buf[w.cur].need(need, w.len, p->cs));
     return QD_OK;
 }
@@ -1169,7 +1194,8 @@ int process_batch(qd_pipe* p, uint32_t n, qd_sink* sink, int64_t batch_index) {
             recs[s] = p->win[s].recs.as<qd_rec>();
             res[s] = p->d_res.as<qd_scan_result>() + s;
         }
-        PCHK(p, qd_text_carry_info(recs, res, p->n_streams, n, p->cs));
+        const uint32_t taken[4] = {n, n, n, n};
+        PCHK(p, qd_text_carry_info(recs, res, p->n_streams, taken, p->cs));
     }
     // 4. read back: per-destination bounds, totals, carry starts
     PCHK(p, p->h_first.need((size_t)nd * 12 + 16));
@@ -1305,9 +1331,30 @@ int process_batch(qd_pipe* p, uint32_t n, qd_sink* sink, int64_t batch_index) {
     return QD_OK;
 }
 
-int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chunk, qd_sink* sink, int64_t* batch_index) {
+// a D2D move of a window's text from `from` on to the front of its other buffer
+int carry_window(qd_pipe* p, Window& w, uint32_t from_in) {
+    const uint32_t from = std::min(from_in, w.len), left = w.len - from;
+    const int nx = w.cur ^ 1;
+    PCHK(p, w.buf[nx].need((size_t)left + 2 * QD_TEXT_TILE, 0, p->cs));
+    if (left) PCHK(p, hipMemcpyAsync(w.buf[nx].p, w.buf[w.cur].p + from, left, hipMemcpyDeviceToDevice, p->cs));
+    w.cur = nx;
+    w.len = left;
+    w.dirty = true;
+    return QD_OK;
+}
+
+int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chunk, const qd_pipe_chunk& spec, int64_t* batch_index) {
+    qd_sink* sink = spec.sink;
     const int ns = p->n_streams;
     const uint32_t B = (uint32_t)std::min<int64_t>(p->batch_pairs, 0x7FFFFFFF);
+    // a chunk that several ranks share: this rank's part starts skip_bytes into the text behind start_offset, skip_kept kept
+    // records further on, and is max_pairs pairs long
+    uint64_t skip_bytes[4], skip_kept[4];
+    for (int s = 0; s < 4; ++s) {
+        skip_bytes[s] = spec.skip_bytes[s] > 0 ? (uint64_t)spec.skip_bytes[s] : 0;
+        skip_kept[s] = spec.skip_kept[s] > 0 ? (uint64_t)spec.skip_kept[s] : 0;
+    }
+    uint64_t pairs_left = spec.max_pairs > 0 ? (uint64_t)spec.max_pairs : ~0ull;
     for (int s = 0; s < ns; ++s) {
         Window& w = p->win[s];
         w.len = 0;
@@ -1323,6 +1370,23 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
         for (int s = 0; s < ns; ++s) {
             const int rc = top_up(p, *feeders[s], p->win[s], s, chunk, want[s]);
             if (rc != QD_OK) return rc;
+        }
+        // (a shared chunk: the text in front of this rank's first record goes before anything is scanned)
+        {
+            bool more = false;
+            for (int s = 0; s < ns; ++s) {
+                Window& w = p->win[s];
+                if (!skip_bytes[s]) continue;
+                if ((uint64_t)w.len < skip_bytes[s] && !w.eof) {
+                    want[s] = (size_t)skip_bytes[s] + 1;
+                    more = true;
+                    continue;
+                }
+                const int rc = carry_window(p, w, (uint32_t)std::min<uint64_t>(skip_bytes[s], w.len));
+                if (rc != QD_OK) return rc;
+                skip_bytes[s] = 0;
+            }
+            if (more) continue;
         }
         // 2. records of the windows that changed
         bool scanned = false;
@@ -1375,6 +1439,37 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
             for (int s = 0; s < ns; ++s) p->win[s].dirty = true;  // (the scans' tables moved: once more, over these first small windows)
             continue;
         }
+        // (a shared chunk: the kept records in front of this rank's first pair are dropped, window by window)
+        {
+            uint32_t drop[4] = {0, 0, 0, 0};
+            bool any = false;
+            for (int s = 0; s < ns; ++s) {
+                drop[s] = (uint32_t)std::min<uint64_t>(skip_kept[s], p->win[s].res.n_kept);
+                any = any || skip_kept[s] > 0;
+            }
+            if (any) {
+                const qd_rec* recs[4] = {nullptr, nullptr, nullptr, nullptr};
+                qd_scan_result* res[4] = {nullptr, nullptr, nullptr, nullptr};
+                for (int s = 0; s < ns; ++s) {
+                    recs[s] = p->win[s].recs.as<qd_rec>();
+                    res[s] = p->d_res.as<qd_scan_result>() + s;
+                }
+                PCHK(p, qd_text_carry_info(recs, res, ns, drop, p->cs));
+                PCHK(p, hipMemcpyAsync(p->h_res.p, p->d_res.p, (size_t)ns * sizeof(qd_scan_result), hipMemcpyDeviceToHost, p->cs));
+                int rc = sync_compute(p);
+                if (rc != QD_OK) return rc;
+                for (int s = 0; s < ns; ++s) {
+                    Window& w = p->win[s];
+                    skip_kept[s] -= drop[s];
+                    if (skip_kept[s] && w.eof && drop[s] == w.res.n_kept) skip_kept[s] = 0;  // (the stream ends before this rank's part: nothing to do)
+                    rc = carry_window(p, w, reinterpret_cast<qd_scan_result*>(p->h_res.p)[s].carry_start);
+                    if (rc != QD_OK) return rc;
+                    const double per = w.avg > 0 ? w.avg : 256.0;
+                    want[s] = std::min<size_t>((size_t)w.len + (size_t)((double)(skip_kept[s] + B) * per * 1.03) + 4096, p->window_max * 3 / 4);
+                }
+                continue;
+            }
+        }
         // 3. a stream short of records that has more input: top it up (its window is scanned again)
         bool short_of = false;
         for (int s = 0; s < ns; ++s) {
@@ -1389,28 +1484,25 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
         }
         if (short_of) continue;
         // 4. lock step: pair j = kept record j of every stream (src/Quade.py:210-221)
-        uint32_t n = B;
+        uint32_t n = (uint32_t)std::min<uint64_t>(B, pairs_left);
         for (int s = 0; s < ns; ++s) n = std::min(n, p->win[s].res.n_kept);
         if (n) {
             const int rc = process_batch(p, n, sink, *batch_index);
             if (rc != QD_OK) return rc;
             ++*batch_index;
+            pairs_left -= n;
         }
-        // 5. the chunk ends with its first exhausted stream (src/Quade.py:223-224)
-        bool done = false;
+        // 5. the chunk ends with its first exhausted stream (src/Quade.py:223-224) -- or with this rank's part of it
+        bool done = pairs_left == 0;
         for (int s = 0; s < ns; ++s) done = done || (p->win[s].eof && p->win[s].res.n_kept == n);
         if (done || n == 0) break;
         // 6. what is left of every window moves to the front of its other buffer
         for (int s = 0; s < ns; ++s) {
             Window& w = p->win[s];
-            const uint32_t from = std::min(w.res.carry_start, w.len), left = w.len - from;
-            const int nx = w.cur ^ 1;
-            PCHK(p, w.buf[nx].need((size_t)left + 2 * QD_TEXT_TILE, 0, p->cs));
-            if (left) PCHK(p, hipMemcpyAsync(w.buf[nx].p, w.buf[w.cur].p + from, left, hipMemcpyDeviceToDevice, p->cs));
-            w.cur = nx;
-            w.len = left;
+            const int rc = carry_window(p, w, w.res.carry_start);
+            if (rc != QD_OK) return rc;
             w.carry_kept = w.res.n_kept - n;
-            w.dirty = true;
+            const uint32_t left = w.len;
             const double per = w.avg > 0 ? w.avg : 256.0;
             want[s] = std::min<size_t>((size_t)left + (size_t)((double)(B > w.carry_kept ? B - w.carry_kept : 0) * per * 1.03) + 4096, WINDOW_MAX * 3 / 4);
         }
@@ -1424,9 +1516,174 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
     return QD_OK;
 }
 
+// ---- a chunk that several ranks share: the index pass -----------------------------------------------------------------------------------
+// file offsets of every BGZF block of a file (and its size behind the last): headers only, 18 bytes per block
+int walk_bgzf(qd_pipe* p, const char* path, std::vector<int64_t>* off) {
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return pfail(p, QD_ERR_FORMAT, std::string(path) + ": " + strerror(errno));
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) {
+        close(fd);
+        return pfail(p, QD_ERR_FORMAT, std::string(path) + ": " + strerror(errno));
+    }
+    int64_t at = 0;
+    uint8_t h[64];
+    int rc = QD_OK;
+    while (at < (int64_t)sb.st_size) {
+        const ssize_t g = pread(fd, h, sizeof h, (off_t)at);
+        const size_t bs = g > 0 ? qdio::bgzf_block_size(h, (size_t)g) : 0;
+        if (bs < 26 || at + (int64_t)bs > (int64_t)sb.st_size) {
+            rc = pfail(p, QD_ERR_UNSUPPORTED, std::string(path) + ": not BGZF blocks throughout (a shared chunk needs bgzip files)");
+            break;
+        }
+        off->push_back(at);
+        at += (int64_t)bs;
+    }
+    close(fd);
+    if (rc == QD_OK) off->push_back(at);
+    return rc;
+}
+
+int index_stream(qd_pipe* p, const char* path, int32_t world, int32_t rank, int32_t grains_per_rank, int32_t want_overlap_blocks, qd_grain_info* out,
+                 int32_t cap, int32_t* n_out) {
+    std::vector<int64_t> boff;
+    int rc = walk_bgzf(p, path, &boff);
+    if (rc != QD_OK) return rc;
+    const int64_t nb = (int64_t)boff.size() - 1;
+    const int64_t G = std::max<int64_t>(1, std::min<int64_t>((int64_t)world * grains_per_rank, nb));
+    auto grain_block = [&](int64_t g) { return g * nb / G; };  // first block of grain g (g == G: nb)
+    const int64_t g_lo = std::min<int64_t>(G, (int64_t)rank * grains_per_rank), g_hi = std::min<int64_t>(G, g_lo + grains_per_rank);
+    *n_out = (int32_t)(g_hi - g_lo);
+    if (g_hi <= g_lo) return QD_OK;
+    if (g_hi - g_lo > cap) return pfail(p, QD_ERR_INVALID, "grain table too small");
+    // one block of lead-in (is the byte in front of the first grain a newline?) and a few of overlap (the record that starts in the last grain)
+    const int64_t b_first = grain_block(g_lo), b_end = grain_block(g_hi);
+    const int64_t b_from = std::max<int64_t>(0, b_first - 1), b_to = std::min<int64_t>(nb, b_end + want_overlap_blocks);
+    Window& w = p->win[0];
+    w.path = path;
+    w.len = 0;
+    w.eof = false;
+    w.dirty = true;
+    w.n_blocks = 0;
+    w.runs.clear();
+    w.avg = 0;
+    w.line_cap = 0;
+    const size_t saved_max = p->window_max;
+    p->window_max = (size_t)3500 << 20;
+    std::vector<FileSpec> files(1);
+    files[0].path = path;
+    files[0].start = boff[b_from];
+    files[0].end = boff[b_to];
+    // (start == 0 would read "the whole file" semantics with end set: fine, the range form only needs end)
+    Feeder f(p->device, files);
+    hipError_t he = f.start();
+    if (he != hipSuccess) {
+        p->window_max = saved_max;
+        return pfail(p, QD_ERR_HIP, std::string("feeder: ") + hipGetErrorString(he));
+    }
+    // the text offset of every block of the range, as its segments arrive
+    std::vector<uint32_t> text_at;  // per block b_from + k
+    uint64_t text_total = 0;
+    for (;;) {
+        Segment sg = f.pop();
+        if (sg.kind == SEG_ERROR) {
+            rc = pfail(p, QD_ERR_FORMAT, sg.err);
+            break;
+        }
+        if (sg.kind == SEG_END) break;
+        if (sg.kind != SEG_BGZF) {
+            rc = pfail(p, QD_ERR_UNSUPPORTED, std::string(path) + ": not BGZF");
+            break;
+        }
+        for (const qd_inflate_block& b : sg.blocks) {
+            text_at.push_back((uint32_t)text_total);
+            text_total += b.out_len;
+        }
+        if (text_total > p->window_max) {
+            rc = pfail(p, QD_ERR_UNSUPPORTED, std::string(path) + ": this rank's share of the chunk exceeds one window (more ranks, or smaller chunks)");
+            PCHK(p, f.consumed(sg.slot, p->cs));
+            break;
+        }
+        w.pending_text += (uint32_t)sg.text_bytes;
+        w.pending.push_back(std::move(sg));
+        if (w.pending.size() >= GROUP_SEGMENTS) {
+            rc = launch_inflate(p, f, w, 0);
+            if (rc != QD_OK) break;
+        }
+    }
+    if (rc == QD_OK) rc = launch_inflate(p, f, w, 0);
+    if (rc == QD_OK && (int64_t)text_at.size() != b_to - b_from) rc = pfail(p, QD_ERR_FORMAT, std::string(path) + ": block walk and reader disagree");
+    const bool at_eof = b_to == nb;
+    w.eof = at_eof;
+    // lines of the window (the line table may have to grow once), then the grains
+    for (int attempt = 0; rc == QD_OK && attempt < 3; ++attempt) {
+        rc = scan_window(p, w, 0);
+        if (rc == QD_OK) rc = sync_compute(p);
+        if (rc != QD_OK) break;
+        w.res = reinterpret_cast<qd_scan_result*>(p->h_res.p)[0];
+        if (w.n_blocks && w.res.first_bad != 0xFFFFFFFFu) {
+            rc = host_inflate_window(p, w);
+            if (rc != QD_OK) break;
+            PCHK(p, hipMemsetAsync(&p->d_res.as<qd_scan_result>()[0].first_bad, 0xFF, 4, p->cs));
+            w.n_blocks = 0;
+            continue;
+        }
+        if (!w.res.overflow) break;
+        w.line_cap = (w.res.n_lines + w.res.n_lines / 8 + 4096 + 3) & ~3u;
+    }
+    if (rc == QD_OK && w.res.overflow) rc = pfail(p, QD_ERR_HIP, "line table overflow");
+    if (w.n_blocks) PCHK(p, hipMemsetAsync(&p->d_res.as<qd_scan_result>()[0].first_bad, 0xFF, 4, p->cs));
+    w.n_blocks = 0;
+    w.runs.clear();
+    const int ng = (int)(g_hi - g_lo);
+    std::vector<uint32_t> gstart((size_t)ng + 1);
+    std::vector<qd_grain_index> gi((size_t)ng);
+    if (rc == QD_OK) {
+        for (int k = 0; k <= ng; ++k) {
+            const int64_t b = grain_block(g_lo + k);
+            gstart[(size_t)k] = b - b_from < (int64_t)text_at.size() ? text_at[(size_t)(b - b_from)] : (uint32_t)text_total;
+        }
+        if (g_hi == G && at_eof) gstart[(size_t)ng] = (uint32_t)text_total + 1;  // (the unterminated last line of the file ends "at" text_total)
+        DevBuf d_g, d_out;
+        PCHK(p, d_g.need(((size_t)ng + 1) * 4, 0, p->cs));
+        PCHK(p, d_out.need((size_t)ng * sizeof(qd_grain_index), 0, p->cs));
+        PCHK(p, p->stage.upload(d_g.p, gstart.data(), ((size_t)ng + 1) * 4, p->cs));
+        PCHK(p, qd_text_grain_index(w.buf[w.cur].p, w.lines.as<uint32_t>(), w.line_cap, p->d_res.as<qd_scan_result>(), d_g.as<uint32_t>(), (uint32_t)ng,
+                                    at_eof ? 1 : 0, d_out.as<qd_grain_index>(), p->cs));
+        PCHK(p, hipStreamSynchronize(p->cs));
+        PCHK(p, hipMemcpy(gi.data(), d_out.p, (size_t)ng * sizeof(qd_grain_index), hipMemcpyDeviceToHost));
+        d_g.release();
+        d_out.release();
+        for (int k = 0; k < ng; ++k) {
+            qd_grain_info& o = out[k];
+            o.file_offset = boff[(size_t)grain_block(g_lo + k)];
+            o.n_lines = gi[(size_t)k].n_lines;
+            for (int q = 0; q < 4; ++q) {
+                o.kept[q] = gi[(size_t)k].kept[q];
+                o.skip_bytes[q] = gi[(size_t)k].first_head[q] == 0xFFFFFFFFu ? 0xFFFFFFFFu : gi[(size_t)k].first_head[q] - gstart[(size_t)k];
+                o.incomplete[q] = gi[(size_t)k].incomplete[q];
+            }
+        }
+    }
+    f.stop();
+    p->window_max = saved_max;
+    w.len = 0;
+    w.eof = false;
+    w.line_cap = 0;
+    w.avg = 0;
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
+
+int qd_pipe_index(qd_pipe* p, const char* path, int32_t world, int32_t rank, int32_t grains_per_rank, qd_grain_info* out, int32_t cap, int32_t* n_out) {
+    if (!p || !path || world < 1 || rank < 0 || rank >= world || grains_per_rank < 1 || !out || cap < 1 || !n_out) return pfail(p, QD_ERR_INVALID, "bad arguments");
+    p->err.clear();
+    PCHK(p, hipSetDevice(p->device));
+    return index_stream(p, path, world, rank, grains_per_rank, 4, out, cap, n_out);
+}
 
 const char* qd_pipe_last_error(const qd_pipe* p) { return p ? p->err.c_str() : g_pipe_error.c_str(); }
 
@@ -1488,9 +1745,14 @@ int qd_pipe_run(qd_pipe* p, const qd_pipe_chunk* chunks, int32_t n_chunks, qd_pi
     p->reserved = false;
     std::vector<std::unique_ptr<Feeder>> feeders;
     for (int s = 0; s < ns; ++s) {
-        std::vector<std::string> paths;
-        for (int c = 0; c < n_chunks; ++c) paths.emplace_back(s == 0 ? chunks[c].r1 : s == 1 ? chunks[c].r2 : s == 2 ? chunks[c].i1 : chunks[c].i2);
-        feeders.emplace_back(new Feeder(p->device, std::move(paths)));
+        std::vector<FileSpec> files;
+        for (int c = 0; c < n_chunks; ++c) {
+            FileSpec f;
+            f.path = s == 0 ? chunks[c].r1 : s == 1 ? chunks[c].r2 : s == 2 ? chunks[c].i1 : chunks[c].i2;
+            f.start = chunks[c].start_offset[s] > 0 ? chunks[c].start_offset[s] : 0;
+            files.push_back(std::move(f));
+        }
+        feeders.emplace_back(new Feeder(p->device, std::move(files)));
     }
     for (auto& f : feeders) PCHK(p, f->start());
     {
@@ -1507,7 +1769,7 @@ int qd_pipe_run(qd_pipe* p, const qd_pipe_chunk* chunks, int32_t n_chunks, qd_pi
             fputs(chunks[c].begin_message, stdout);
             fflush(stdout);
         }
-        rc = run_chunk(p, feeders, c, chunks[c].sink, &batch_index);
+        rc = run_chunk(p, feeders, c, chunks[c], &batch_index);
         if (rc == QD_OK && chunks[c].end_message) {
             BatchOut m;
             m.message = chunks[c].end_message;

@@ -55,9 +55,21 @@ struct qd_scan_scratch {
 hipError_t qd_text_scan(const uint8_t* text, uint32_t len, int at_eof, int want_names, uint32_t need, const qd_scan_scratch& s,
                         qd_scan_result* result, hipStream_t st);
 
-// carry_start of every stream for a batch that consumes the first n kept records of each: the head of kept record n, or
+// carry_start of every stream for a batch that consumes the first n[s] kept records of stream s: the head of kept record n[s], or
 // tail_start when the window holds no more kept records
-hipError_t qd_text_carry_info(const qd_rec* const recs[4], qd_scan_result* const results[4], int n_streams, uint32_t n, hipStream_t st);
+hipError_t qd_text_carry_info(const qd_rec* const recs[4], qd_scan_result* const results[4], int n_streams, const uint32_t n[4], hipStream_t st);
+
+// Grains (a chunk shared by several ranks): the window's text is cut at grain_start[0 .. n_grains] (text offsets, ascending; the
+// last entry closes the last grain).  A record belongs to the grain its header line starts in.  For each grain and each residue
+// phase = (lines of the file before the grain) mod 4: how many of its records are kept, where the first kept one starts, and whether
+// a record of the grain reaches beyond the window (then the caller needs more text behind it).  Needs the scan's line table.
+struct qd_grain_index {
+    uint32_t first_line;  // newlines of the window before the grain
+    uint32_t n_lines;     // newlines inside the grain
+    uint32_t kept[4], first_head[4], incomplete[4];
+};
+hipError_t qd_text_grain_index(const uint8_t* text, const uint32_t* lines, uint32_t line_cap, const qd_scan_result* res, const uint32_t* grain_start,
+                               uint32_t n_grains, int at_eof, qd_grain_index* out, hipStream_t st);
 
 // Index rows of pairs [0, n): stream k's rows from text[k] / recs[k] as qd_layout says (seq window zero padded, barcode
 // qualities 0xFF padded, len = min(255, read length)).  short_idx / n_short: the pairs with a read shorter than its window

@@ -240,11 +240,73 @@ __global__ __launch_bounds__(256) void rec_write(const uint8_t* text, const uint
 }
 
 __global__ void carry_info(const qd_rec* r0, const qd_rec* r1, const qd_rec* r2, const qd_rec* r3, qd_scan_result* s0, qd_scan_result* s1,
-                           qd_scan_result* s2, qd_scan_result* s3, int n_streams, uint32_t n) {
+                           qd_scan_result* s2, qd_scan_result* s3, int n_streams, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n3) {
     const qd_rec* recs[4] = {r0, r1, r2, r3};
     qd_scan_result* res[4] = {s0, s1, s2, s3};
+    const uint32_t ns[4] = {n0, n1, n2, n3};
     const int k = (int)threadIdx.x;
-    if (k < n_streams) res[k]->carry_start = n < res[k]->n_kept ? recs[k][n].head : res[k]->tail_start;
+    if (k < n_streams) res[k]->carry_start = ns[k] < res[k]->n_kept ? recs[k][ns[k]].head : res[k]->tail_start;
+}
+
+// ---- grains: a stream's text cut at BGZF block boundaries, indexed without knowing where its records start -----------------------
+// A chunk that several ranks share is cut into grains; a grain's rank does not know how many lines lie before it in the file, so
+// it counts for all four residues: a line whose end is newline i of the window heads a record under the phase that makes
+// (lines before the grain + i - first) a multiple of 4.  Every line is the candidate of exactly one phase of its grain.
+__global__ void grain_bounds(const uint32_t* lines, const qd_scan_result* res, const uint32_t* grain_start, uint32_t n_grains, qd_grain_index* out) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_grains) return;
+    const uint32_t n = res->overflow ? 0u : res->n_lines;
+    auto lower = [&](uint32_t pos) {  // newlines before `pos`
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (lines[mid] < pos) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo;
+    };
+    qd_grain_index r;
+    r.first_line = lower(grain_start[g]);
+    r.n_lines = lower(grain_start[g + 1]) - r.first_line;
+    for (int k = 0; k < 4; ++k) {
+        r.kept[k] = 0;
+        r.first_head[k] = 0xFFFFFFFFu;
+        r.incomplete[k] = 0;
+    }
+    out[g] = r;
+}
+
+__global__ __launch_bounds__(256) void grain_index(const uint8_t* text, const uint32_t* lines, const qd_scan_result* res, const uint32_t* grain_start,
+                                                   uint32_t n_grains, int at_eof, qd_grain_index* out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;  // newline i ends a candidate header line
+    const uint32_t n = res->overflow ? 0u : res->n_lines;
+    if (i >= n) return;
+    const uint32_t head = i ? lines[i - 1] + 1 : 0u;
+    // the grain that owns a record is the one its header line STARTS in
+    uint32_t lo = 0, hi = n_grains;  // the last g with grain_start[g] <= head
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (grain_start[mid] <= head) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t g = lo;
+    if (head < grain_start[g] || head >= grain_start[g + 1]) return;  // (before the first grain / in the overlap behind the last)
+    const uint32_t phase = (out[g].first_line - i) & 3u;  // lines before the grain, mod 4, under which line i is a header
+    if (i + 3 >= n) {  // the record's lines are not all in the window
+        if (!at_eof) atomicOr(&out[g].incomplete[phase], 1u);
+        return;
+    }
+    Lines4 l;
+    l.head = head;
+    l.e0 = lines[i];
+    l.e1 = lines[i + 1];
+    l.e2 = lines[i + 2];
+    l.e3 = lines[i + 3];
+    uint32_t sl;
+    if (record_kept(text, l, &sl)) {
+        atomicAdd(&out[g].kept[phase], 1u);
+        atomicMin(&out[g].first_head[phase], head);
+    }
 }
 
 // ---- index rows -------------------------------------------------------------------------------------------------------
@@ -664,9 +726,17 @@ hipError_t qd_text_scan(const uint8_t* text, uint32_t len, int at_eof, int want_
     return hipGetLastError();
 }
 
-hipError_t qd_text_carry_info(const qd_rec* const recs[4], qd_scan_result* const results[4], int n_streams, uint32_t n, hipStream_t st) {
+hipError_t qd_text_grain_index(const uint8_t* text, const uint32_t* lines, uint32_t line_cap, const qd_scan_result* res, const uint32_t* grain_start,
+                               uint32_t n_grains, int at_eof, qd_grain_index* out, hipStream_t st) {
+    if (!n_grains) return hipSuccess;
+    hipLaunchKernelGGL(grain_bounds, dim3((n_grains + 63) / 64), dim3(64), 0, st, lines, res, grain_start, n_grains, out);
+    if (line_cap) hipLaunchKernelGGL(grain_index, dim3((line_cap + 255) / 256), dim3(256), 0, st, text, lines, res, grain_start, n_grains, at_eof, out);
+    return hipGetLastError();
+}
+
+hipError_t qd_text_carry_info(const qd_rec* const recs[4], qd_scan_result* const results[4], int n_streams, const uint32_t n[4], hipStream_t st) {
     hipLaunchKernelGGL(carry_info, dim3(1), dim3(64), 0, st, recs[0], recs[1], recs[2], recs[3], results[0], results[1], results[2], results[3],
-                       n_streams, n);
+                       n_streams, n[0], n[1], n[2], n[3]);
     return hipGetLastError();
 }
 

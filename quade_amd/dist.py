@@ -94,6 +94,71 @@ def sum_counts_through_files(outdir, token, rank, world, counts, timeout=600.0):
     return total
 
 
+def allgather_bytes(outdir, token, rank, world, name, payload, timeout=3600.0):
+    """Every rank publishes `payload` under name.<rank> in the rendezvous directory and reads all the others':
+    the list of the world's payloads in rank order.  (Small tables only: the grain indexes of a shared chunk.)"""
+    d = rendezvous_dir(outdir, token)
+    os.makedirs(d, exist_ok=True)
+    mine = os.path.join(d, "%s.%d" % (name, rank))
+    with open(mine + ".tmp", "wb") as fh:
+        fh.write(payload)
+    os.replace(mine + ".tmp", mine)
+    out = []
+    t0 = time.time()
+    for r in range(world):
+        p = os.path.join(d, "%s.%d" % (name, r))
+        while not os.path.exists(p):
+            if time.time() - t0 > timeout:
+                raise RuntimeError("rank %d: rank %d never published %s" % (rank, r, name))
+            time.sleep(0.005)
+        with open(p, "rb") as fh:
+            out.append(fh.read())
+    return out
+
+
+def plan_parts(tables, world):
+    """One chunk cut across `world` ranks.  tables[s] = the grains of stream s in file order (every rank's
+    qd_pipe_index output, concatenated): dicts {file_offset, n_lines, kept[4], skip_bytes[4], incomplete[4]}.  The reference pairs
+    kept record j of every stream counted from the start of the chunk (src/Quade.py:210-221): adding the grains' line counts up
+    gives every grain's residue (lines before it, mod 4), hence which of its four counts is the true one; the running sum of
+    those is the index of a grain's first kept record.  The chunk holds N = min over the streams of their kept records pairs;
+    rank r takes pairs [r N / world, (r + 1) N / world) and starts every stream at the grain that holds its first one.
+    Returns a list of `world` parts ({"start_offset", "skip_bytes", "skip_kept": [4 values], "max_pairs"}; None for a rank
+    without pairs), or None when the chunk cannot be cut (a table missing, a record reaching beyond what its rank looked at)."""
+    import bisect
+    first, resid, totals = [], [], []
+    for grains in tables:
+        if grains is None or not grains:
+            return None
+        phase, k, ks, ps = 0, 0, [0], []
+        for g in grains:
+            ps.append(phase)
+            if g["incomplete"][phase]:
+                return None
+            k += g["kept"][phase]
+            ks.append(k)
+            phase = (phase + g["n_lines"]) & 3
+        first.append(ks)
+        resid.append(ps)
+        totals.append(k)
+    n_pairs = min(totals)
+    parts = []
+    for r in range(world):
+        a, b = r * n_pairs // world, (r + 1) * n_pairs // world
+        if b <= a:
+            parts.append(None)
+            continue
+        part = {"start_offset": [0] * 4, "skip_bytes": [0] * 4, "skip_kept": [0] * 4, "max_pairs": b - a}
+        for s, grains in enumerate(tables):
+            g0 = bisect.bisect_right(first[s], a) - 1  # the grain that holds kept record a of this stream
+            g = grains[g0]
+            part["start_offset"][s] = g["file_offset"]
+            part["skip_bytes"][s] = g["skip_bytes"][resid[s][g0]]
+            part["skip_kept"][s] = a - first[s][g0]
+        parts.append(part)
+    return parts
+
+
 # ---- chunk-sharded runs of the command line (one process per GPU) -----------------------------------
 def chunk_owner(chunk_index, world):
     """Chunk files are the natural shard unit (src/Quade.py:198,229): chunk c -> rank c mod world."""

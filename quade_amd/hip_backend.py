@@ -59,7 +59,13 @@ class qd_slot_buffers(C.Structure):
 
 class qd_pipe_chunk(C.Structure):
     _fields_ = [("r1", C.c_char_p), ("r2", C.c_char_p), ("i1", C.c_char_p), ("i2", C.c_char_p), ("sink", C.c_void_p),
-                ("begin_message", C.c_char_p), ("end_message", C.c_char_p)]
+                ("begin_message", C.c_char_p), ("end_message", C.c_char_p),
+                ("start_offset", C.c_int64 * 4), ("skip_bytes", C.c_int64 * 4), ("skip_kept", C.c_int64 * 4), ("max_pairs", C.c_int64)]
+
+
+class qd_grain_info(C.Structure):
+    _fields_ = [("file_offset", C.c_int64), ("n_lines", C.c_uint32), ("kept", C.c_uint32 * 4), ("skip_bytes", C.c_uint32 * 4),
+                ("incomplete", C.c_uint32 * 4)]
 
 
 class qd_pipe_stats(C.Structure):
@@ -159,6 +165,7 @@ SYMBOLS = [
     ("qd_pipe_create", C.c_int, [_P, C.POINTER(_P)]),
     ("qd_pipe_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("qd_pipe_run", C.c_int, [_P, C.POINTER(qd_pipe_chunk), C.c_int32, C.POINTER(qd_pipe_stats)]),
+    ("qd_pipe_index", C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(qd_grain_info), C.c_int32, C.POINTER(C.c_int32)]),
     ("qd_pipe_last_error", C.c_char_p, [_P]),
     ("qd_pipe_destroy", C.c_int, [_P]),
     ("qd_dev_fastq_scan", C.c_int64, [C.c_int, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _P, C.c_int64, _P]),
@@ -612,14 +619,40 @@ class Pipe(object):
         if r != QD_OK:
             raise QuadeHipError(r, self.lib.qd_pipe_last_error(self._h).decode())
 
+    def index(self, path, world, rank, grains_per_rank=8):
+        """This rank's grains of the BGZF file `path` for a chunk that `world` ranks share (qd_pipe_index): a list of dicts
+        {file_offset, n_lines, kept[4], skip_bytes[4], incomplete[4]}, or None when the file cannot be shared this way."""
+        arr = (qd_grain_info * grains_per_rank)()
+        n = C.c_int32(0)
+        r = self.lib.qd_pipe_index(self._h, str(path).encode(), int(world), int(rank), int(grains_per_rank), arr, grains_per_rank, C.byref(n))
+        if r == QD_ERR_UNSUPPORTED:
+            return None
+        if r != QD_OK:
+            msg = self.lib.qd_pipe_last_error(self._h).decode()
+            if r == QD_ERR_FORMAT:
+                raise IOError(msg)
+            raise QuadeHipError(r, msg)
+        return [{"file_offset": int(g.file_offset), "n_lines": int(g.n_lines), "kept": [int(x) for x in g.kept],
+                 "skip_bytes": [int(x) for x in g.skip_bytes], "incomplete": [int(x) for x in g.incomplete]} for g in arr[:n.value]]
+
     def run(self, chunks):
-        """chunks: list of (r1, r2, i1, i2 or None, sink handle, begin message or None, end message or None).
+        """chunks: list of (r1, r2, i1, i2 or None, sink handle, begin message or None, end message or None[, part]) where part
+        (a chunk that several ranks share: dist.plan_parts) = {"start_offset": [4], "skip_bytes": [4], "skip_kept": [4], "max_pairs": n}.
         Returns the statistics as a dict."""
         def enc(x):
             return None if x is None else (x if isinstance(x, bytes) else str(x).encode())
         arr = (qd_pipe_chunk * max(len(chunks), 1))()
-        for i, (r1, r2, i1, i2, sink, m0, m1) in enumerate(chunks):
-            arr[i] = qd_pipe_chunk(enc(r1), enc(r2), enc(i1), enc(i2), sink, enc(m0), enc(m1))
+        for i, ch in enumerate(chunks):
+            r1, r2, i1, i2, sink, m0, m1 = ch[:7]
+            part = ch[7] if len(ch) > 7 and ch[7] else None
+            z = (C.c_int64 * 4)(0, 0, 0, 0)
+            arr[i] = qd_pipe_chunk(enc(r1), enc(r2), enc(i1), enc(i2), sink, enc(m0), enc(m1), z, z, z, 0)
+            if part:
+                for k in range(4):
+                    arr[i].start_offset[k] = int(part["start_offset"][k])
+                    arr[i].skip_bytes[k] = int(part["skip_bytes"][k])
+                    arr[i].skip_kept[k] = int(part["skip_kept"][k])
+                arr[i].max_pairs = int(part["max_pairs"])
         st = qd_pipe_stats()
         r = self.lib.qd_pipe_run(self._h, arr, len(chunks), C.byref(st))
         if r != QD_OK:

@@ -134,6 +134,12 @@ class Quade(object):
         # pipeline over pinned slots below.
         self.use_pipe = bool(cf.device_pipeline and cf.device_inflate and cf.device_deflate and cf.gzip_level in (-1, 1)
                              and self.workers == 1 and len(devices) == 1)
+        # One chunk across several ranks (SURVEY.md 8e "large single chunks are split into contiguous row ranges"): with fewer chunks
+        # than ranks ([gpu] shard_chunks : auto, the default) or always (True), every rank takes a pair range of EVERY chunk
+        # (quade_amd/dist.py plan_parts); needs the device pipeline and BGZF inputs, falls back to one rank per chunk otherwise
+        self.shard = bool(self.world > 1 and self.use_pipe and
+                          (cf.shard_chunks == "true" or (cf.shard_chunks == "auto" and n_chunks < self.world)))
+        self.n_parts = n_chunks * self.world if self.shard else n_chunks
         self.engine_groups = []
         for _ in range(self.workers):
             group = []
@@ -176,7 +182,7 @@ class Quade(object):
                 dist.barrier_through_files(self.outdir, self.token, self.rank, self.world, "closed")
             stems = [s.name + q for s in Sample.SAMPLE_LIST for q in ("_pass", "_fail")] + ["Undetermined"]
             with _timed("merge chunk parts"):
-                dist.merge_parts(self.outdir, n_chunks, self.rank, self.world,
+                dist.merge_parts(self.outdir, self.n_parts, self.rank, self.world,
                                  names=[st + r + ".fastq.gz" for st in stems for r in ("_R1", "_R2")])
             if self.world > 1:
                 dist.barrier_through_files(self.outdir, self.token, self.rank, self.world, "merged")
@@ -257,7 +263,7 @@ class Quade(object):
         from .sample import WriterSet
         mine = [c for c in range(len(chunks)) if chunk_owner(c, self.world) == self.rank]
         if self.use_pipe:
-            return self._run_chunks_on_device(chunks, mine, banner)
+            return self._run_chunks_on_device(chunks, list(range(len(chunks))) if self.shard else mine, banner)
 
         def one_chunk(c, streams, engines):
             print(banner.format(c + 1, len(chunks)))
@@ -322,9 +328,10 @@ class Quade(object):
         eng = self.engine_groups[0][0]
         part_writers = []
         args = []
-        for c in mine:
+
+        def one(c, part_index, part=None):
             if self.parts:
-                d = part_dir(self.outdir, c)
+                d = part_dir(self.outdir, part_index)
                 os.makedirs(d, exist_ok=True)
                 ws = WriterSet(d, self.cf.gzip_level, deflate_device=-1)
                 part_writers.append(ws)
@@ -333,12 +340,53 @@ class Quade(object):
                     Sample.WRITERS = WriterSet(Sample.OUTDIR, Sample.GZIP_LEVEL, deflate_device=-1)
                 ws = Sample.WRITERS
             f = list(chunks[c]) + [None] * (4 - len(chunks[c]))
-            args.append((f[0], f[1], f[2], f[3], ws.handle(), banner.format(c + 1, len(chunks)) + "\n",
-                         "\tEnd of chunk {}\n".format(c + 1)))
+            return (f[0], f[1], f[2], f[3], ws.handle(), banner.format(c + 1, len(chunks)) + "\n",
+                    "\tEnd of chunk {}\n".format(c + 1), part)
         try:
             with hb.Pipe(eng, self.cf.batch_pairs if self.cf.batch_pairs_given else 2000000) as pipe:
-                with _timed("device pipeline"):
-                    self.pipe_stats = pipe.run(args)
+                if not self.shard:
+                    args = [one(c, c) for c in mine]
+                    with _timed("device pipeline"):
+                        self.pipe_stats = pipe.run(args)
+                    return
+                # shared chunks: index pass (every rank its grains of every stream), the tables exchanged, the parts planned
+                # identically on every rank, then this rank's pair range of the chunk
+                import json
+                from . import dist
+                self.pipe_stats = None
+                self.shared_chunks = 0
+                for c in mine:
+                    with _timed("index pass"):
+                        mine_tables = [pipe.index(f, self.world, self.rank) for f in chunks[c]]
+                    got = dist.allgather_bytes(self.outdir, self.token, self.rank, self.world, "index.c%d" % c, json.dumps(mine_tables).encode())
+                    per_rank = [json.loads(b.decode()) for b in got]
+                    tables = []
+                    for s in range(len(chunks[c])):
+                        t = []
+                        for r in range(self.world):
+                            t = None if (t is None or per_rank[r][s] is None) else t + per_rank[r][s]
+                        tables.append(t)
+                    parts = None if any(t is None for t in tables) else dist.plan_parts(tables, self.world)
+                    if parts is None:  # not BGZF, or a record longer than the overlap: the chunk stays with one rank
+                        if dist.chunk_owner(c, self.world) != self.rank:
+                            continue
+                        run = [one(c, c * self.world)]
+                    else:
+                        self.shared_chunks += 1
+                        if parts[self.rank] is None:
+                            continue
+                        part = dict(parts[self.rank])
+                        print("\tchunk {} is cut across {} ranks: {} pairs here".format(c + 1, self.world, part["max_pairs"]))
+                        for key in ("start_offset", "skip_bytes", "skip_kept"):  # single index: three streams
+                            part[key] = (list(part[key]) + [0, 0, 0, 0])[:4]
+                        run = [one(c, c * self.world + self.rank, part)]
+                    with _timed("device pipeline"):
+                        st = pipe.run(run)
+                    if self.pipe_stats is None:
+                        self.pipe_stats = st
+                    else:
+                        for k in st:
+                            self.pipe_stats[k] += st[k]
         finally:
             for ws in part_writers:
                 ws.close()

@@ -68,3 +68,61 @@ def hip_on_device(engine, seq, qual, n, lens=None):
     torch.cuda.synchronize()
     c = codes.cpu().numpy().view(np.uint16)[:n]
     return c, (mol.cpu().numpy()[:n] if M else None)
+
+
+# ---- a chunk shared by several ranks: the grain tables by definition (pure Python) -------------------------------------------
+def grain_tables_model(text, grain_starts):
+    """What qd_pipe_index reports for the text of one whole file cut at grain_starts (ascending text offsets, the first is 0):
+    per grain {n_lines, kept[4], skip_bytes[4]} with kept[q] = kept records whose header line STARTS in the grain when (lines
+    before the grain) mod 4 == q.  Rules of oracle.FastqReader: 4-line records, a trailing '\\r' is not part of a line, a last
+    line without newline counts, a record is kept when sequence and quality have one length."""
+    data = text if (not text or text.endswith(b"\n")) else text + b"\n"
+    ends, pos = [], 0
+    while True:
+        e = data.find(b"\n", pos)
+        if e < 0:
+            break
+        ends.append(e)
+        pos = e + 1
+    bounds = list(grain_starts) + [len(data) + 1]
+    out = []
+    for g in range(len(grain_starts)):
+        lo, hi = bounds[g], bounds[g + 1]
+        first_line = sum(1 for e in ends if e < lo)
+        n_lines = sum(1 for e in ends if lo <= e < hi)
+        kept, first = [0] * 4, [None] * 4
+        for i in range(len(ends)):
+            head = ends[i - 1] + 1 if i else 0
+            if not (lo <= head < hi) or i + 3 >= len(ends):
+                continue
+            q = (first_line - i) & 3
+            seq = data[ends[i] + 1:ends[i + 1]]
+            qual = data[ends[i + 2] + 1:ends[i + 3]]
+            seq = seq[:-1] if seq.endswith(b"\r") else seq
+            qual = qual[:-1] if qual.endswith(b"\r") else qual
+            if len(seq) == len(qual):
+                kept[q] += 1
+                if first[q] is None:
+                    first[q] = head - lo
+        out.append({"n_lines": n_lines, "kept": kept, "skip_bytes": [0xFFFFFFFF if f is None else f for f in first],
+                    "incomplete": [0, 0, 0, 0], "file_offset": lo})
+    return out
+
+
+def kept_records(text):
+    """(head offset, record bytes) of the kept records of a whole file, sequentially (oracle.FastqReader's rules)."""
+    data = text if (not text or text.endswith(b"\n")) else text + b"\n"
+    lines, starts, pos = [], [], 0
+    while True:
+        e = data.find(b"\n", pos)
+        if e < 0:
+            break
+        lines.append(data[pos:e])
+        starts.append(pos)
+        pos = e + 1
+    out = []
+    for r in range(len(lines) // 4):
+        seq, qual = [ln[:-1] if ln.endswith(b"\r") else ln for ln in (lines[4 * r + 1], lines[4 * r + 3])]
+        if len(seq) == len(qual):
+            out.append((starts[4 * r], b"\n".join(lines[4 * r:4 * r + 4]) + b"\n"))
+    return out

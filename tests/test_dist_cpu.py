@@ -133,3 +133,53 @@ def test_launcher_tears_the_job_down_when_a_rank_fails(tmp_path):
     assert r.returncode == 7 and time.time() - t0 < 60
     seen = [(tmp_path / ("seen.%d" % i)).read_text().split() for i in range(3)]
     assert len({s[0] for s in seen}) == 1 and all(s[1] == "3" for s in seen)
+
+
+def test_plan_parts_reproduces_the_sequential_pairing():
+    """One chunk cut across ranks (quade_amd/dist.py plan_parts): whatever the grain boundaries -- in the middle of
+    lines and records -- and with records dropped upstream of the cuts, rank r's part must hold exactly the pairs
+    [r N / world, (r + 1) N / world) of the sequential lock-step pairing (src/Quade.py:210-221)."""
+    import numpy as np
+    from quade_amd import dist
+    from tests import helpers as H
+    rng = np.random.default_rng(31)
+    for trial in range(12):
+        n = int(rng.integers(40, 400))
+        texts = []
+        for s in range(4):
+            recs = []
+            for i in range(n + int(rng.integers(0, 5))):
+                L = int(rng.integers(0, 40))
+                seq = bytes(rng.choice(list(b"ACGT"), L).astype(np.uint8))
+                qual = bytes(rng.integers(33, 74, L).astype(np.uint8))
+                if rng.integers(0, 25) == 0:
+                    qual += b"I"  # dropped inside its own stream: every later record of the stream shifts
+                recs.append(b"@r%d:%d x\n" % (s, i) + seq + b"\n+\n" + qual + b"\n")
+            t = b"".join(recs)
+            if trial % 3 == 0:
+                t = t[:-1]  # no final newline
+            texts.append(t)
+        world = int(rng.integers(2, 6))
+        tables, cuts_all = [], []
+        for t in texts:
+            G = world * int(rng.integers(1, 4))
+            cuts = [0] + sorted(int(x) for x in rng.choice(np.arange(1, len(t)), size=G - 1, replace=False))
+            tables.append(H.grain_tables_model(t, cuts))
+            cuts_all.append(cuts)
+        parts = dist.plan_parts(tables, world)
+        seq = [H.kept_records(t) for t in texts]
+        N = min(len(k) for k in seq)
+        got = []
+        for r, part in enumerate(parts):
+            a, b = r * N // world, (r + 1) * N // world
+            if part is None:
+                assert a == b
+                continue
+            assert part["max_pairs"] == b - a
+            for s, t in enumerate(texts):
+                start = part["start_offset"][s] + part["skip_bytes"][s]   # (in this model a grain's file offset IS its text offset)
+                tail = H.kept_records(t[start:])                             # a reader started at that byte ...
+                mine = tail[part["skip_kept"][s]:part["skip_kept"][s] + part["max_pairs"]]
+                assert [x[1] for x in mine] == [x[1] for x in seq[s][a:b]], (trial, r, s)
+            got.append((a, b))
+        assert sum(b - a for a, b in got) == N
