@@ -182,3 +182,33 @@ def test_full_totals_as_eight_sequential_shards(name, total):
     assert counts[0] == total == counts[1] + counts[2] + counts[3]
     assert (counts[4:] == total_hist).all() and counts[3] == undet
     assert counts[1] == total_hist[0::2].sum() and counts[2] == total_hist[1::2].sum()
+
+
+@needs_two
+def test_one_chunk_cut_across_real_ranks_matches_the_oracle(tmp_path):
+    """A single chunk and N ranks on N GPUs (real RCCL count reduce): [gpu] shard_chunks : auto cuts the chunk into pair ranges over all
+    ranks (index pass per rank, tables exchanged, parts planned identically everywhere); records dropped upstream of the cuts keep
+    their effect on the pairing -> the oracle's sequential run, byte for byte (the 1-GPU rehearsal:
+    tests/test_gpu_text.py::test_shared_chunk_three_ranks_vs_oracle)."""
+    from tests.test_gpu_e2e import _conf
+    from tests.test_gpu_text import _dataset as _bgzf_dataset
+    rng = np.random.default_rng(92)
+    data = tmp_path / "data"
+    data.mkdir()
+    n = 12000
+    files, samples = _bgzf_dataset(str(data), rng, 1, n, 6, fmt="bgzf", read_len=100, trunc=True,
+                                   malformed={(0, "seq_R1", 7), (0, "index_R2", n // 2), (0, "seq_R2", n - 3)})
+    conf = tmp_path / "conf.txt"
+    _conf(str(conf), files, True, ((1, 8), (1, 8), (9, 14), None), 25, samples, (True, True, True), "[gpu]\nbatch_pairs : 1500\n")
+    ref_dir, my_dir = tmp_path / "ref", tmp_path / "mine"
+    ref_dir.mkdir()
+    my_dir.mkdir()
+    qo.run_quade(str(conf), outdir=str(ref_dir))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "QUADE_DIST_TRANSPORT", "QUADE_DEVICE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "quade_amd.launch", "-n", str(N_RANKS), "-c", str(conf)], cwd=str(my_dir), env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.stdout.count("is cut across %d ranks" % N_RANKS) == N_RANKS, r.stdout[-2000:]
+    _same_outputs(str(my_dir), str(ref_dir))
