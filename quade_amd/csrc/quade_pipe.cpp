@@ -1743,6 +1743,10 @@ int qd_pipe_run(qd_pipe* p, const qd_pipe_chunk* chunks, int32_t n_chunks, qd_pi
         p->r1_compressed = p->r1_compressed || (n >= 3 && strcmp(chunks[c].r1 + n - 3, ".gz") == 0) || (n >= 3 && strcmp(chunks[c].r1 + n - 3, ".GZ") == 0);
     }
     p->reserved = false;
+    {
+        std::lock_guard<std::mutex> g(p->om);
+        for (OutSet& o : p->out) o.busy = false;  // (a run that failed half way may have left one taken)
+    }
     std::vector<std::unique_ptr<Feeder>> feeders;
     for (int s = 0; s < ns; ++s) {
         std::vector<FileSpec> files;

@@ -408,3 +408,17 @@ def test_shared_chunk_three_ranks_vs_oracle(tmp_path):
     _compare_dirs(str(my_dir), str(ref_dir))
     with open(my_dir / "Quade_report.csv") as fh:
         assert "Total pair\t%d" % sset.counts()[0] in fh.read()
+
+
+def test_pipeline_many_samples_and_empty_streams(tmp_path):
+    """300 samples (601 destinations: the two-pass radix sort, hundreds of small pieces per batch), a chunk whose index_R2 file is empty
+    (the chunk ends at once, src/Quade.py:223-224), an entirely empty chunk, and a normal one behind them."""
+    rng = np.random.default_rng(15)
+    data = tmp_path / "data"
+    data.mkdir()
+    files, samples = _dataset(str(data), rng, 3, 4000, 300, fmt="bgzf", malformed={(2, "seq_R1", 100)})
+    _bgzip(files["index_R2"][0], b"")
+    for k in files:
+        _bgzip(files[k][1], b"")
+    st = _run_and_compare(tmp_path, files, samples, "[gpu]\nbatch_pairs : 1500\n")
+    assert st["pairs"] == 3999
