@@ -277,14 +277,75 @@ __device__ __forceinline__ int slow_sym(uint32_t bits, const uint16_t* count, co
     return -1;
 }
 
-// Tokens from bit `pos` on while they start before `limit`.  WRITE: literals -> ob[o...], matches -> list[m...].
-template <bool WRITE>
+// What a lane keeps of its last decode of its span: the result, and the first token boundary at or behind each of three marks
+// early in the span with the counts up to there.  A later decode of the span from another start that lands on one of these
+// boundaries has joined the old path -- the rest would be the same tokens -- and takes the old result from there on: Huffman
+// codes resynchronise within a few symbols, so the second round of a block decodes a fifth of a span instead of all of it.
+struct SpanMemo {
+    uint32_t pos[3], out[3], mat[3];  // pos 0xFFFFFFFF: none
+    uint32_t ex, no, nm, fl;
+};
+#ifndef QD_INFLATE2_MEMO
+#define QD_INFLATE2_MEMO 1 /* A/B: 0 = every round decodes whole spans */
+#endif
+constexpr uint32_t MEMO_STEP = 40;  // bits between the marks
+
+// Tokens from bit `pos` on while they start before `limit`.  WRITE: literals -> ob[o...], matches -> list[m...].  MEMO (counting
+// rounds): `memo` is read (the lane's last decode, if any) and rewritten; mark0 = the first mark (a property of the span, not of the start).
+template <bool WRITE, bool MEMO = false>
 __device__ __forceinline__ void decode_span(const uint32_t* pw, uint32_t total_bits, const Lds& L, int nlsym, int ndsym, uint32_t pos,
                                             uint32_t limit, uint8_t* ob, uint32_t o, uint32_t olen, unsigned long long* list, uint32_t m,
-                                            uint32_t mcap, uint32_t& exit_pos, uint32_t& n_out, uint32_t& n_mat, uint32_t& flag) {
+                                            uint32_t mcap, uint32_t& exit_pos, uint32_t& n_out, uint32_t& n_mat, uint32_t& flag,
+                                            SpanMemo* memo = nullptr, uint32_t mark0 = 0) {
     uint32_t out = 0, mat = 0, fl = 0;
+    SpanMemo nw;
+    uint32_t nrec = 0;
+    if (MEMO) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) nw.pos[k] = 0xFFFFFFFFu;
+    }
 #pragma unroll 1
     for (int guard = 0; guard < 70000 && pos < limit; ++guard) {
+        if (MEMO) {
+            // joined the last decode's path?
+            int hit = -1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (pos == memo->pos[k]) hit = k;
+            if (hit >= 0) {
+                uint32_t oo = 0, om = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if (k == hit) {
+                        oo = memo->out[k];
+                        om = memo->mat[k];
+                    }
+                const uint32_t d_out = out - oo, d_mat = mat - om;  // (what this decode counted up to here, less what the old one had)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if ((uint32_t)k >= nrec && memo->pos[k] != 0xFFFFFFFFu && memo->pos[k] >= pos) {  // the marks still ahead: the old path's
+                        nw.pos[k] = memo->pos[k];
+                        nw.out[k] = memo->out[k] + d_out;
+                        nw.mat[k] = memo->mat[k] + d_mat;
+                    }
+                out = memo->no + d_out;
+                mat = memo->nm + d_mat;
+                fl = memo->fl;
+                pos = memo->ex;
+                break;
+            }
+            // the first boundary at or behind the next mark
+            if (nrec < 3 && pos >= mark0 + nrec * MEMO_STEP) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if ((uint32_t)k == nrec) {
+                        nw.pos[k] = pos;
+                        nw.out[k] = out;
+                        nw.mat[k] = mat;
+                    }
+                ++nrec;
+            }
+        }
         if (pos >= total_bits) {
             fl = F_ERR_TRUNC;
             break;
@@ -355,6 +416,13 @@ __device__ __forceinline__ void decode_span(const uint32_t* pw, uint32_t total_b
     n_out = out;
     n_mat = mat;
     flag = fl;
+    if (MEMO) {
+        nw.ex = pos;
+        nw.no = out;
+        nw.nm = mat;
+        nw.fl = fl;
+        *memo = nw;
+    }
 }
 
 template <int NT>
@@ -542,12 +610,15 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
         __syncthreads();
         uint32_t eob_lane = NT;
         uint32_t ex = 0, no = 0, nm = 0, fl = 0, decoded_from = 0xFFFFFFFFu;
+        SpanMemo memo;
+        memo.pos[0] = memo.pos[1] = memo.pos[2] = 0xFFFFFFFFu;
+        const uint32_t mark0 = bitpos + tid * span + MEMO_STEP;
 #pragma unroll 1
         for (int round = 0; round <= QD_INFLATE2_MAX_ROUNDS; ++round) {
             const uint32_t st = S.start[tid];
             // (a lane whose start did not move keeps what it found: the confirming rounds decode only the spans that still change)
             if (st != decoded_from) {
-                decode_span<false>(pw, total_bits, L, lit_codes, dist_codes, st, my_limit, ob, 0, olen, list, 0, mcap, ex, no, nm, fl);
+                decode_span<false, QD_INFLATE2_MEMO != 0>(pw, total_bits, L, lit_codes, dist_codes, st, my_limit, ob, 0, olen, list, 0, mcap, ex, no, nm, fl, &memo, mark0);
                 decoded_from = st;
             }
             S.exitp[tid] = ex;

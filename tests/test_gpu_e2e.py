@@ -73,8 +73,9 @@ def _write_fastq(path, names, seqs, quals, plus="+"):
             fh.write(("@%s\n%s\n%s\n%s\n" % (n, s, plus, q)).encode("latin-1"))
 
 
-def _make_dataset(d, rng, n_chunks, n, dual, idx_len, barcodes, trunc=False, malformed=False, plain=False):
-    """barcodes: list of (b1, b2) expected at the start of index read 1 / 2."""
+def _make_dataset(d, rng, n_chunks, n, dual, idx_len, barcodes, trunc=False, malformed=False, plain=False, bgzf=False):
+    """barcodes: list of (b1, b2) expected at the start of index read 1 / 2.  bgzf: the .gz files in bgzip's block layout (what the
+    device inflates) instead of one gzip member."""
     ext = ".fastq" if plain else ".fastq.gz"
     files = {"seq_R1": [], "seq_R2": [], "index_R1": [], "index_R2": []}
     for c in range(n_chunks):
@@ -117,6 +118,11 @@ def _make_dataset(d, rng, n_chunks, n, dual, idx_len, barcodes, trunc=False, mal
                 continue
             p = os.path.join(d, "C%d_%s%s" % (c, key, ext))
             _write_fastq(p, nm, ss, qs, plus="+" if c % 2 == 0 else "+" + "x")
+            if bgzf and not plain:
+                from quade_amd import hip_backend as hb
+                text = _gz(p)
+                buf = np.frombuffer(text, dtype=np.uint8) if text else np.zeros(1, np.uint8)
+                assert hb.load_library().qd_write_gzip_file(p.encode(), hb._ptr(buf), len(text), 1, -1) == 0
             files[key].append(p)
     return files
 
@@ -390,10 +396,12 @@ def test_random_conf_end_to_end_fuzz(tmp_path):
         data.mkdir()
         files = _make_dataset(str(data), rng, int(rng.integers(1, 5)), int(rng.integers(1, 90)), dual, idx_len, emb,
                               trunc=bool(rng.integers(0, 3) == 0), malformed=bool(rng.integers(0, 3) == 0),
-                              plain=bool(rng.integers(0, 4) == 0))
+                              plain=bool(rng.integers(0, 4) == 0), bgzf=bool(rng.integers(0, 2)))
         flags = tuple(bool(rng.integers(0, 4) > 0) for _ in range(3))
-        gpu = "[gpu]\nbatch_pairs : %d\nslots : %d\nchunk_workers : %d\n" % (
-            int(rng.integers(1, 60)), int(rng.integers(1, 4)), int(rng.integers(1, 4)))
+        # half of the cases through the device-resident chunk pipeline (one chunk worker), the others over pinned slots
+        gpu = "[gpu]\nbatch_pairs : %d\nslots : %d\nchunk_workers : %d\ngzip_level : %d\n" % (
+            int(rng.integers(1, 60)), int(rng.integers(1, 4)), 1 if rng.integers(0, 2) else int(rng.integers(2, 4)),
+            [1, 1, -1, 6][int(rng.integers(0, 4))])
         samples = [("S%d" % i, b1, b2) for i, (b1, b2) in enumerate(bcs)]
         conf = d / "conf.txt"
         _conf(str(conf), files, dual, (i1, i2, m1, m2), int(rng.integers(0, 41)), samples, flags, gpu)
