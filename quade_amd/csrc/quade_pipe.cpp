@@ -71,7 +71,7 @@ struct Tick {  // adds the wall time of its scope to a counter
     explicit Tick(double& a) : acc(a) {}
     ~Tick() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
-double g_alloc_seconds = 0;  // (driver thread only)
+thread_local double g_alloc_seconds = 0;  // (device allocations are made by the driving thread)
 
 struct DevBuf {  // grow-only device allocation
     uint8_t* p = nullptr;
