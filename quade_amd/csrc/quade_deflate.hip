@@ -529,14 +529,17 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
             if (p + 4 <= L) {
                 const uint32_t h = (a[0] * 2654435761u) >> (32 - LZ_HASH_BITS);
                 const uint32_t bucket = table[h];
-                if (p >= 1) {  // a run (the nearest candidate there is)
+                // (a candidate is compared in full only when its first 4 bytes are this position's: shorter matches are never taken, and
+                //  most bucket entries are hash collisions -- the lanes that drop out issue no LDS reads, which is where this kernel's time goes)
+                if (p >= 1 && rd32(tw, p - 1) == a[0]) {  // a run (the nearest candidate there is)
                     best = same32(tw, a, p - 1);
                     dist = 1;
                 }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {  // nearest first: a later candidate must be longer to win
                     const uint32_t c = (bucket >> (16 * k)) & 0xFFFFu;
-                    const uint32_t n = same32(tw, a, c);  // (any entry is a position inside the text: only a guess until compared)
+                    uint32_t n = 0;
+                    if (c < p && rd32(tw, c) == a[0]) n = same32(tw, a, c);  // (any entry is a position inside the text: only a guess until compared)
                     if (c < p && p - c <= 32768u && n > best) {
                         best = n;
                         dist = p - c;

@@ -291,12 +291,14 @@ class Feeder {
     int take_slot() {
         const int s = slot_next_;
         slot_next_ = (slot_next_ + 1) % RING_SLOTS;
+        int state;
         {
             std::unique_lock<std::mutex> g(m_);
             cv_.wait(g, [&] { return stop_ || state_[s] != 1; });
             if (stop_) return -1;
+            state = state_[s];
         }
-        if (state_[s] == 2 && wait_event_napping(consumed_[s]) != hipSuccess) return -1;
+        if (state == 2 && wait_event_napping(consumed_[s]) != hipSuccess) return -1;
         return s;
     }
     // pin[0 .. n) -> a ring slot; the segment goes to the driver
@@ -1568,7 +1570,11 @@ int index_stream(qd_pipe* p, const char* path, int32_t world, int32_t rank, int3
     w.runs.clear();
     w.avg = 0;
     w.line_cap = 0;
-    const size_t saved_max = p->window_max;
+    struct WindowMax {  // the index pass holds a rank's whole share of a stream in one window
+        qd_pipe* p;
+        size_t saved;
+        ~WindowMax() { p->window_max = saved; }
+    } restore{p, p->window_max};
     p->window_max = (size_t)3500 << 20;
     std::vector<FileSpec> files(1);
     files[0].path = path;
@@ -1577,10 +1583,7 @@ int index_stream(qd_pipe* p, const char* path, int32_t world, int32_t rank, int3
     // (start == 0 would read "the whole file" semantics with end set: fine, the range form only needs end)
     Feeder f(p->device, files);
     hipError_t he = f.start();
-    if (he != hipSuccess) {
-        p->window_max = saved_max;
-        return pfail(p, QD_ERR_HIP, std::string("feeder: ") + hipGetErrorString(he));
-    }
+    if (he != hipSuccess) return pfail(p, QD_ERR_HIP, std::string("feeder: ") + hipGetErrorString(he));
     // the text offset of every block of the range, as its segments arrive
     std::vector<uint32_t> text_at;  // per block b_from + k
     uint64_t text_total = 0;
@@ -1666,7 +1669,6 @@ int index_stream(qd_pipe* p, const char* path, int32_t world, int32_t rank, int3
         }
     }
     f.stop();
-    p->window_max = saved_max;
     w.len = 0;
     w.eof = false;
     w.line_cap = 0;
