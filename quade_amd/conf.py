@@ -23,8 +23,8 @@ Optional [gpu] section (not in Quade 0.3.2; a conf file without it runs with the
   device_pipeline : True the whole chunk loop on the GPU (libquade_hip qd_pipe_run): BGZF blocks inflated, records found, index rows
                          packed and matched, records scattered by routing code, formatted, CRC-32'd and coded into gzip members with
                          the fastq text staying in device memory; only compressed bytes cross PCIe (17-21 M pairs/s at 0.06-0.12
-                         core-s per M pairs on one MI355X).  Needs device_inflate, device_deflate, gzip_level 1 or -1, one device and
-                         one chunk worker per process; anything else runs the batch pipeline over pinned slots (7 M pairs/s at 1.5).
+                         core-s per M pairs on one MI355X).  Needs device_inflate, device_deflate and gzip_level 1 or -1 (one pipeline per device
+                         and chunk worker, chunks dealt out); anything else runs the batch pipeline over pinned slots (7 M pairs/s at 1.5).
                          Inputs that are not BGZF are inflated by the host's threads and join the device path as text
   shard_chunks : auto    under a launcher (one process per GPU): a chunk is cut into pair ranges over ALL ranks -- auto: when there are
                          fewer chunks than ranks, True: always, False: never (chunk c belongs to rank c mod N).  Needs the device
@@ -39,7 +39,7 @@ Optional [gpu] section (not in Quade 0.3.2; a conf file without it runs with the
                          random ones (41.9 %; 40.3 / 43.2 %); levels 2-9 are libdeflate on the host's pool (level 6: 1.6 M pairs/s).
                          The device's level-1 files are not byte-reproducible from run to run (their decompressed content is).
                          The reference writes with Python's gzip default (9); only the decompressed bytes are its format
-  chunk_workers : 1      chunks processed concurrently by host threads (pinned-slots path; outputs identical)
+  chunk_workers : 1      chunks processed concurrently (a pipeline / a slot set each; outputs identical)
   io_threads : 0         threads of the native I/O pool (0 = one per core)
   device_deflate : True  with gzip_level -1 or 1: the output members are made on the GPU (-1: Huffman coding only; 1: LZ77 + Huffman,
                          one workgroup per 64 KiB of formatted text); no effect at the other levels

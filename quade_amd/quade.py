@@ -129,15 +129,16 @@ class Quade(object):
         self.workers = max(1, min(cf.chunk_workers, len(my_chunks)))
         self.parts = self.world > 1 or self.workers > 1  # per-chunk part files, merged in chunk order
         # The whole chunk loop on the device (qd_pipe_*): inflate -> record scan -> rows -> match -> scatter -> format -> code
-        # with the text resident in HBM; one context drives it.  Anything it does not cover (several devices or chunk
-        # workers in one process, gzip levels the device does not code, the device stages switched off) takes the batch
-        # pipeline over pinned slots below.
-        self.use_pipe = bool(cf.device_pipeline and cf.device_inflate and cf.device_deflate and cf.gzip_level in (-1, 1)
-                             and self.workers == 1 and len(devices) == 1)
+        # with the text resident in HBM; a context drives one pipeline, several contexts (devices, chunk workers) one each
+        # with the chunks dealt out to them.  Anything it does not cover (gzip levels the device does not code, the device
+        # stages switched off) takes the batch pipeline over pinned slots below.
+        self.use_pipe = bool(cf.device_pipeline and cf.device_inflate and cf.device_deflate and cf.gzip_level in (-1, 1))
+        if self.use_pipe and self.workers * len(devices) > 1:
+            self.parts = True  # several pipelines (one per context: devices x chunk workers) each take whole chunks: per-chunk part files
         # One chunk across several ranks (SURVEY.md 8e "large single chunks are split into contiguous row ranges"): with fewer chunks
         # than ranks ([gpu] shard_chunks : auto, the default) or always (True), every rank takes a pair range of EVERY chunk
         # (quade_amd/dist.py plan_parts); needs the device pipeline and BGZF inputs, falls back to one rank per chunk otherwise
-        self.shard = bool(self.world > 1 and self.use_pipe and
+        self.shard = bool(self.world > 1 and self.use_pipe and self.workers * len(devices) == 1 and
                           (cf.shard_chunks == "true" or (cf.shard_chunks == "auto" and n_chunks < self.world)))
         self.n_parts = n_chunks * self.world if self.shard else n_chunks
         self.engine_groups = []
@@ -328,6 +329,7 @@ class Quade(object):
         eng = self.engine_groups[0][0]
         part_writers = []
         args = []
+        batch = self.cf.batch_pairs if self.cf.batch_pairs_given else 2000000
 
         def one(c, part_index, part=None):
             if self.parts:
@@ -343,7 +345,33 @@ class Quade(object):
             return (f[0], f[1], f[2], f[3], ws.handle(), banner.format(c + 1, len(chunks)) + "\n",
                     "\tEnd of chunk {}\n".format(c + 1), part)
         try:
-            with hb.Pipe(eng, self.cf.batch_pairs if self.cf.batch_pairs_given else 2000000) as pipe:
+            if len(self.engines) > 1:
+                # several contexts (devices, chunk workers): a pipeline each, the chunks dealt out round robin, one host thread
+                # per pipeline inside the native call (the GIL is released); every chunk writes its own part files
+                import threading
+                shares = [[one(c, c) for c in mine[i::len(self.engines)]] for i in range(len(self.engines))]
+                stats, errors = [None] * len(self.engines), []
+
+                def drive(i):
+                    try:
+                        with hb.Pipe(self.engines[i], batch) as pipe:
+                            stats[i] = pipe.run(shares[i])
+                    except BaseException as e:  # surfaced in the main thread
+                        errors.append(e)
+                threads = [threading.Thread(target=drive, args=(i,), name="quade-pipe-%d" % i) for i in range(len(self.engines)) if shares[i]]
+                with _timed("device pipelines"):
+                    for t in threads:
+                        t.start()
+                    for t in threads:
+                        t.join()
+                if errors:
+                    raise errors[0]
+                self.pipe_stats = {}
+                for st in stats:
+                    for k, v in (st or {}).items():
+                        self.pipe_stats[k] = self.pipe_stats.get(k, 0) + v
+                return
+            with hb.Pipe(eng, batch) as pipe:
                 if not self.shard:
                     args = [one(c, c) for c in mine]
                     with _timed("device pipeline"):

@@ -162,7 +162,8 @@ SCENARIOS = {
                               gpu="[gpu]\nbatch_pairs : 50\n"),
     "malformed_desync": dict(dual=True, idx_len=8, pos=((1, 8), (1, 8), None, None), minq=25, malformed=True,
                              gpu="[gpu]\nbatch_pairs : 16\nslots : 3\n"),
-    # two contexts (both on GPU 0 here) fed round-robin: output order must still equal input order
+    # two contexts (both on GPU 0 here): batches fed round-robin over pinned slots / a pipeline each with the chunks dealt out --
+    # output order must still equal input order
     "two_engines_round_robin": dict(dual=True, idx_len=8, pos=((1, 8), (1, 8), None, None), minq=25,
                                     gpu="[gpu]\ndevices : 0 0\nbatch_pairs : 23\nslots : 2\n"),
     # three host threads take chunks from a queue; per-chunk parts merged in chunk order
@@ -398,10 +399,10 @@ def test_random_conf_end_to_end_fuzz(tmp_path):
                               trunc=bool(rng.integers(0, 3) == 0), malformed=bool(rng.integers(0, 3) == 0),
                               plain=bool(rng.integers(0, 4) == 0), bgzf=bool(rng.integers(0, 2)))
         flags = tuple(bool(rng.integers(0, 4) > 0) for _ in range(3))
-        # half of the cases through the device-resident chunk pipeline (one chunk worker), the others over pinned slots
-        gpu = "[gpu]\nbatch_pairs : %d\nslots : %d\nchunk_workers : %d\ngzip_level : %d\n" % (
-            int(rng.integers(1, 60)), int(rng.integers(1, 4)), 1 if rng.integers(0, 2) else int(rng.integers(2, 4)),
-            [1, 1, -1, 6][int(rng.integers(0, 4))])
+        # half of the cases through the device-resident chunk pipeline (one pipeline per chunk worker), the others over pinned slots
+        gpu = "[gpu]\nbatch_pairs : %d\nslots : %d\nchunk_workers : %d\ngzip_level : %d\ndevice_pipeline : %s\n" % (
+            int(rng.integers(1, 60)), int(rng.integers(1, 4)), int(rng.integers(1, 4)), [1, 1, -1, 6][int(rng.integers(0, 4))],
+            bool(rng.integers(0, 2)))
         samples = [("S%d" % i, b1, b2) for i, (b1, b2) in enumerate(bcs)]
         conf = d / "conf.txt"
         _conf(str(conf), files, dual, (i1, i2, m1, m2), int(rng.integers(0, 41)), samples, flags, gpu)
