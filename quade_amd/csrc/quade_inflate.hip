@@ -29,7 +29,13 @@
 
 namespace {
 
-constexpr int LBITS = 10, DBITS = 8;         // first-level lookup widths
+#ifndef QD_INFLATE_LBITS
+#define QD_INFLATE_LBITS 10
+#endif
+#ifndef QD_INFLATE_DBITS
+#define QD_INFLATE_DBITS 8
+#endif
+constexpr int LBITS = QD_INFLATE_LBITS, DBITS = QD_INFLATE_DBITS;  // first-level lookup widths
 constexpr uint32_t WINDOW = 65536;           // BGZF: ISIZE <= 64 KiB
 struct Lds {                                  // dynamic LDS of one workgroup (= one wave): the tables only
     uint16_t llut[1 << LBITS];                // literal/length: symbol | code length << 9 (0 = longer code or none)

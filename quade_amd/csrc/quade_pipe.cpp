@@ -562,6 +562,7 @@ struct qd_pipe {
     std::string err;
     int64_t batch_pairs = 2000000;
     int64_t test_fail_inflate_batch = -1;  // option: the device "refuses" the BGZF blocks of this batch (the host inflates them)
+    int64_t test_host_code_every = 0;      // option: every k-th member is coded by the host as if the device had given it up
     qd_plan plan{};
     qd_layout lay{};
     hipStream_t cs = nullptr, ds = nullptr;
@@ -670,6 +671,8 @@ void collect_one(qd_pipe* p, BatchOut& b) {
         if (e == hipSuccess) e = hipEventRecord(o.done, p->ds);
         if (e == hipSuccess) e = wait_event_napping(o.done);
         const uint64_t total = e == hipSuccess ? off[b.n_pieces] : 0;
+        if (e == hipSuccess && p->test_host_code_every > 0)  // test option: every k-th member is treated as one the device gave up
+            for (uint32_t i = 0; i < b.n_pieces; i += (uint32_t)p->test_host_code_every) len[i] = 0;
         // members the device gave up (they did not fit their slots: text that does not compress): their text comes back instead
         std::vector<std::vector<uint8_t>> rescue(b.n_pieces);
         std::vector<uint8_t> text;
@@ -1720,6 +1723,7 @@ int qd_pipe_set_option(qd_pipe* p, const char* name, int64_t value) {
     const std::string n(name);
     if (n == "batch_pairs" && value >= 1) p->batch_pairs = value;
     else if (n == "test_fail_inflate_batch") p->test_fail_inflate_batch = value;
+    else if (n == "test_host_code_every" && value >= 0) p->test_host_code_every = value;
     else return pfail(p, QD_ERR_INVALID, "unknown option " + n);
     return QD_OK;
 }

@@ -307,6 +307,21 @@ def test_pipeline_falls_back_to_the_host_for_blocks_the_device_refuses(tmp_path)
     for f in sorted(os.listdir(ref_dir)):
         if f.endswith(".fastq.gz"):
             assert gzip.open(out / f).read() == gzip.open(ref_dir / f).read(), f
+    # members the device gives up are coded by the host from the piece's text (forced here for every third member)
+    out3 = tmp_path / "mine3"
+    out3.mkdir()
+    with hb.Engine(0) as eng:
+        eng.set_plan(cf.plan())
+        eng.set_barcodes(Sample.BARCODES())
+        ws = WriterSet(str(out3), 1, deflate_device=-1)
+        with hb.Pipe(eng, 6000) as pipe:
+            pipe.set_option("test_host_code_every", 3)
+            st = pipe.run([(cf.seq_R1[0], cf.seq_R2[0], cf.index_R1[0], cf.index_R2[0], ws.handle(), None, None)])
+        ws.close()
+        assert st["host_coded_pieces"] >= st["pieces"] // 3 > 0
+    for f in sorted(os.listdir(ref_dir)):
+        if f.endswith(".fastq.gz"):
+            assert gzip.open(out3 / f).read() == gzip.open(ref_dir / f).read(), f
     # damage one block of R2 in the middle of the file
     raw = bytearray(open(cf.seq_R2[0], "rb").read())
     raw[len(raw) // 2] ^= 0x5A
