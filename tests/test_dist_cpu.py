@@ -183,3 +183,15 @@ def test_plan_parts_reproduces_the_sequential_pairing():
                 assert [x[1] for x in mine] == [x[1] for x in seq[s][a:b]], (trial, r, s)
             got.append((a, b))
         assert sum(b - a for a, b in got) == N
+
+
+def test_allgather_bytes_between_processes(tmp_path):
+    """dist.allgather_bytes (the grain tables of a shared chunk travel this way): three processes, every one gets all three payloads in rank order."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from quade_amd import dist; r = int(sys.argv[1]); "
+            "got = dist.allgather_bytes(%r, 'tok', r, 3, 'tables', ('payload of rank %%d' %% r).encode() * (r + 1)); "
+            "assert got == [('payload of rank %%d' %% k).encode() * (k + 1) for k in range(3)], got; print('ok', r)") % (ROOT, str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs) and sorted(o.strip() for o in outs) == ["ok 0", "ok 1", "ok 2"]

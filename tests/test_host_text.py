@@ -11,3 +11,32 @@ def test_shared_text_rules_and_crc_arithmetic(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "native", "text_rules_test.cpp"), "-lz"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:]
+
+
+def _build_io_seams(tmp_path, sanitizer):
+    exe = str(tmp_path / ("io_seams_" + sanitizer.replace(",", "_")))
+    csrc = os.path.join(ROOT, "quade_amd", "csrc")
+    cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=" + sanitizer, "-fno-omit-frame-pointer", os.path.join(ROOT, "tests", "native", "io_seams_test.cpp"),
+           os.path.join(csrc, "quade_io.cpp"), os.path.join(csrc, "fastq_pack.cpp"), os.path.join(csrc, "quade_pgz.cpp"), "-o", exe, "-lz", "-ldl", "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_io_seams_of_the_pipeline_under_asan_and_ubsan(tmp_path):
+    """quade_io_internal.h (raw text reader on every input flavour, host inflate of BGZF members, the sink's files, the pool) -- what
+    quade_pipe.cpp builds on -- with AddressSanitizer + UBSan, no GPU."""
+    exe = _build_io_seams(tmp_path, "address,undefined")
+    d = tmp_path / "w"
+    d.mkdir()
+    # (leak check off: the library keeps one libdeflate compressor / decompressor per thread and level for the life of the process)
+    r = subprocess.run([exe, str(d)], capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_io_seams_of_the_pipeline_under_tsan(tmp_path):
+    exe = _build_io_seams(tmp_path, "thread")
+    d = tmp_path / "w"
+    d.mkdir()
+    r = subprocess.run([exe, str(d)], capture_output=True, text=True, timeout=900, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-3000:])
