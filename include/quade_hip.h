@@ -496,6 +496,8 @@ typedef struct qd_grain_info {
 int qd_pipe_index(qd_pipe* pipe, const char* path, int32_t world, int32_t rank, int32_t grains_per_rank, qd_grain_info* out, int32_t cap,
                   int32_t* n_out);
 /* "batch_pairs": pairs per batch at most (default 2 000 000; windows of text are sized from it, at most 1 GiB per stream);
+ * "member_slots_bytes": device memory the member slots of one batch may take (default 12 GiB): a member holds 1 MiB of one destination's
+ * text, less (down to 64 KiB) when thousands of destinations would need more slots than that;
  * "test_fail_inflate_batch": tests -- the device's BGZF result of that batch is treated as refused;
  * "test_host_code_every": tests -- every k-th member is coded by the host, as one that did not fit its slot on the device would be */
 int qd_pipe_set_option(qd_pipe* pipe, const char* name, int64_t value);

@@ -47,7 +47,7 @@ namespace {
 constexpr size_t SEG_BYTES = 16u << 20;  // bytes per upload (compressed blocks or text)
 constexpr int RING_SLOTS = 48;           // device ring per stream: how far a feeder runs ahead of the kernels
 constexpr int PIN_SLOTS = 3;             // page-locked upload buffers per stream
-constexpr uint32_t PIECE_BYTES = 1u << 20;       // text per gzip member
+constexpr uint32_t PIECE_BYTES = 1u << 20;       // text per gzip member at most (piece_bytes_for)
 constexpr size_t WINDOW_MAX = (size_t)1 << 30;   // text per stream and batch (offsets are 32 bit)
 constexpr uint32_t LAUNCH_BLOCKS = 8192;         // BGZF blocks per inflate launch at most (sizes the match scratch)
 constexpr size_t GROUP_SEGMENTS = 8;             // uploads gathered per inflate launch
@@ -563,6 +563,7 @@ struct qd_pipe {
     int64_t batch_pairs = 2000000;
     int64_t test_fail_inflate_batch = -1;  // option: the device "refuses" the BGZF blocks of this batch (the host inflates them)
     int64_t test_host_code_every = 0;      // option: every k-th member is coded by the host as if the device had given it up
+    int64_t member_slots_bytes = (int64_t)12 << 30;  // option: device memory one batch's member slots may take (sizes the pieces, piece_bytes_for)
     qd_plan plan{};
     qd_layout lay{};
     hipStream_t cs = nullptr, ds = nullptr;
@@ -1036,6 +1037,14 @@ int host_inflate_window(qd_pipe* p, Window& w) {
     return rc;
 }
 
+// Text per gzip member: 1 MiB -- less when so many destinations take members in one batch that their slots (every member gets one of
+// the longest member's bound) would not fit member_slots_bytes: thousands of samples make thousands of small members per batch.
+uint32_t piece_bytes_for(const qd_pipe* p, uint64_t text_bytes, uint64_t n_dest) {
+    uint32_t pb = PIECE_BYTES;
+    while (pb > QD_LZ_SUB && (text_bytes / pb + 2 * n_dest + 2) * (uint64_t)qd_huffman_member_bound(pb) > (uint64_t)p->member_slots_bytes) pb >>= 1;
+    return pb;
+}
+
 // Every buffer at the size a full batch needs, in one go, once the first scan has told what a record of every stream weighs:
 // growing them one by one as the first batches arrive drains the compute stream each time (a quarter of a 16 M-pair run).
 int reserve_buffers(qd_pipe* p, uint32_t B, uint32_t n_dest) {
@@ -1076,8 +1085,9 @@ int reserve_buffers(qd_pipe* p, uint32_t B, uint32_t n_dest) {
     PCHK(p, p->sdest.need(n * 2 + 64, 0, p->cs));
     PCHK(p, p->scan_tiles.need((n / 4096 + 4) * 4, 0, p->cs));
     const size_t T = (size_t)out_text + (size_t)n_dest * 64;
-    const size_t n_pieces = T / PIECE_BYTES + 2 * (size_t)n_dest + 2, n_subs = T / QD_LZ_SUB + n_pieces;
-    const size_t out_stride = (size_t)qd_huffman_member_bound(PIECE_BYTES), sub_stride = (size_t)qd_huffman_member_bound(QD_LZ_SUB);
+    const uint32_t piece_bytes = piece_bytes_for(p, T, n_dest);
+    const size_t n_pieces = T / piece_bytes + 2 * (size_t)n_dest + 2, n_subs = T / QD_LZ_SUB + n_pieces;
+    const size_t out_stride = (size_t)qd_huffman_member_bound(piece_bytes), sub_stride = (size_t)qd_huffman_member_bound(QD_LZ_SUB);
     for (OutSet& o : p->out) {
         PCHK(p, o.text.need(T + 64, 0, p->cs));
         PCHK(p, o.pieces.need(n_pieces * sizeof(qd_deflate_piece), 0, p->cs));
@@ -1219,6 +1229,7 @@ int process_batch(qd_pipe* p, uint32_t n, qd_sink* sink, int64_t batch_index) {
     for (int s = 0; s < p->n_streams; ++s) p->win[s].res.carry_start = reinterpret_cast<qd_scan_result*>(p->h_res.p)[s].carry_start;
     // 5. layout of the output text: every destination's R1 region, then every R2 region, 16-byte aligned; pieces of 1 MiB
     std::vector<int64_t> base1(nd, 0), base2(nd, 0);
+    const uint32_t piece_bytes = piece_bytes_for(p, (uint64_t)h_tot[0] + h_tot[1], nd);
     BatchOut bo;
     bo.sink = sink;
     bo.level = si.level;
@@ -1247,8 +1258,8 @@ int process_batch(qd_pipe* p, uint32_t n, qd_sink* sink, int64_t batch_index) {
                 fr.k = k;
                 fr.first = (uint32_t)bo.pieces.size();
                 fr.text_bytes = bytes;
-                for (uint64_t a = 0; a < bytes; a += PIECE_BYTES) {
-                    const uint32_t plen = (uint32_t)std::min<uint64_t>(PIECE_BYTES, bytes - a);
+                for (uint64_t a = 0; a < bytes; a += piece_bytes) {
+                    const uint32_t plen = (uint32_t)std::min<uint64_t>(piece_bytes, bytes - a);
                     first_sub.push_back((uint32_t)subs.size());
                     for (uint32_t q = 0; q < plen; q += QD_LZ_SUB) {
                         const uint32_t slen = std::min<uint32_t>(QD_LZ_SUB, plen - q);
@@ -1274,7 +1285,7 @@ int process_batch(qd_pipe* p, uint32_t n, qd_sink* sink, int64_t batch_index) {
     OutSet& o = p->out[set];
     bo.set = set;
     bo.n_pieces = n_pieces;
-    const int64_t out_stride = qd_huffman_member_bound(PIECE_BYTES);
+    const int64_t out_stride = qd_huffman_member_bound(piece_bytes);
     const int64_t sub_stride = qd_huffman_member_bound(QD_LZ_SUB);
     PCHK(p, o.text.need((size_t)at + 64, 0, p->cs));
     PCHK(p, p->base1.need((size_t)nd * 8, 0, p->cs));
@@ -1724,6 +1735,7 @@ int qd_pipe_set_option(qd_pipe* p, const char* name, int64_t value) {
     if (n == "batch_pairs" && value >= 1) p->batch_pairs = value;
     else if (n == "test_fail_inflate_batch") p->test_fail_inflate_batch = value;
     else if (n == "test_host_code_every" && value >= 0) p->test_host_code_every = value;
+    else if (n == "member_slots_bytes" && value >= (1 << 20)) p->member_slots_bytes = value;
     else return pfail(p, QD_ERR_INVALID, "unknown option " + n);
     return QD_OK;
 }

@@ -316,6 +316,7 @@ def test_pipeline_falls_back_to_the_host_for_blocks_the_device_refuses(tmp_path)
         ws = WriterSet(str(out3), 1, deflate_device=-1)
         with hb.Pipe(eng, 6000) as pipe:
             pipe.set_option("test_host_code_every", 3)
+            pipe.set_option("member_slots_bytes", 8 << 20)  # ... and members of 64 KiB of text, as with thousands of destinations
             st = pipe.run([(cf.seq_R1[0], cf.seq_R2[0], cf.index_R1[0], cf.index_R2[0], ws.handle(), None, None)])
         ws.close()
         assert st["host_coded_pieces"] >= st["pieces"] // 3 > 0
