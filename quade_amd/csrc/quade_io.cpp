@@ -664,12 +664,13 @@ class DeflateService {
         bool usable = qd_deflater_create && qd_deflater_run && qd_huffman_member_bound && qd_deflater_create(device_, &def) == QD_OK;
         int64_t batches = 0;
         if (usable) add_slab(12);  // a first small slab; more are made as pieces ask for them (want_slab_), up to MAX_BUFS
+        else lane_lost();          // (no deflater on this lane: when none is left the pool's jobs stop asking for buffers)
         for (;;) {
             std::vector<DevPiece> b;
             bool slab = false;
             {
                 std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [this] { return !q_.empty() || want_slab_; });
+                cv_.wait(g, [this, usable] { return !q_.empty() || (want_slab_ && usable); });  // (only a lane that can use buffers makes them)
                 while (!q_.empty() && (int)b.size() < MAX_BATCH && (b.empty() || q_.front().level == b[0].level)) {  // one level per launch
                     b.push_back(q_.front());
                     q_.pop_front();
@@ -714,6 +715,7 @@ class DeflateService {
                         failed_ = true;
                     }
                     cv_free_.notify_all();
+                    cv_.notify_all();  // (a slab request this lane was about to serve goes to a lane that still can)
                 }
             }
             // The members go to their files on the pool's threads (a copy out of the batch's block, the appends in file
@@ -749,6 +751,12 @@ class DeflateService {
             }
         }
     }
+    void lane_lost() {
+        std::lock_guard<std::mutex> g(m_);
+        if (++lanes_lost_ >= lanes_n_) failed_ = true;
+        cv_free_.notify_all();
+    }
+    int lanes_lost_ = 0;
     // blocks of members (one per batch), recycled: a fresh 75 MB allocation per batch is 18 000 page faults
     struct MemberBlock {
         uint8_t* p = nullptr;
