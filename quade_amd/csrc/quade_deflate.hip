@@ -18,6 +18,7 @@
 // reported with length 0 and made by the host.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "crc_lds.h"
 #include "quade_deflate.h"
@@ -383,19 +384,27 @@ __device__ __forceinline__ uint32_t len_extra_bits(uint32_t sym) {  // of litera
 __device__ __forceinline__ uint32_t dist_extra_bits(uint32_t sym) { return sym < 4 ? 0u : (sym >> 1) - 1; }
 
 // Lengths (<= 15) of a Huffman code for the used ones of n symbols, by one workgroup: the construction of code_lengths()
-// with the sort done by all threads (rank = how many used symbols come before this one by (count, symbol)).  fx, order, w,
-// parent: LDS scratch of n, n, 2n, 2n entries.  Every thread calls it; len[] is complete when it returns.
+// with everything but the two-queue merge done by all threads -- the sort (rank = how many used symbols come before this one
+// by (count, symbol)), the leaves' depths (each leaf walks up to the root), the lengths' hand-out -- and the per-length
+// counts in LDS (an array a lane indexes with a variable lies in scratch memory: one lane's counts there, a trip to memory
+// per step, made this and canonical_lut() a quarter of the sub-block kernel's time).  fx, order, w, parent: LDS scratch of
+// n, n, 2n, 2n entries.  Every thread calls it; len[] is complete when it returns.
 __device__ void block_code_lengths(const uint32_t* freq, int n, uint8_t* len, uint32_t* fx, uint16_t* order, uint32_t* w, int16_t* parent,
                                    uint32_t* m_out) {
+    __shared__ uint32_t bl[16];
     const int tid = threadIdx.x, nthr = blockDim.x;
     for (int s = tid; s < n; s += nthr) {
         fx[s] = freq[s];
         len[s] = 0;
     }
+    if (tid < 16) bl[tid] = 0;
+    if (tid == 0) *m_out = 0;
     __syncthreads();
-    if (tid == 0) {  // a prefix code needs two codes: lend one to an unused symbol
-        int used = 0;
-        for (int s = 0; s < n; ++s) used += fx[s] != 0;
+    for (int s = tid; s < n; s += nthr)
+        if (fx[s]) atomicAdd(m_out, 1u);
+    __syncthreads();
+    if (tid == 0 && *m_out < 2) {  // a prefix code needs two codes: lend one to an unused symbol
+        int used = (int)*m_out;
         for (int s = 0; used < 2 && s < n; ++s)
             if (!fx[s]) {
                 fx[s] = 1;
@@ -416,9 +425,9 @@ __device__ void block_code_lengths(const uint32_t* freq, int n, uint8_t* len, ui
         order[rank] = (uint16_t)s;
         w[rank] = f;
     }
+    for (int i = tid; i < 2 * m - 1; i += nthr) parent[i] = -1;
     __syncthreads();
     if (tid == 0) {
-        for (int i = 0; i < 2 * m - 1; ++i) parent[i] = -1;
         int leaf = 0, inner = m, next = m;
         while (next < 2 * m - 1) {
             int pick[2];
@@ -427,12 +436,17 @@ __device__ void block_code_lengths(const uint32_t* freq, int n, uint8_t* len, ui
             parent[pick[0]] = parent[pick[1]] = (int16_t)next;
             ++next;
         }
-        int bl[16] = {0};
-        w[2 * m - 2] = 0;  // depth of every node from the root down (w is reused for the depths)
-        for (int k = 2 * m - 3; k >= 0; --k) w[k] = w[parent[k]] + 1;
-        for (int i = 0; i < m; ++i) ++bl[w[i] < 15 ? w[i] : 15];
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += nthr) {  // a leaf's depth = the steps up to the root (node 2m - 2)
+        uint32_t d = 0;
+        for (int k = i; parent[k] >= 0; k = parent[k]) ++d;
+        atomicAdd(&bl[d < 15 ? d : 15], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
         uint32_t kraft = 0;
-        for (int d = 1; d <= 15; ++d) kraft += (uint32_t)bl[d] << (15 - d);
+        for (int d = 1; d <= 15; ++d) kraft += bl[d] << (15 - d);
         for (uint32_t excess = kraft - (1u << 15); excess > 0; --excess) {
             int bits = 14;
             while (bl[bits] == 0) --bits;
@@ -440,24 +454,56 @@ __device__ void block_code_lengths(const uint32_t* freq, int n, uint8_t* len, ui
             bl[bits + 1] += 2;
             --bl[15];
         }
-        int at = 0;
-        for (int bits = 15; bits >= 1; --bits)
-            for (int c = 0; c < bl[bits]; ++c) len[order[at++]] = (uint8_t)bits;
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += nthr) {  // the rarest symbols take the longest codes: bl[15] of them 15 bits, the next bl[14] 14, ...
+        int bits = 15;
+        for (uint32_t upto = bl[15]; (uint32_t)i >= upto && bits > 1;) upto += bl[--bits];
+        len[order[i]] = (uint8_t)bits;
     }
     __syncthreads();
 }
 
-// canonical codes, bit-reversed, of n symbols with the lengths len[] -> lut[s] = len | code << 8
-__device__ void canonical_lut(const uint8_t* len, int n, uint32_t* lut) {
-    int blc[16] = {0}, nxt[16] = {0};
-    for (int s = 0; s < n; ++s) ++blc[len[s]];
-    blc[0] = 0;
-    for (int b = 1, c = 0; b <= 15; ++b) {
-        c = (c + blc[b - 1]) << 1;
-        nxt[b] = c;
+// canonical codes, bit-reversed, of n symbols with the lengths len[] -> lut[s] = len | code << 8.  Every thread calls it.
+__device__ void block_canonical_lut(const uint8_t* len, int n, uint32_t* lut) {
+    __shared__ uint32_t cnt[16], nxt[16];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    if (tid < 16) cnt[tid] = 0;
+    __syncthreads();
+    for (int s = tid; s < n; s += nthr)
+        if (len[s]) atomicAdd(&cnt[len[s]], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t c = 0;
+        for (int b = 1; b <= 15; ++b) {
+            c = (c + (b > 1 ? cnt[b - 1] : 0u)) << 1;
+            nxt[b] = c;
+        }
     }
-    for (int s = 0; s < n; ++s) lut[s] = len[s] ? ((uint32_t)len[s] | (rev_bits((uint32_t)nxt[len[s]]++, len[s]) << 8)) : 0;
+    __syncthreads();
+    for (int s = tid; s < n; s += nthr) {
+        const uint32_t l = len[s];
+        uint32_t rank = 0;
+        for (int t = 0; t < s; ++t) rank += len[t] == l ? 1u : 0u;
+        lut[s] = l ? (l | (rev_bits(nxt[l] + rank, (int)l) << 8)) : 0u;
+    }
+    __syncthreads();
 }
+
+#if defined(QD_LZ_TIMING) /* measurement build: where a sub-block's time goes (100 MHz ticks, summed over the workgroups) */
+__device__ unsigned long long g_lz_ticks[8];
+#define LZ_STAMP(k)                                                          \
+    do {                                                                     \
+        __syncthreads();                                                     \
+        const uint64_t now_ = (uint64_t)wall_clock64();                      \
+        if (threadIdx.x == 0) atomicAdd(&g_lz_ticks[k], (unsigned long long)(now_ - since_)); \
+        since_ = now_;                                                       \
+    } while (0)
+#else
+#define LZ_STAMP(k) \
+    do {            \
+    } while (0)
+#endif
 
 __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, const qd_lz_sub* subs, uint32_t* tokens, uint8_t* sub_out,
                                                          int64_t sub_stride, uint32_t* sub_bytes, uint32_t* sub_crc) {
@@ -473,6 +519,9 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
     const uint8_t* src = text + subs[blockIdx.x].text_off;  // 16-byte aligned
     uint32_t* dst = reinterpret_cast<uint32_t*>(sub_out + (int64_t)blockIdx.x * sub_stride);
     uint32_t* tok0 = tokens + (size_t)blockIdx.x * LZ_SUB;  // candidates per position, then the waves' token lists
+#if defined(QD_LZ_TIMING)
+    uint64_t since_ = (uint64_t)wall_clock64();
+#endif
 
     // 0. stage the text (zero behind it) and count its bytes on the way (8 replicas of a histogram in the table's space, which is
     //    not in use yet): what a literal costs, in bits, decides below which matches are worth taking
@@ -509,6 +558,7 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
         bcost[tid] = (uint8_t)(c < 1 ? 1 : (c > 12 ? 12 : c));
     }
     __syncthreads();
+    LZ_STAMP(0);  // staged, histogram
     if (sub_crc) {  // the sub-block's CRC-32 while its text is at hand (the tables borrow the hash table's space, which is not in use yet)
         static_assert((4u << LZ_HASH_BITS) >= 4096 + 64 && (size_t)LZ_BLOCK * LZ_CRC_SW * 4 >= (size_t)LZ_SUB, "the CRC stage's tables and slices");
         qdcrc::stage_tables<LZ_BLOCK>(table);
@@ -518,6 +568,7 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
     }
     for (uint32_t i = tid; i < (1u << LZ_HASH_BITS); i += LZ_BLOCK) table[i] = 0;
     __syncthreads();
+    LZ_STAMP(1);  // CRC
 
     // 1. candidates: rounds of 256 positions, one barrier per round
     for (uint32_t r0 = 0; r0 < L; r0 += LZ_BLOCK) {
@@ -550,11 +601,16 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
                 // ... and worth its bits: the literals it replaces, priced by the 8 bytes at its start, against ~13 bits of
                 // length and distance symbols + the distance's extra bits (short matches inside lines of random qualities lose,
                 // as those inside the sequence lines do: 43.0 -> 41.5 % of the benchmarks' synthetic records, tools/lz_model.cpp)
-                uint32_t c8 = 0;
+                // (priced only where there is a match of the needed length: the eight byte-wide look-ups are the reads that collide in the banks)
+                if (best < need) {
+                    best = 0;
+                } else {
+                    uint32_t c8 = 0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) c8 += bcost[(a[k >> 2] >> (8 * (k & 3))) & 0xFFu];
-                const uint32_t mbits = (uint32_t)LZ_MATCH_BITS + (dist > 1 ? 31u - (uint32_t)__clz(dist) : 0u);
-                if (best < need || best * c8 < mbits * 8) best = 0;
+                    for (int k = 0; k < 8; ++k) c8 += bcost[(a[k >> 2] >> (8 * (k & 3))) & 0xFFu];
+                    const uint32_t mbits = (uint32_t)LZ_MATCH_BITS + (dist > 1 ? 31u - (uint32_t)__clz(dist) : 0u);
+                    if (best * c8 < mbits * 8) best = 0;
+                }
                 table[h] = (bucket << 16) | p;
             }
             tok0[p] = best | (dist << 8);
@@ -562,6 +618,7 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
         __syncthreads();
     }
 
+    LZ_STAMP(2);  // candidates
     // 2. parse: this wave's quarter of the sub-block, 64 positions at a time
     {
         const uint32_t rbeg = wave * LZ_REG, rend = min(rbeg + (uint32_t)LZ_REG, L);
@@ -645,6 +702,7 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
     }
     if (tid == 0) lfreq[256] = 1;  // end of block
     __syncthreads();
+    LZ_STAMP(3);  // parse
 
     // 3. the two codes (the text in LDS is not needed any more: its space holds the builders' scratch)
     {
@@ -655,10 +713,21 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
         block_code_lengths(lfreq, LZ_NL, llen, fx, order, w, parent, &ctl[2]);
         block_code_lengths(dfreq, LZ_ND, dlen, fx, order, w, parent, &ctl[2]);
     }
+    LZ_STAMP(4);  // code lengths
     uint32_t* words = tw + 2048;  // 256 tokens x <= 48 bits, + the carried word
+    block_canonical_lut(llen, LZ_NL, llut);
+    block_canonical_lut(dlen, LZ_ND, dlut);
+    if (tid == 0) ctl[3] = 0;
+    __syncthreads();
+    {  // the block's size in bits without its header: symbols + extra bits
+        uint32_t bits = 0;
+        for (uint32_t s = tid; s < (uint32_t)LZ_NL; s += LZ_BLOCK) bits += lfreq[s] * (llen[s] + (s > 256 ? len_extra_bits(s) : 0u));
+        for (uint32_t s = tid; s < (uint32_t)LZ_ND; s += LZ_BLOCK) bits += dfreq[s] * (dlen[s] + dist_extra_bits(s));
+        if (bits) atomicAdd(&ctl[3], bits);
+    }
+    __syncthreads();
+    LZ_STAMP(7);  // tables
     if (tid == 0) {
-        canonical_lut(llen, LZ_NL, llut);
-        canonical_lut(dlen, LZ_ND, dlut);
         int nl = LZ_NL, nd = LZ_ND;
         while (nl > 257 && llen[nl - 1] == 0) --nl;
         while (nd > 1 && dlen[nd - 1] == 0) --nd;
@@ -720,13 +789,12 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
         carry_word = (uint32_t)acc;
         carry_bits = (uint32_t)cnt;
         // the block must fit its slot: header, symbols + extra bits, end of block, the empty stored block
-        uint64_t bits = 3 + 14 + 19 * 3 + 5 * (uint64_t)(nl + nd);  // (the header: at most 5 bits per length)
-        for (int s = 0; s < LZ_NL; ++s) bits += (uint64_t)lfreq[s] * (llen[s] + (s > 256 ? len_extra_bits((uint32_t)s) : 0u));
-        for (int s = 0; s < LZ_ND; ++s) bits += (uint64_t)dfreq[s] * (dlen[s] + dist_extra_bits((uint32_t)s));
+        const uint64_t bits = 3 + 14 + 19 * 3 + 5 * (uint64_t)(nl + nd) + ctl[3];  // (the header: at most 5 bits per length)
         ctl[0] = (uint32_t)wi;
         ctl[1] = ((bits + 7) / 8 + 3 + 4 + 8 <= (uint64_t)sub_stride) ? 1u : 0u;
     }
     __syncthreads();
+    LZ_STAMP(5);  // header (one lane)
     uint32_t out_word = ctl[0];
     if (ctl[1] == 0) {
         if (tid == 0) sub_bytes[blockIdx.x] = 0;
@@ -801,6 +869,7 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
         out_word += full;
         __syncthreads();
     }
+    LZ_STAMP(6);  // encode
     // end of block; then an empty stored block puts the next sub-block on a byte boundary
     if (tid == 0) {
         uint64_t acc = carry_word;
@@ -879,6 +948,19 @@ hipError_t qd_launch_lz_subblocks(const uint8_t* text, const qd_lz_sub* subs, ui
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lz_subblocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(lz_subblocks, dim3(n_subs), dim3(LZ_BLOCK), lds, st, text, subs, tokens, sub_out, sub_stride, sub_bytes, sub_crc);
+#if defined(QD_LZ_TIMING)
+    {
+        unsigned long long t[8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_lz_ticks), sizeof t);
+        static const char* names[8] = {"stage+histogram", "crc", "candidates", "parse", "code lengths", "header (one lane)", "encode", "tables"};
+        unsigned long long sum = 0;
+        for (int k = 0; k < 8; ++k) sum += t[k];
+        fprintf(stderr, "lz_subblocks phases (all launches so far, %u sub-blocks in this one):", n_subs);
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f %%", names[k], sum ? 100.0 * (double)t[k] / (double)sum : 0.0);
+        fprintf(stderr, "\n");
+    }
+#endif
     return hipGetLastError();
 }
 

@@ -256,6 +256,7 @@ struct Lds2 {
     uint32_t start[NT], exitp[NT], nout[NT], nmat[NT], flag[NT];
     uint32_t start_sum[2 * (NT / 64)];  // the waves' totals of the span scan
     uint32_t ctl[8];
+    uint32_t win_first[65536 / QD_INFLATE2_Q + 2];  // per window of the match stage: the first match that starts in it
 };
 enum { F_EOB = 1, F_ERR_CODE = 2, F_ERR_TRUNC = 4 };
 
@@ -296,14 +297,16 @@ struct SpanMemo {
 #endif
 constexpr uint32_t MEMO_STEP = 40;  // bits between the marks
 
-// Tokens from bit `pos` on while they start before `limit`.  WRITE: literals -> ob[o...], matches -> list[m...].  MEMO (counting
+// Tokens from bit `pos` on while they start before `limit`.  WRITE: literals -> ob[o...], matches -> list[m...], and win_first[w]
+// = the lowest list index of a match whose first byte lies in window w of the text (the match stage's windows).  MEMO (counting
 // rounds): `memo` is read (the lane's last decode, if any) and rewritten; mark0 = the first mark (a property of the span, not of the start).
 template <bool WRITE, bool MEMO = false>
 __device__ __forceinline__ void decode_span(const uint32_t* pw, uint32_t total_bits, const Lds& L, int nlsym, int ndsym, uint32_t pos,
                                             uint32_t limit, uint8_t* ob, uint32_t o, uint32_t olen, unsigned long long* list, uint32_t m,
                                             uint32_t mcap, uint32_t& exit_pos, uint32_t& n_out, uint32_t& n_mat, uint32_t& flag,
-                                            SpanMemo* memo = nullptr, uint32_t mark0 = 0) {
+                                            SpanMemo* memo = nullptr, uint32_t mark0 = 0, uint32_t* win_first = nullptr) {
     uint32_t out = 0, mat = 0, fl = 0;
+    uint32_t last_win = 0xFFFFFFFFu;
     SpanMemo nw;
     uint32_t nrec = 0;
     if (MEMO) {
@@ -412,8 +415,18 @@ __device__ __forceinline__ void decode_span(const uint32_t* pw, uint32_t total_b
             break;
         }
         if (WRITE) {
-            if (m + mat < mcap) list[m + mat] = (unsigned long long)(o + out) | ((unsigned long long)len << 20) | ((unsigned long long)dist << 32);
-            else fl = F_ERR_CODE;
+            if (m + mat < mcap) {
+                list[m + mat] = (unsigned long long)(o + out) | ((unsigned long long)len << 20) | ((unsigned long long)dist << 32);
+#if !defined(QD_INFLATE2_FULL_LIST)
+                const uint32_t win = min((o + out) / (uint32_t)QD_INFLATE2_Q, 65536u / QD_INFLATE2_Q);
+                if (win != last_win) {
+                    atomicMin(&win_first[win], m + mat);
+                    last_win = win;
+                }
+#endif
+            } else {
+                fl = F_ERR_CODE;
+            }
         }
         out += len;
         ++mat;
@@ -710,10 +723,13 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
             err = QD_INFLATE_OVERRUN;  // (more matches than the list holds: the host inflates this run)
             break;
         }
+        constexpr uint32_t N_WIN = 65536 / QD_INFLATE2_Q + 2;
+        if (tid < N_WIN) S.win_first[tid] = n_matches;
+        __syncthreads();
         if (tid <= eob_lane) {
             uint32_t ex, no, nm, fl;
             decode_span<true>(pw, total_bits, L, lit_codes, dist_codes, S.start[tid], my_limit, ob, S.nout[tid], olen, list, S.nmat[tid], mcap, ex, no,
-                              nm, fl);
+                              nm, fl, nullptr, 0, S.win_first);
         }
         __threadfence_block();
         __syncthreads();
@@ -732,14 +748,26 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
             //  as the writes "byte, then final" of the lane that owns the parent do)
             volatile uint16_t* par = reinterpret_cast<volatile uint16_t*>(ow + 16384 + 4);
             volatile uint8_t* vob = ob;
-            if (tid == 0) S.ctl[4] = 0;
+            if (tid == 0) S.ctl[4] = S.ctl[5] = S.ctl[6] = S.ctl[7] = 0;
             __syncthreads();
 #pragma unroll 1
             for (uint32_t qb = (opos / Q) * Q; qb < new_opos; qb += Q) {
                 const uint32_t lo = max(qb, opos), hi = min(qb + Q, new_opos);  // (positions below `lo` are final)
                 for (uint32_t p = lo + tid; p < hi; p += NT) par[p - qb] = (uint16_t)p;
                 __syncthreads();
-                for (uint32_t m = tid; m < n_matches; m += NT) {
+                // the matches that can reach into this window: those that start in it, and the last one before them.  (The
+                // list is in text order; every match starts in exactly one window, so each is also checked once.)
+                uint32_t m_lo = n_matches, m_hi = n_matches;
+                for (uint32_t w = qb / Q; w < N_WIN; ++w) {
+                    const uint32_t f = S.win_first[w];
+                    if (f < m_lo) m_lo = f;
+                    if (w > qb / Q && f < m_hi) m_hi = f;
+                }
+                if (m_lo > 0) --m_lo;
+#if defined(QD_INFLATE2_FULL_LIST) /* A/B: every window walks the whole list */
+                m_lo = 0, m_hi = n_matches;
+#endif
+                for (uint32_t m = m_lo + tid; m < m_hi; m += NT) {
                     const unsigned long long e = list[m];
                     const uint32_t d = (uint32_t)e & 0xFFFFFu, len = ((uint32_t)e >> 20), dist = (uint32_t)(e >> 32);
                     if (dist == 0 || dist > d || len > olen - d) {
@@ -750,27 +778,40 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
                     for (uint32_t p = a; p < z; ++p) par[p - qb] = (uint16_t)(p - dist);
                 }
                 __syncthreads();
+                // This lane's positions of the window: qb + tid + k * NT; `pend` = those not final yet, kept over the rounds, so a
+                // round touches only them (most bytes are literals or final after the first round; reading every position's parent to
+                // find that out was most of a round).  A lane takes its pending positions in rising order, as the whole workgroup
+                // does: a parent made final earlier in the round already counts, which settles most chains within two rounds (all
+                // reads of a batch of positions before their writes -- fewer dependent trips -- needed six and was slower).
+                constexpr int K = (int)(Q / NT);
+                static_assert(Q % NT == 0 && K <= 32, "a lane's share of a window");
+                uint32_t pend = 0;
+#pragma unroll 4
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t p = qb + tid + (uint32_t)k * NT;
+                    if (p >= lo && p < hi && par[p - qb] != p) pend |= 1u << k;
+                }
 #pragma unroll 1
                 for (int round = 0; round < MATCH_ROUNDS; ++round) {
-                    if (tid == 0) S.ctl[5] = 0;
-                    __syncthreads();
-                    uint32_t pending = 0;
-                    for (uint32_t p = lo + tid; p < hi; p += NT) {
+#pragma unroll 1
+                    for (uint32_t left = pend; left; left &= left - 1u) {
+                        const uint32_t k = (uint32_t)__builtin_ctz(left), p = qb + tid + k * NT;
                         const uint32_t q = par[p - qb];
-                        if (q == p) continue;
                         if (q < lo || par[q - qb] == q) {
                             vob[p] = vob[q];
                             par[p - qb] = (uint16_t)p;
+                            pend &= ~(1u << k);
                         } else {
                             par[p - qb] = par[q - qb];
-                            pending = 1;
                         }
                     }
-                    if (pending) S.ctl[5] = 1;
+                    uint32_t* flag = &S.ctl[5];  // three flags in turn: the one of round r + 2 is cleared behind the barrier of round r
+                    if (pend) flag[round % 3] = 1;
                     __syncthreads();
-                    if (S.ctl[5] == 0) break;
+                    const uint32_t more = flag[round % 3];
+                    if (tid == 0) flag[(round + 2) % 3] = 0;
+                    if (!more) break;
                     if (round == MATCH_ROUNDS - 1 && tid == 0) S.ctl[4] = 1;  // (chains halve every round: cannot happen; a block that did is not shipped)
-                    __syncthreads();
                 }
             }
         }
