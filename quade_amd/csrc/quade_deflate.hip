@@ -490,6 +490,11 @@ __device__ void block_canonical_lut(const uint8_t* len, int n, uint32_t* lut) {
     __syncthreads();
 }
 
+// A barrier that waits for this wave's LDS traffic only.  __syncthreads() also waits until the wave's global stores have
+// landed; in the loops below every round ends with stores nobody in the kernel reads before the next full barrier, and the
+// round trip of each to memory was on the critical path of every round.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #if defined(QD_LZ_TIMING) /* measurement build: where a sub-block's time goes (100 MHz ticks, summed over the workgroups) */
 __device__ unsigned long long g_lz_ticks[8];
 #define LZ_STAMP(k)                                                          \
@@ -615,8 +620,9 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
             }
             tok0[p] = best | (dist << 8);
         }
-        __syncthreads();
+        lds_barrier();  // (the table and the text are LDS; the candidates are read after the full barrier below)
     }
+    __syncthreads();
 
     LZ_STAMP(2);  // candidates
     // 2. parse: this wave's quarter of the sub-block, 64 positions at a time
@@ -625,12 +631,27 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
         uint32_t* tok = tok0 + rbeg;
         uint32_t ntok = 0;
         int carry = 0;  // positions of the next stretch that the last match already covers
+        // The candidates come in through LDS, a few stretches per trip to memory (the hash table's space, free now: an equal share
+        // per wave).  Loads and stores share one counter of outstanding operations on this hardware, so a wave that waits for a
+        // load also waits for every store it has issued: with the candidates fetched stretch by stretch, each stretch began by
+        // waiting for the token stores of the one before.  (The tokens written below go to indices at or below the stretch's
+        // positions, never into the stretches fetched ahead.)
+        constexpr uint32_t AHEAD = (1u << LZ_HASH_BITS) / LZ_WAVES / 64;  // stretches per fetch
+        static_assert(AHEAD >= 1 && AHEAD * 64 * LZ_WAVES == (1u << LZ_HASH_BITS), "the waves' shares of the table's space");
+        uint32_t* cbuf = table + wave * (AHEAD * 64);
+        uint32_t in_buf = AHEAD;
         for (uint32_t base = rbeg; base < rend; base += 64) {
             const uint32_t p = base + lane;
             const int limit = (int)min(64u, rend - base);
             uint32_t eff = 0, dist = 0;
+            if (in_buf == AHEAD) {
+#pragma unroll
+                for (uint32_t j = 0; j < AHEAD; ++j) cbuf[64 * j + lane] = p + 64 * j < rend ? tok0[p + 64 * j] : 0u;
+                in_buf = 0;
+            }
+            const uint32_t cd = cbuf[64 * in_buf + lane];
+            ++in_buf;
             if ((int)lane < limit) {
-                const uint32_t cd = tok0[p];
                 eff = min(cd & 0xFFu, rend - p);  // (a match ends with the quarter)
                 dist = cd >> 8;
                 if (eff < 4) eff = 0;
@@ -714,7 +735,7 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
         block_code_lengths(dfreq, LZ_ND, dlen, fx, order, w, parent, &ctl[2]);
     }
     LZ_STAMP(4);  // code lengths
-    uint32_t* words = tw + 2048;  // 256 tokens x <= 48 bits, + the carried word
+    uint32_t* words = tw + 2048;  // a step's tokens (LZ_BLOCK x 4) x <= 48 bits, + the carried word
     block_canonical_lut(llen, LZ_NL, llut);
     block_canonical_lut(dlen, LZ_ND, dlut);
     if (tid == 0) ctl[3] = 0;
@@ -800,45 +821,61 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
         if (tid == 0) sub_bytes[blockIdx.x] = 0;
         return;
     }
-    // 4. encode: the waves' token lists one after the other, 256 tokens per step
+    // 4. encode: the waves' token lists one after the other, LZ_TPL consecutive tokens per lane and step: a step is one trip to
+    //    memory for its tokens (which, loads and stores sharing a counter, also waits for the words the step before sent off), one
+    //    workgroup scan of the lanes' bit counts and three barriers, whatever its width.  The barriers wait for LDS traffic only.
+    constexpr int LZ_TPL = 4;
     uint32_t pre[LZ_WAVES + 1];
     pre[0] = 0;
 #pragma unroll
     for (int i = 0; i < LZ_WAVES; ++i) pre[i + 1] = pre[i] + wave_ntok[i];
     const uint32_t T = pre[LZ_WAVES];
-    for (uint32_t g0 = 0; g0 < T; g0 += LZ_BLOCK) {
-        const uint32_t g = g0 + tid;
-        uint64_t b = 0;
-        uint32_t nb = 0;
-        if (g < T) {
-            uint32_t wv = 0;
+    for (uint32_t g0 = 0; g0 < T; g0 += LZ_BLOCK * LZ_TPL) {
+        uint32_t t[LZ_TPL];
 #pragma unroll
-            for (int i = 1; i < LZ_WAVES; ++i) wv += g >= pre[i] ? 1u : 0u;
-            const uint32_t t = tok0[(size_t)wv * LZ_REG + (g - pre[wv])];
-            if (t & 0x80000000u) {
-                const uint32_t e = llut[t & 0xFFu];
-                b = e >> 8;
-                nb = e & 0xFFu;
-            } else {
-                uint32_t sym, eb, ev;
-                len_symbol(t & 0xFFu, sym, eb, ev);
-                uint32_t e = llut[sym];
-                b = (uint64_t)(e >> 8) | ((uint64_t)ev << (e & 0xFFu));
-                nb = (e & 0xFFu) + eb;
-                dist_symbol((t >> 8) & 0x7FFFu, sym, eb, ev);
-                e = dlut[sym];
-                b |= ((uint64_t)(e >> 8) | ((uint64_t)ev << (e & 0xFFu))) << nb;
-                nb += (e & 0xFFu) + eb;
+        for (int j = 0; j < LZ_TPL; ++j) {
+            const uint32_t g = g0 + tid * LZ_TPL + j;
+            t[j] = 0;
+            if (g < T) {
+                uint32_t wv = 0;
+#pragma unroll
+                for (int i = 1; i < LZ_WAVES; ++i) wv += g >= pre[i] ? 1u : 0u;
+                t[j] = tok0[(size_t)wv * LZ_REG + (g - pre[wv])];
             }
         }
-        uint32_t x = nb;
+        uint64_t b[LZ_TPL];
+        uint32_t nb[LZ_TPL], mine = 0;
+#pragma unroll
+        for (int j = 0; j < LZ_TPL; ++j) {
+            b[j] = 0;
+            nb[j] = 0;
+            if (g0 + tid * LZ_TPL + j < T) {
+                if (t[j] & 0x80000000u) {
+                    const uint32_t e = llut[t[j] & 0xFFu];
+                    b[j] = e >> 8;
+                    nb[j] = e & 0xFFu;
+                } else {
+                    uint32_t sym, eb, ev;
+                    len_symbol(t[j] & 0xFFu, sym, eb, ev);
+                    uint32_t e = llut[sym];
+                    b[j] = (uint64_t)(e >> 8) | ((uint64_t)ev << (e & 0xFFu));
+                    nb[j] = (e & 0xFFu) + eb;
+                    dist_symbol((t[j] >> 8) & 0x7FFFu, sym, eb, ev);
+                    e = dlut[sym];
+                    b[j] |= ((uint64_t)(e >> 8) | ((uint64_t)ev << (e & 0xFFu))) << nb[j];
+                    nb[j] += (e & 0xFFu) + eb;
+                }
+            }
+            mine += nb[j];
+        }
+        uint32_t x = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t y = __shfl_up(x, d, 64);
             if (lane >= (uint32_t)d) x += y;
         }
         if (lane == 63) scan[wave] = x;
-        __syncthreads();
+        lds_barrier();  // (also: the step before has read its words and left the carry)
         uint32_t before = 0, total = 0;
 #pragma unroll
         for (int i = 0; i < LZ_WAVES; ++i) {
@@ -849,26 +886,30 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
         const uint32_t cb = carry_bits, cw = carry_word;
         const uint32_t nwords = (cb + total + 31) >> 5;
         for (uint32_t i = tid; i <= nwords + 2; i += LZ_BLOCK) words[i] = i == 0 ? cw : 0;
-        __syncthreads();
-        if (nb) {
-            const uint32_t pos = cb + before + x - nb, w0 = pos >> 5, sh = pos & 31u;
-            const uint64_t lo = b << sh;
-            const uint32_t hi = sh ? (uint32_t)(b >> (64 - sh)) : 0u;
-            if ((uint32_t)lo) atomicOr(&words[w0], (uint32_t)lo);
-            if ((uint32_t)(lo >> 32)) atomicOr(&words[w0 + 1], (uint32_t)(lo >> 32));
-            if (hi) atomicOr(&words[w0 + 2], hi);
+        lds_barrier();
+        uint32_t pos = cb + before + x - mine;
+#pragma unroll
+        for (int j = 0; j < LZ_TPL; ++j) {
+            if (nb[j]) {
+                const uint32_t w0 = pos >> 5, sh = pos & 31u;
+                const uint64_t lo = b[j] << sh;
+                const uint32_t hi = sh ? (uint32_t)(b[j] >> (64 - sh)) : 0u;
+                if ((uint32_t)lo) atomicOr(&words[w0], (uint32_t)lo);
+                if ((uint32_t)(lo >> 32)) atomicOr(&words[w0 + 1], (uint32_t)(lo >> 32));
+                if (hi) atomicOr(&words[w0 + 2], hi);
+            }
+            pos += nb[j];
         }
-        __syncthreads();
+        lds_barrier();
         const uint32_t full = (cb + total) >> 5;
         for (uint32_t i = tid; i < full; i += LZ_BLOCK) dst[out_word + i] = words[i];
-        __syncthreads();
-        if (tid == 0) {
+        if (tid == 0) {  // (read by the others behind the next step's first barrier -- or behind the one below)
             carry_word = words[full];
             carry_bits = (cb + total) & 31u;
         }
         out_word += full;
-        __syncthreads();
     }
+    __syncthreads();
     LZ_STAMP(6);  // encode
     // end of block; then an empty stored block puts the next sub-block on a byte boundary
     if (tid == 0) {

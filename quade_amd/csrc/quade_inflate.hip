@@ -23,6 +23,7 @@
 // itself.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "crc_lds.h"
 #include "quade_inflate.h"
@@ -250,6 +251,9 @@ namespace v2 {
 #define QD_INFLATE2_Q 16384 /* positions per window of the match stage (2 bytes of LDS each) */
 #endif
 static_assert(2 * QD_INFLATE2_Q >= 4096 + 64, "the CRC stage's tables lie where the match stage keeps its parents");
+#if defined(QD_INFLATE_TIMING)
+__device__ unsigned long long g_inflate_ticks[11];
+#endif
 template <int NT>
 struct Lds2 {
     Lds t;
@@ -307,6 +311,31 @@ __device__ __forceinline__ void decode_span(const uint32_t* pw, uint32_t total_b
                                             SpanMemo* memo = nullptr, uint32_t mark0 = 0, uint32_t* win_first = nullptr) {
     uint32_t out = 0, mat = 0, fl = 0;
     uint32_t last_win = 0xFFFFFFFFu;
+    // The stream from `pos` on in a register: `have` bits of it in `buf`, the word behind them (`ahead`) fetched one refill early.
+    // A token then costs its table look-ups and nothing else on the dependent path (a peek at the payload per code -- two
+    // more LDS trips per literal, four per match -- was half of a decode).
+    uint64_t buf = 0;
+    uint32_t have = 0, wi = 0, ahead = 0;
+    if (pos < total_bits) {
+        wi = pos >> 5;
+        const uint32_t sh = pos & 31u;
+        buf = ((uint64_t)pw[wi] | ((uint64_t)pw[wi + 1] << 32)) >> sh;
+        have = 64 - sh;
+        wi += 2;
+        ahead = pw[wi];
+    }
+    auto top_up = [&]() {  // at least 33 bits in hand
+        if (have <= 32) {
+            buf |= (uint64_t)ahead << have;
+            have += 32;
+            ahead = pw[++wi];
+        }
+    };
+    auto drop = [&](uint32_t n) {
+        buf >>= n;
+        have -= n;
+        pos += n;
+    };
     SpanMemo nw;
     uint32_t nrec = 0;
     if (MEMO) {
@@ -359,21 +388,21 @@ __device__ __forceinline__ void decode_span(const uint32_t* pw, uint32_t total_b
             fl = F_ERR_TRUNC;
             break;
         }
-        uint32_t w = peek(pw, pos);
+        top_up();
         int sym;
         uint32_t used;
-        const uint32_t e = L.llut[w & ((1u << LBITS) - 1u)];
+        const uint32_t e = L.llut[(uint32_t)buf & ((1u << LBITS) - 1u)];
         if (e >> 9) {
             sym = (int)(e & 511u);
             used = e >> 9;
         } else {
-            sym = slow_sym(w, L.lcount, L.lsym, nlsym, used);
+            sym = slow_sym((uint32_t)buf, L.lcount, L.lsym, nlsym, used);
             if (sym < 0) {
                 fl = F_ERR_CODE;
                 break;
             }
         }
-        pos += used;
+        drop(used);
         if (sym < 256) {
             if (WRITE) {
                 if (o + out < olen) ob[o + out] = (uint8_t)sym;
@@ -391,25 +420,30 @@ __device__ __forceinline__ void decode_span(const uint32_t* pw, uint32_t total_b
             fl = F_ERR_CODE;
             break;
         }
-        w >>= used;  // (code <= 15 bits + <= 5 extra bits: inside the 32 peeked)
-        const uint32_t le = LEXT[sym], len = (uint32_t)LBASE[sym] + (w & ((1u << le) - 1u));
-        pos += le;
-        w = peek(pw, pos);
+        // (base and extra bits of the length and distance symbols by arithmetic -- RFC 1951's tables are regular -- not from tables
+        //  in constant memory, which a lane indexes with its own symbol: a trip to memory each.  Code <= 15 bits + <= 5 extra
+        //  bits: inside the 33 in hand.)
+        const uint32_t s = (uint32_t)sym;
+        const uint32_t le = (s < 8 || s == 28) ? 0u : (s >> 2) - 1u;
+        const uint32_t len = (s < 8 ? 3u + s : (s == 28 ? 258u : 3u + ((4u + (s & 3u)) << le))) + ((uint32_t)buf & ((1u << le) - 1u));
+        drop(le);
+        top_up();
         int ds;
-        const uint32_t d = L.dlut[w & ((1u << DBITS) - 1u)];
+        const uint32_t d = L.dlut[(uint32_t)buf & ((1u << DBITS) - 1u)];
         if (d >> 5) {
             ds = (int)(d & 31u);
             used = d >> 5;
         } else {
-            ds = slow_sym(w, L.dcount, L.dsym, ndsym, used);
+            ds = slow_sym((uint32_t)buf, L.dcount, L.dsym, ndsym, used);
         }
         if (ds < 0 || ds >= 30) {
             fl = F_ERR_CODE;
             break;
         }
-        w >>= used;
-        const uint32_t de = DEXT[ds], dist = (uint32_t)DBASE[ds] + (w & ((1u << de) - 1u));
-        pos += used + de;
+        drop(used);
+        const uint32_t de = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
+        const uint32_t dist = (ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << de)) + ((uint32_t)buf & ((1u << de) - 1u));
+        drop(de);
         if (pos > total_bits) {
             fl = F_ERR_TRUNC;
             break;
@@ -449,7 +483,7 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
                                                            int32_t* status, unsigned long long* matches, uint32_t mcap, uint32_t pay_words,
                                                            uint32_t* rounds_out, const uint32_t* expect_crc) {
     uint32_t rounds_used = 0, dblocks = 0;
-    uint64_t tm[8] = {(uint64_t)wall_clock64(), 0, 0, 0, 0, 0, 0, 0};  // measurement: where a block's time goes (100 MHz ticks), summed over its deflate blocks
+    uint64_t tm[10] = {(uint64_t)wall_clock64(), 0, 0, 0, 0, 0, 0, 0, 0, 0};  // measurement: where a block's time goes (100 MHz ticks), summed over its deflate blocks
     auto stamp = [&](int k, uint64_t& since) {
         const uint64_t now = (uint64_t)wall_clock64();
         tm[k] += now - since;
@@ -606,6 +640,7 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
                 break;
             }
         }
+        stamp(8, since);  // block header, code lengths
         int r = build(L.lengths, nlen, L.lcount, L.lsym, L.llut, LBITS, 9, tid);
         const int lit_codes = L.lcount[0] == 0xFFFF ? 0 : nlen - (int)L.lcount[0];
         if (type == 2 && (r < 0 || (r > 0 && lit_codes != 1))) {
@@ -618,7 +653,7 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
             err = QD_INFLATE_BAD_TABLE;
             break;
         }
-        stamp(2, since);  // header + tables
+        stamp(2, since);  // the two tables
         // ---- the block's symbols: 256 spans, guessed starts, rounds until the chain from lane 0 is confirmed up to the end-of-block symbol
         const uint32_t bitpos = 8u * (b.pos - b.ahead_bytes) - (uint32_t)b.cnt;  // (cnt >= 0: checked above)
         const uint32_t rest = total_bits > bitpos ? total_bits - bitpos : 0;
@@ -864,8 +899,16 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
     if (tid == 0) status[i] = err;
     if (tid == 0 && rounds_out) {
         rounds_out[8 * i] = rounds_used | (dblocks << 16);
-        for (int k = 1; k < 8; ++k) rounds_out[8 * i + k] = (uint32_t)tm[k];
+        for (int k = 1; k < 8; ++k) rounds_out[8 * i + k] = (uint32_t)(k == 2 ? tm[2] + tm[8] : tm[k]);  // (2: headers + tables)
     }
+#if defined(QD_INFLATE_TIMING) /* measurement build: where the blocks' time goes, summed over a process's launches */
+    if (tid == 0) {
+        atomicAdd(&g_inflate_ticks[0], (unsigned long long)rounds_used);
+        for (int k = 1; k < 9; ++k) atomicAdd(&g_inflate_ticks[k], (unsigned long long)tm[k]);
+        atomicAdd(&g_inflate_ticks[9], 1ull);
+        atomicAdd(&g_inflate_ticks[10], (unsigned long long)dblocks);
+    }
+#endif
 }
 }  // namespace v2
 
@@ -1040,6 +1083,20 @@ static hipError_t launch_inflate2(const uint8_t* comp, const qd_inflate_block* b
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(v2::inflate_bgzf_blocks2<NT>, dim3(n_blocks), dim3(NT), lds, st, comp, blocks, n_blocks, out, status, matches,
                        matches_per_block, pay_words, rounds_out, expect_crc);
+#if defined(QD_INFLATE_TIMING)
+    {
+        unsigned long long t[11];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(v2::g_inflate_ticks), sizeof t);
+        static const char* names[9] = {"", "stage", "tables", "rounds", "scan+write", "matches", "flush", "", "headers"};
+        const double nb = t[9] ? (double)t[9] : 1.0;
+        fprintf(stderr, "inflate_bgzf_blocks2<%d> per block over %llu blocks so far: %.2f deflate blocks, %.2f rounds, %.0f matches;", NT, t[9], (double)t[10] / nb,
+                (double)t[0] / nb, (double)t[7] / nb);
+        for (int k = 1; k < 9; ++k)
+            if (k != 7) fprintf(stderr, " %s %.1f us", names[k], (double)t[k] / nb / 100.0);
+        fprintf(stderr, "\n");
+    }
+#endif
     return hipGetLastError();
 }
 
