@@ -498,6 +498,8 @@ int qd_pipe_index(qd_pipe* pipe, const char* path, int32_t world, int32_t rank, 
 /* "batch_pairs": pairs per batch at most (default 2 000 000; windows of text are sized from it, at most 1 GiB per stream);
  * "member_slots_bytes": device memory the member slots of one batch may take (default 12 GiB): a member holds 1 MiB of one destination's
  * text, less (down to 64 KiB) when thousands of destinations would need more slots than that;
+ * "inflate_streams": 1 (default) = the BGZF inflate launches go down the compute stream one after the other; 2 = they alternate between
+ * two streams of their own, so one launch's last blocks and the next one's first share the device (measured slower: DESIGN.md 4.4);
  * "test_fail_inflate_batch": tests -- the device's BGZF result of that batch is treated as refused;
  * "test_host_code_every": tests -- every k-th member is coded by the host, as one that did not fit its slot on the device would be */
 int qd_pipe_set_option(qd_pipe* pipe, const char* name, int64_t value);

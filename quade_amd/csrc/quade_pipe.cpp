@@ -52,6 +52,9 @@ constexpr size_t WINDOW_MAX = (size_t)1 << 30;   // text per stream and batch (o
 constexpr uint32_t LAUNCH_BLOCKS = 8192;         // BGZF blocks per inflate launch at most (sizes the match scratch)
 constexpr size_t GROUP_SEGMENTS = 8;             // uploads gathered per inflate launch
 constexpr size_t READ_PART = 4u << 20;           // an upload buffer is filled by parallel reads of this much
+#ifndef QD_PIPE_INFLATE_STREAMS
+#define QD_PIPE_INFLATE_STREAMS 1 /* 2: the inflate launches alternate between two streams of their own (measured: slower, see qd_pipe::is) */
+#endif
 
 hipError_t wait_event_napping(hipEvent_t ev) {  // hipEventSynchronize spins on this runtime: poll, then nap
     for (int i = 0; i < 64; ++i) {
@@ -84,12 +87,12 @@ struct DevBuf {  // grow-only device allocation
         uint8_t* q = nullptr;
         hipError_t e = hipMalloc((void**)&q, want);
         if (e != hipSuccess) return e;
+        // nothing queued anywhere may still use the old allocation (the inflate launches run on streams of their own)
+        if (p) (void)hipDeviceSynchronize();
         if (p && keep) {
             e = hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) return e;
-        } else if (p) {
-            (void)hipStreamSynchronize(st);  // nothing queued may still use the old allocation
         }
         if (p) (void)hipFree(p);
         p = q;
@@ -568,6 +571,16 @@ struct qd_pipe {
     qd_layout lay{};
     hipStream_t cs = nullptr, ds = nullptr;
     hipEvent_t sync_ev = nullptr;
+    // Option "inflate_streams" = 2: the inflate launches alternate between two streams of their own, so that the next launch
+    // (another stream's window, the short index reads' few hundred blocks) fills the CUs a launch's last blocks leave idle; the
+    // compute stream joins a window's launches when it first reads the window (join_inflate).  Measured: the launches overlap
+    // (their summed time 441 -> 700 ms for the same blocks) and the job gets SLOWER, 0.75 -> 0.82 s per 16 M pairs
+    // (profiles/r04_ab_inflate_streams.txt) -- two 150 KB workgroups do not fit a CU, and blocks of two launches competing for
+    // the CUs run longer than they save at the tails.  So the default is 1: down the compute stream, one after the other.
+    hipStream_t is[2] = {nullptr, nullptr};
+    hipEvent_t tables_up = nullptr;  // the launch's block tables are on the device (recorded on cs)
+    int n_is = QD_PIPE_INFLATE_STREAMS, next_is = 0;
+    DevBuf matches_b;                // the second stream's match lists
     StagePool stage;
     qd_pipe_stats_impl st;
 
@@ -585,6 +598,8 @@ struct qd_pipe {
         uint32_t pending_text = 0;
         std::vector<std::pair<int64_t, std::pair<size_t, std::pair<uint32_t, uint32_t>>>> runs;  // (file offset, (bytes, (window offset, text bytes))) of this batch's BGZF text
         uint32_t n_blocks = 0;                                         // blocks inflated into this window since the last verification
+        hipEvent_t inflated[2] = {nullptr, nullptr};                   // the window's last launch on each inflate stream
+        bool in_flight[2] = {false, false};
         std::string path;
         qd_scan_result res{};
     } win[4];
@@ -845,6 +860,16 @@ void to_collector(qd_pipe* p, BatchOut&& b) {
 // ---- driver ------------------------------------------------------------------------------------------------------------------------
 using Window = qd_pipe::Window;
 
+// the compute stream goes on behind the window's inflate launches
+int join_inflate(qd_pipe* p, Window& w) {
+    for (int k = 0; k < 2; ++k)
+        if (w.in_flight[k]) {
+            PCHK(p, hipStreamWaitEvent(p->cs, w.inflated[k], 0));
+            w.in_flight[k] = false;
+        }
+    return QD_OK;
+}
+
 // room for `extra` more bytes of text in the window (the line kernels read whole tiles: padding behind the text)
 int window_room(qd_pipe* p, Window& w, size_t extra) {
     const size_t need = (size_t)w.len + extra + 2 * QD_TEXT_TILE;
@@ -861,8 +886,11 @@ int launch_inflate(qd_pipe* p, Feeder& f, Window& w, int stream_index) {
     std::vector<qd_inflate_block> blk;
     std::vector<uint32_t> expect;
     uint32_t longest = 0;
+    const int xi = p->n_is > 1 ? p->next_is : -1;
+    if (xi >= 0) p->next_is ^= 1;
+    const hipStream_t xs = xi >= 0 ? p->is[xi] : p->cs;
     for (Segment& s : w.pending) {
-        PCHK(p, hipStreamWaitEvent(p->cs, f.ready(s.slot), 0));
+        PCHK(p, hipStreamWaitEvent(xs, f.ready(s.slot), 0));
         for (size_t i = 0; i < s.blocks.size(); ++i) {
             qd_inflate_block b = s.blocks[i];
             b.in_off += (uint32_t)((size_t)s.slot * SEG_BYTES);
@@ -889,23 +917,33 @@ int launch_inflate(qd_pipe* p, Feeder& f, Window& w, int stream_index) {
     PCHK(p, p->stage.upload(d_expect, expect.data(), nb * 4, p->cs));
     uint32_t* first_bad = &p->d_res.as<qd_scan_result>()[stream_index].first_bad;
     const bool form2 = qd_inflate2_lds(longest) <= 160 * 1024;
+    DevBuf& matches = xi == 1 ? p->matches_b : p->matches;
+    if (form2) PCHK(p, matches.need((size_t)std::min<size_t>(nb, LAUNCH_BLOCKS) * QD_INFLATE_MATCHES_PER_BLOCK * 8, 0, p->cs));
+    if (xi >= 0) {  // behind everything the compute stream has queued so far: the tables above, the last readers of the window's buffer
+        PCHK(p, hipEventRecord(p->tables_up, p->cs));
+        PCHK(p, hipStreamWaitEvent(xs, p->tables_up, 0));
+    }
     for (size_t at = 0; at < nb; at += LAUNCH_BLOCKS) {
         const uint32_t n = (uint32_t)std::min<size_t>(LAUNCH_BLOCKS, nb - at);
         if (form2) {
-            PCHK(p, p->matches.need((size_t)std::min<size_t>(nb, LAUNCH_BLOCKS) * QD_INFLATE_MATCHES_PER_BLOCK * 8, 0, p->cs));
             // (every block's CRC-32 against its trailer is checked by the kernel, while the text is in LDS)
-            PCHK(p, qd_launch_inflate2(f.ring(), d_blk + at, n, w.buf[w.cur].p, d_status + at, p->matches.as<unsigned long long>(), QD_INFLATE_MATCHES_PER_BLOCK,
-                                       longest, p->cs, nullptr, d_expect + at));
+            PCHK(p, qd_launch_inflate2(f.ring(), d_blk + at, n, w.buf[w.cur].p, d_status + at, matches.as<unsigned long long>(), QD_INFLATE_MATCHES_PER_BLOCK,
+                                       longest, xs, nullptr, d_expect + at));
         } else {
-            PCHK(p, qd_launch_inflate(f.ring(), d_blk + at, n, w.buf[w.cur].p, d_status + at, p->cs));
+            PCHK(p, qd_launch_inflate(f.ring(), d_blk + at, n, w.buf[w.cur].p, d_status + at, xs));
         }
     }
-    for (Segment& s : w.pending) PCHK(p, f.consumed(s.slot, p->cs));
+    for (Segment& s : w.pending) PCHK(p, f.consumed(s.slot, xs));
     if (form2) {
-        PCHK(p, qd_text_check_blocks(d_status, d_expect, d_expect, (uint32_t)nb, w.n_blocks, first_bad, p->cs));  // (the statuses say it all)
+        PCHK(p, qd_text_check_blocks(d_status, d_expect, d_expect, (uint32_t)nb, w.n_blocks, first_bad, xs));  // (the statuses say it all)
     } else {  // the one-wave form does not check: a CRC-32 pass over the text, one range per block
-        PCHK(p, qd_text_crc32_blocks(w.buf[w.cur].p, d_blk, (uint32_t)nb, d_crc, p->cs));
-        PCHK(p, qd_text_check_blocks(d_status, d_crc, d_expect, (uint32_t)nb, w.n_blocks, first_bad, p->cs));
+        PCHK(p, qd_text_crc32_blocks(w.buf[w.cur].p, d_blk, (uint32_t)nb, d_crc, xs));
+        PCHK(p, qd_text_check_blocks(d_status, d_crc, d_expect, (uint32_t)nb, w.n_blocks, first_bad, xs));
+    }
+    if (xi >= 0) {
+        if (!w.inflated[xi]) PCHK(p, hipEventCreateWithFlags(&w.inflated[xi], hipEventDisableTiming));
+        PCHK(p, hipEventRecord(w.inflated[xi], xs));
+        w.in_flight[xi] = true;
     }
     w.n_blocks += (uint32_t)nb;
     p->st.bgzf_blocks += (int64_t)nb;
@@ -975,6 +1013,7 @@ int drain_chunk(qd_pipe* p, Feeder& f, Window& w, int chunk) {
 }
 
 int scan_window(qd_pipe* p, Window& w, int stream_index) {
+    if (join_inflate(p, w) != QD_OK) return QD_ERR_HIP;
     const uint32_t n_tiles = w.len / QD_TEXT_TILE + 1;
     PCHK(p, w.tile_counts.need((size_t)(n_tiles + 2) * 4, 0, p->cs));
     PCHK(p, w.tile_base.need((size_t)(n_tiles + 2) * 4, 0, p->cs));
@@ -1007,6 +1046,7 @@ int scan_window(qd_pipe* p, Window& w, int stream_index) {
 
 // the host inflates this batch's BGZF text of one window (the device refused a block): same bytes, or the file is damaged
 int host_inflate_window(qd_pipe* p, Window& w) {
+    if (join_inflate(p, w) != QD_OK) return QD_ERR_HIP;
     const int fd = open(w.path.c_str(), O_RDONLY | O_CLOEXEC);
     if (fd < 0) return pfail(p, QD_ERR_FORMAT, w.path + ": " + strerror(errno));
     std::vector<uint8_t> comp, text;
@@ -1069,6 +1109,7 @@ int reserve_buffers(qd_pipe* p, uint32_t B, uint32_t n_dest) {
         if (s < 2) out_text += (double)B * avg * 1.06;
     }
     PCHK(p, p->matches.need((size_t)LAUNCH_BLOCKS * QD_INFLATE_MATCHES_PER_BLOCK * 8, 0, p->cs));
+    if (p->n_is > 1) PCHK(p, p->matches_b.need((size_t)LAUNCH_BLOCKS * QD_INFLATE_MATCHES_PER_BLOCK * 8, 0, p->cs));
     const size_t n = B;
     for (int k = 0; k < L.n_streams; ++k) {
         PCHK(p, p->rows_seq[k].need(n * L.seq_stride[k] + 64, 0, p->cs));
@@ -1349,6 +1390,7 @@ int process_batch(qd_pipe* p, uint32_t n, qd_sink* sink, int64_t batch_index) {
 
 // a D2D move of a window's text from `from` on to the front of its other buffer
 int carry_window(qd_pipe* p, Window& w, uint32_t from_in) {
+    if (join_inflate(p, w) != QD_OK) return QD_ERR_HIP;
     const uint32_t from = std::min(from_in, w.len), left = w.len - from;
     const int nx = w.cur ^ 1;
     PCHK(p, w.buf[nx].need((size_t)left + 2 * QD_TEXT_TILE, 0, p->cs));
@@ -1373,6 +1415,7 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
     uint64_t pairs_left = spec.max_pairs > 0 ? (uint64_t)spec.max_pairs : ~0ull;
     for (int s = 0; s < ns; ++s) {
         Window& w = p->win[s];
+        if (join_inflate(p, w) != QD_OK) return QD_ERR_HIP;
         w.len = 0;
         w.eof = false;
         w.dirty = true;
@@ -1718,7 +1761,9 @@ int qd_pipe_create(qd_ctx* ctx, qd_pipe** out) {
     p->plan = P;
     p->n_streams = 2 + L.n_streams;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&p->cs, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&p->ds, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming) != hipSuccess)
+        hipStreamCreateWithFlags(&p->ds, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&p->is[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p->is[1], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&p->tables_up, hipEventDisableTiming) != hipSuccess)
         return pfail(nullptr, QD_ERR_HIP, "stream creation failed");
     for (int i = 0; i < 2; ++i)
         if (hipEventCreateWithFlags(&p->out[i].done, hipEventDisableTiming) != hipSuccess) return pfail(nullptr, QD_ERR_HIP, "event creation failed");
@@ -1736,6 +1781,7 @@ int qd_pipe_set_option(qd_pipe* p, const char* name, int64_t value) {
     else if (n == "test_fail_inflate_batch") p->test_fail_inflate_batch = value;
     else if (n == "test_host_code_every" && value >= 0) p->test_host_code_every = value;
     else if (n == "member_slots_bytes" && value >= (1 << 20)) p->member_slots_bytes = value;
+    else if (n == "inflate_streams" && (value == 1 || value == 2)) p->n_is = (int)value;
     else return pfail(p, QD_ERR_INVALID, "unknown option " + n);
     return QD_OK;
 }
@@ -1841,10 +1887,14 @@ int qd_pipe_destroy(qd_pipe* p) {
     (void)hipSetDevice(p->device);
     if (p->cs) (void)hipStreamSynchronize(p->cs);
     if (p->ds) (void)hipStreamSynchronize(p->ds);
+    for (hipStream_t st : p->is)
+        if (st) (void)hipStreamSynchronize(st);
     for (qd_pipe::Window& w : p->win) {
+        for (hipEvent_t ev : w.inflated)
+            if (ev) (void)hipEventDestroy(ev);
         for (DevBuf* b : {&w.buf[0], &w.buf[1], &w.tile_counts, &w.tile_base, &w.lines, &w.rec_tile, &w.recs, &w.status, &w.crc, &w.blk, &w.expect}) b->release();
     }
-    for (DevBuf* b : {&p->d_res, &p->matches, &p->rows_seq[0], &p->rows_seq[1], &p->rows_qual[0], &p->rows_qual[1], &p->rows_len[0], &p->rows_len[1], &p->codes, &p->mol,
+    for (DevBuf* b : {&p->d_res, &p->matches, &p->matches_b, &p->rows_seq[0], &p->rows_seq[1], &p->rows_qual[0], &p->rows_qual[1], &p->rows_len[0], &p->rows_len[1], &p->codes, &p->mol,
                       &p->short_idx, &p->dest, &p->len1, &p->len2, &p->hist, &p->tmp, &p->perm, &p->sdest, &p->g1, &p->g2, &p->scan_tiles, &p->first, &p->g1_first,
                       &p->g2_first, &p->subs, &p->first_sub, &p->ranges, &p->crc, &p->tokens, &p->sub_out, &p->sub_bytes, &p->base1, &p->base2})
         b->release();
@@ -1860,6 +1910,9 @@ int qd_pipe_destroy(qd_pipe* p) {
         if (p->slab_ev[k]) (void)hipEventDestroy(p->slab_ev[k]);
     }
     if (p->sync_ev) (void)hipEventDestroy(p->sync_ev);
+    if (p->tables_up) (void)hipEventDestroy(p->tables_up);
+    for (hipStream_t st : p->is)
+        if (st) (void)hipStreamDestroy(st);
     if (p->cs) (void)hipStreamDestroy(p->cs);
     if (p->ds) (void)hipStreamDestroy(p->ds);
     delete p;

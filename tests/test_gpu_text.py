@@ -300,6 +300,7 @@ def test_pipeline_falls_back_to_the_host_for_blocks_the_device_refuses(tmp_path)
         ws = WriterSet(str(out), 1, deflate_device=-1)
         with hb.Pipe(eng, 6000) as pipe:
             pipe.set_option("test_fail_inflate_batch", 0)
+            pipe.set_option("inflate_streams", 2)  # ... with the inflate launches on the two streams of their own
             st = pipe.run([(cf.seq_R1[0], cf.seq_R2[0], cf.index_R1[0], cf.index_R2[0], ws.handle(), None, None)])
         ws.close()
         assert st["host_inflated_runs"] >= 4 and st["pairs"] == 20000
