@@ -148,8 +148,19 @@ __device__ int build(const uint8_t* length, int n, uint16_t* count, uint16_t* sy
         for (uint32_t s = lane; s < (uint32_t)n; s += nthr) {
             const uint32_t l = length[s] & 15;
             if (!l) continue;
+            // how many earlier symbols have this length: four lengths per LDS word (every length is < 16; byte by byte this loop was
+            // most of a table's time)
             uint32_t rank = 0;
-            for (uint32_t q = 0; q < s; ++q) rank += (length[q] & 15u) == l ? 1u : 0u;
+            {
+                const uint32_t* lw = reinterpret_cast<const uint32_t*>(length);  // (the tables' lengths start on word boundaries)
+                const uint32_t pat = l * 0x01010101u, whole = s >> 2;
+                auto equal_bytes = [&](uint32_t w) {  // 0x80 in every byte of w that equals l
+                    const uint32_t x = w ^ pat;
+                    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+                };
+                for (uint32_t q = 0; q < whole; ++q) rank += (uint32_t)__popc(equal_bytes(lw[q]));
+                if (s & 3u) rank += (uint32_t)__popc(equal_bytes(lw[whole]) & ((1u << (8u * (s & 3u))) - 1u));
+            }
             symbol[offs[l] + rank] = (uint16_t)s;
             const uint32_t c = next[l] + rank;
             if ((int)l <= bits) {  // the stream carries codes MSB first inside an LSB-first bit order: index by the reversed code
@@ -586,20 +597,54 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
                 if (tid == 0) L.lengths[CLORDER[k]] = (uint8_t)v;
             }
             __syncthreads();
-            if (b.cnt < 0 || build(L.lengths, 19, L.lcount, L.lsym, L.llut, 7, 9, tid) != 0) {
+            // (the code-length code's 7-bit table goes where the distance table will be; the literal table's space holds a table of
+            //  PAIRS meanwhile: 10 bits of the stream -> two plain lengths at once where two codes fit -- the walk over the ~300
+            //  code lengths is one dependent look-up after the other, by every wave alike, and was a sixth of a block's time)
+            static_assert(DBITS >= 7 && LBITS >= 10, "the header's two tables borrow the code tables' space");
+            if (b.cnt < 0 || build(L.lengths, 19, L.lcount, L.lsym, L.dlut, 7, 9, tid) != 0) {
                 err = b.cnt < 0 ? QD_INFLATE_TRUNCATED : QD_INFLATE_BAD_TABLE;
                 break;
             }
+            // entry: first symbol (5 bits) | its code's bits (3: 1..7, 0 = no code) | second symbol (4) | both codes' bits (4: 0 = no pair)
+            for (uint32_t i = tid; i < 1024u; i += NT) {
+                const uint32_t e1 = L.dlut[i & 127u];
+                uint32_t e = 0;
+                if (e1 >> 9) {
+                    const uint32_t s1 = e1 & 511u, n1 = e1 >> 9;
+                    e = s1 | (n1 << 5);
+                    const uint32_t e2 = L.dlut[(i >> n1) & 127u];
+                    if (s1 < 16 && (e2 >> 9) && (e2 & 511u) < 16 && n1 + (e2 >> 9) <= 10) e |= ((e2 & 511u) << 8) | ((n1 + (e2 >> 9)) << 12);
+                }
+                L.llut[i] = (uint16_t)e;
+            }
+            __syncthreads();
             int idx = 0, prev = 0;
 #pragma unroll 1
             while (idx < nlen + ndist && !err) {
                 refill(b);
                 int sym;
-                const uint32_t e = uni(L.llut[(uint32_t)b.buf & 127u]);
-                if (e >> 9) {
-                    sym = e & 511;
-                    b.buf >>= (e >> 9);
-                    b.cnt -= (e >> 9);
+                const uint32_t e = uni(L.llut[(uint32_t)b.buf & 1023u]);
+                if ((e >> 12) && idx + 2 <= nlen + ndist) {  // two plain lengths
+                    const int s1 = (int)(e & 31u), s2 = (int)((e >> 8) & 15u);
+                    const uint32_t used = e >> 12;
+                    b.buf >>= used;
+                    b.cnt -= (int)used;
+                    if (b.cnt < 0) {
+                        err = QD_INFLATE_TRUNCATED;
+                        break;
+                    }
+                    if (tid < 2) {
+                        const int at = idx + (int)tid;
+                        L.lengths[at < nlen ? at : 288 + (at - nlen)] = (uint8_t)(tid ? s2 : s1);
+                    }
+                    idx += 2;
+                    prev = s2;
+                    continue;
+                }
+                if ((e >> 5) & 7u) {
+                    sym = (int)(e & 31u);
+                    b.buf >>= ((e >> 5) & 7u);
+                    b.cnt -= (int)((e >> 5) & 7u);
                 } else {
                     sym = -1;
                 }
