@@ -712,37 +712,49 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
         SpanMemo memo;
         memo.pos[0] = memo.pos[1] = memo.pos[2] = 0xFFFFFFFFu;
         const uint32_t mark0 = bitpos + tid * span + MEMO_STEP;
+        // A round: the lanes whose start moved decode their spans again; then every lane compares its start with its predecessor's
+        // exit (a shuffle inside the wave, LDS across waves), the waves post their first lane that is out of step and their first
+        // that met the end, and every lane takes the minimum -- two barriers a round (r04 first had four, and atomics).
+        uint32_t st = S.start[tid];
+        uint32_t* const wave_first = S.start_sum;  // [0, NT/64): out of step, [NT/64, 2 NT/64): ended (the scan below uses the space afterwards)
 #pragma unroll 1
         for (int round = 0; round <= QD_INFLATE2_MAX_ROUNDS; ++round) {
-            const uint32_t st = S.start[tid];
             // (a lane whose start did not move keeps what it found: the confirming rounds decode only the spans that still change)
             if (st != decoded_from) {
                 decode_span<false, QD_INFLATE2_MEMO != 0>(pw, total_bits, L, lit_codes, dist_codes, st, my_limit, ob, 0, olen, list, 0, mcap, ex, no, nm, fl, &memo, mark0);
                 decoded_from = st;
             }
-            S.exitp[tid] = ex;
-            S.nout[tid] = no;
-            S.nmat[tid] = nm;
-            S.flag[tid] = fl;
-            if (tid == 0) {
-                S.ctl[0] = NT;  // first lane that does not start at its predecessor's exit
-                S.ctl[1] = NT;  // first lane that ends the block or fails
+            const uint32_t lane = tid & 63u, wave = tid >> 6;
+            if (lane == 63) S.exitp[tid] = ex;
+            __syncthreads();
+            uint32_t prev_exit = (uint32_t)__shfl_up((int)ex, 1, 64);
+            if (lane == 0) prev_exit = tid ? S.exitp[tid - 1] : st;
+            const uint64_t off = __ballot(st != prev_exit), ended = __ballot(fl != 0);
+            if (lane == 0) {
+                wave_first[wave] = off ? wave * 64u + (uint32_t)__builtin_ctzll(off) : (uint32_t)NT;
+                wave_first[NT / 64 + wave] = ended ? wave * 64u + (uint32_t)__builtin_ctzll(ended) : (uint32_t)NT;
             }
             __syncthreads();
-            if (tid > 0 && st != S.exitp[tid - 1]) atomicMin(&S.ctl[0], tid);
-            if (fl) atomicMin(&S.ctl[1], tid);
-            __syncthreads();
-            const uint32_t confirmed = S.ctl[0], ender = S.ctl[1];  // lanes [0, confirmed) are the sequential decode
-            __syncthreads();
+            uint32_t confirmed = NT, ender = NT;  // lanes [0, confirmed) are the sequential decode; ender: the first lane that ends the block or fails
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) {
+                confirmed = min(confirmed, wave_first[w]);
+                ender = min(ender, wave_first[NT / 64 + w]);
+            }
             if (ender < confirmed) {
                 eob_lane = ender;
                 break;
             }
             if (confirmed >= NT) break;  // every lane confirmed and none met the end: the payload ended first
-            if (tid > 0) S.start[tid] = S.exitp[tid - 1];
-            __syncthreads();
+            st = prev_exit;
             ++rounds_used;
         }
+        S.start[tid] = st;
+        S.exitp[tid] = ex;
+        S.nout[tid] = no;
+        S.nmat[tid] = nm;
+        S.flag[tid] = fl;
+        __syncthreads();
         ++rounds_used;
         ++dblocks;
         stamp(3, since);  // rounds
