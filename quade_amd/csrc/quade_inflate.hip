@@ -272,6 +272,7 @@ struct Lds2 {
     uint32_t start_sum[2 * (NT / 64)];  // the waves' totals of the span scan
     uint32_t ctl[8];
     uint32_t win_first[65536 / QD_INFLATE2_Q + 2];  // per window of the match stage: the first match that starts in it
+    uint32_t ll[1 << LBITS], dl[1 << DBITS];        // the span decode's tables (lit_entry / dist_entry)
 };
 enum { F_EOB = 1, F_ERR_CODE = 2, F_ERR_TRUNC = 4 };
 
@@ -299,27 +300,39 @@ __device__ __forceinline__ int slow_sym(uint32_t bits, const uint16_t* count, co
     return -1;
 }
 
-// What a lane keeps of its last decode of its span: the result, and the first token boundary at or behind each of three marks
-// early in the span with the counts up to there.  A later decode of the span from another start that lands on one of these
-// boundaries has joined the old path -- the rest would be the same tokens -- and takes the old result from there on: Huffman
-// codes resynchronise within a few symbols, so the second round of a block decodes a fifth of a span instead of all of it.
-struct SpanMemo {
-    uint32_t pos[3], out[3], mat[3];  // pos 0xFFFFFFFF: none
-    uint32_t ex, no, nm, fl;
-};
-#ifndef QD_INFLATE2_MEMO
-#define QD_INFLATE2_MEMO 1 /* A/B: 0 = every round decodes whole spans */
-#endif
-constexpr uint32_t MEMO_STEP = 40;  // bits between the marks
+// The span decode's tables: what build() made (symbol | code bits), widened so that a token costs one look-up and no arithmetic on
+// the symbol.  Literal/length entry: code bits (4; 0 = a longer code, or none) | extra bits << 4 | value << 8 (the byte, or
+// the length's base) | kind << 17 (0 literal, 1 length, 2 end of block, 3 no such symbol).  Distance entry: code bits | extra
+// bits << 4 | base << 8 (0 = no such symbol).  RFC 1951's base/extra tables are regular: computed, not looked up.
+__device__ __forceinline__ uint32_t lit_entry(uint32_t sym, uint32_t nbits) {
+    if (sym < 256) return nbits | (sym << 8);
+    if (sym == 256) return nbits | (2u << 17);
+    const uint32_t s = sym - 257;
+    if (s >= 29) return nbits | (3u << 17);
+    const uint32_t le = (s < 8 || s == 28) ? 0u : (s >> 2) - 1u;
+    const uint32_t base = s < 8 ? 3u + s : (s == 28 ? 258u : 3u + ((4u + (s & 3u)) << le));
+    return nbits | (le << 4) | (base << 8) | (1u << 17);
+}
+__device__ __forceinline__ uint32_t dist_entry(uint32_t ds, uint32_t nbits) {
+    if (ds >= 30) return nbits;
+    const uint32_t de = ds < 4 ? 0u : (ds >> 1) - 1u;
+    const uint32_t base = ds < 4 ? 1u + ds : 1u + ((2u + (ds & 1u)) << de);
+    return nbits | (de << 4) | (base << 8);
+}
 
 // Tokens from bit `pos` on while they start before `limit`.  WRITE: literals -> ob[o...], matches -> list[m...], and win_first[w]
-// = the lowest list index of a match whose first byte lies in window w of the text (the match stage's windows).  MEMO (counting
-// rounds): `memo` is read (the lane's last decode, if any) and rewritten; mark0 = the first mark (a property of the span, not of the start).
-template <bool WRITE, bool MEMO = false>
-__device__ __forceinline__ void decode_span(const uint32_t* pw, uint32_t total_bits, const Lds& L, int nlsym, int ndsym, uint32_t pos,
-                                            uint32_t limit, uint8_t* ob, uint32_t o, uint32_t olen, unsigned long long* list, uint32_t m,
-                                            uint32_t mcap, uint32_t& exit_pos, uint32_t& n_out, uint32_t& n_mat, uint32_t& flag,
-                                            SpanMemo* memo = nullptr, uint32_t mark0 = 0, uint32_t* win_first = nullptr) {
+// = the lowest list index of a match whose first byte lies in window w of the text (the match stage's windows).  ll / dl: the
+// widened tables above; L: the canonical tables behind them, for codes longer than the first-level look-up.
+// (Tried on top of this and dropped, both measured with the timing build on the end-to-end job's blocks: remembering three token
+//  boundaries per lane so that a re-decode which meets one takes the old result from there -- 192 us of rounds per block with it,
+//  180 without: the bookkeeping ran on every token; and letting every lane decode 1 / 3 / 6 spans ahead of its own first, for a
+//  start that is already in step -- 16.5 -> 14.6 / 11.0 / 7.4 rounds per block, 191 -> 197 / 233 / 306 us: a round's cost is
+//  its decode, not its barriers.)
+template <bool WRITE>
+__device__ __forceinline__ void decode_span(const uint32_t* pw, uint32_t total_bits, const Lds& L, const uint32_t* ll, const uint32_t* dl, int nlsym,
+                                            int ndsym, uint32_t pos, uint32_t limit, uint8_t* ob, uint32_t o, uint32_t olen, unsigned long long* list,
+                                            uint32_t m, uint32_t mcap, uint32_t& exit_pos, uint32_t& n_out, uint32_t& n_mat, uint32_t& flag,
+                                            uint32_t* win_first = nullptr) {
     uint32_t out = 0, mat = 0, fl = 0;
     uint32_t last_win = 0xFFFFFFFFu;
     // The stream from `pos` on in a register: `have` bits of it in `buf`, the word behind them (`ahead`) fetched one refill early.
@@ -347,114 +360,64 @@ __device__ __forceinline__ void decode_span(const uint32_t* pw, uint32_t total_b
         have -= n;
         pos += n;
     };
-    SpanMemo nw;
-    uint32_t nrec = 0;
-    if (MEMO) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) nw.pos[k] = 0xFFFFFFFFu;
-    }
 #pragma unroll 1
-    for (int guard = 0; guard < 70000 && pos < limit; ++guard) {
-        if (MEMO) {
-            // joined the last decode's path?
-            int hit = -1;
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                if (pos == memo->pos[k]) hit = k;
-            if (hit >= 0) {
-                uint32_t oo = 0, om = 0;
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if (k == hit) {
-                        oo = memo->out[k];
-                        om = memo->mat[k];
-                    }
-                const uint32_t d_out = out - oo, d_mat = mat - om;  // (what this decode counted up to here, less what the old one had)
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if ((uint32_t)k >= nrec && memo->pos[k] != 0xFFFFFFFFu && memo->pos[k] >= pos) {  // the marks still ahead: the old path's
-                        nw.pos[k] = memo->pos[k];
-                        nw.out[k] = memo->out[k] + d_out;
-                        nw.mat[k] = memo->mat[k] + d_mat;
-                    }
-                out = memo->no + d_out;
-                mat = memo->nm + d_mat;
-                fl = memo->fl;
-                pos = memo->ex;
-                break;
-            }
-            // the first boundary at or behind the next mark
-            if (nrec < 3 && pos >= mark0 + nrec * MEMO_STEP) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if ((uint32_t)k == nrec) {
-                        nw.pos[k] = pos;
-                        nw.out[k] = out;
-                        nw.mat[k] = mat;
-                    }
-                ++nrec;
-            }
-        }
+    while (pos < limit) {  // (every turn takes at least one bit)
         if (pos >= total_bits) {
             fl = F_ERR_TRUNC;
             break;
         }
         top_up();
-        int sym;
-        uint32_t used;
-        const uint32_t e = L.llut[(uint32_t)buf & ((1u << LBITS) - 1u)];
-        if (e >> 9) {
-            sym = (int)(e & 511u);
-            used = e >> 9;
-        } else {
-            sym = slow_sym((uint32_t)buf, L.lcount, L.lsym, nlsym, used);
+        uint32_t e = ll[(uint32_t)buf & ((1u << LBITS) - 1u)];
+        if ((e & 15u) == 0) {
+            uint32_t used;
+            const int sym = slow_sym((uint32_t)buf, L.lcount, L.lsym, nlsym, used);
             if (sym < 0) {
                 fl = F_ERR_CODE;
                 break;
             }
+            e = lit_entry((uint32_t)sym, used);
         }
-        drop(used);
-        if (sym < 256) {
+        const uint32_t nb = e & 15u, kind = e >> 17;
+        if (kind == 0) {
             if (WRITE) {
-                if (o + out < olen) ob[o + out] = (uint8_t)sym;
+                if (o + out < olen) ob[o + out] = (uint8_t)(e >> 8);
                 else fl = F_ERR_CODE;
             }
             ++out;
+            drop(nb);
             continue;
         }
-        if (sym == 256) {
-            fl |= F_EOB;
+        if (kind != 1) {
+            if (kind == 2) {
+                fl |= F_EOB;
+                drop(nb);
+            } else {
+                fl = F_ERR_CODE;
+            }
             break;
         }
-        sym -= 257;
-        if (sym >= 29) {
-            fl = F_ERR_CODE;
-            break;
-        }
-        // (base and extra bits of the length and distance symbols by arithmetic -- RFC 1951's tables are regular -- not from tables
-        //  in constant memory, which a lane indexes with its own symbol: a trip to memory each.  Code <= 15 bits + <= 5 extra
-        //  bits: inside the 33 in hand.)
-        const uint32_t s = (uint32_t)sym;
-        const uint32_t le = (s < 8 || s == 28) ? 0u : (s >> 2) - 1u;
-        const uint32_t len = (s < 8 ? 3u + s : (s == 28 ? 258u : 3u + ((4u + (s & 3u)) << le))) + ((uint32_t)buf & ((1u << le) - 1u));
-        drop(le);
+        // (code <= 15 bits + <= 5 extra bits: inside the 33 in hand)
+        const uint32_t le = (e >> 4) & 15u;
+        const uint32_t len = ((e >> 8) & 511u) + ((uint32_t)(buf >> nb) & ((1u << le) - 1u));
+        drop(nb + le);
         top_up();
-        int ds;
-        const uint32_t d = L.dlut[(uint32_t)buf & ((1u << DBITS) - 1u)];
-        if (d >> 5) {
-            ds = (int)(d & 31u);
-            used = d >> 5;
-        } else {
-            ds = slow_sym((uint32_t)buf, L.dcount, L.dsym, ndsym, used);
+        uint32_t d = dl[(uint32_t)buf & ((1u << DBITS) - 1u)];
+        if ((d & 15u) == 0) {
+            uint32_t used;
+            const int ds = slow_sym((uint32_t)buf, L.dcount, L.dsym, ndsym, used);
+            if (ds < 0) {
+                fl = F_ERR_CODE;
+                break;
+            }
+            d = dist_entry((uint32_t)ds, used);
         }
-        if (ds < 0 || ds >= 30) {
+        if ((d >> 8) == 0) {
             fl = F_ERR_CODE;
             break;
         }
-        drop(used);
-        const uint32_t de = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
-        const uint32_t dist = (ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << de)) + ((uint32_t)buf & ((1u << de) - 1u));
-        drop(de);
+        const uint32_t dn = d & 15u, de = (d >> 4) & 15u;
+        const uint32_t dist = (d >> 8) + ((uint32_t)(buf >> dn) & ((1u << de) - 1u));
+        drop(dn + de);
         if (pos > total_bits) {
             fl = F_ERR_TRUNC;
             break;
@@ -480,13 +443,6 @@ __device__ __forceinline__ void decode_span(const uint32_t* pw, uint32_t total_b
     n_out = out;
     n_mat = mat;
     flag = fl;
-    if (MEMO) {
-        nw.ex = pos;
-        nw.no = out;
-        nw.nm = mat;
-        nw.fl = fl;
-        *memo = nw;
-    }
 }
 
 template <int NT>
@@ -698,6 +654,17 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
             err = QD_INFLATE_BAD_TABLE;
             break;
         }
+#pragma unroll 1
+        for (uint32_t i = tid; i < (1u << LBITS); i += NT) {
+            const uint32_t e = L.llut[i];
+            S.ll[i] = (e >> 9) ? lit_entry(e & 511u, e >> 9) : 0u;
+        }
+#pragma unroll 1
+        for (uint32_t i = tid; i < (1u << DBITS); i += NT) {
+            const uint32_t e = L.dlut[i];
+            S.dl[i] = (e >> 5) ? dist_entry(e & 31u, e >> 5) : 0u;
+        }
+        __syncthreads();
         stamp(2, since);  // the two tables
         // ---- the block's symbols: 256 spans, guessed starts, rounds until the chain from lane 0 is confirmed up to the end-of-block symbol
         const uint32_t bitpos = 8u * (b.pos - b.ahead_bytes) - (uint32_t)b.cnt;  // (cnt >= 0: checked above)
@@ -709,9 +676,6 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
         __syncthreads();
         uint32_t eob_lane = NT;
         uint32_t ex = 0, no = 0, nm = 0, fl = 0, decoded_from = 0xFFFFFFFFu;
-        SpanMemo memo;
-        memo.pos[0] = memo.pos[1] = memo.pos[2] = 0xFFFFFFFFu;
-        const uint32_t mark0 = bitpos + tid * span + MEMO_STEP;
         // A round: the lanes whose start moved decode their spans again; then every lane compares its start with its predecessor's
         // exit (a shuffle inside the wave, LDS across waves), the waves post their first lane that is out of step and their first
         // that met the end, and every lane takes the minimum -- two barriers a round (r04 first had four, and atomics).
@@ -721,7 +685,7 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
         for (int round = 0; round <= QD_INFLATE2_MAX_ROUNDS; ++round) {
             // (a lane whose start did not move keeps what it found: the confirming rounds decode only the spans that still change)
             if (st != decoded_from) {
-                decode_span<false, QD_INFLATE2_MEMO != 0>(pw, total_bits, L, lit_codes, dist_codes, st, my_limit, ob, 0, olen, list, 0, mcap, ex, no, nm, fl, &memo, mark0);
+                decode_span<false>(pw, total_bits, L, S.ll, S.dl, lit_codes, dist_codes, st, my_limit, ob, 0, olen, list, 0, mcap, ex, no, nm, fl);
                 decoded_from = st;
             }
             const uint32_t lane = tid & 63u, wave = tid >> 6;
@@ -820,8 +784,8 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
         __syncthreads();
         if (tid <= eob_lane) {
             uint32_t ex, no, nm, fl;
-            decode_span<true>(pw, total_bits, L, lit_codes, dist_codes, S.start[tid], my_limit, ob, S.nout[tid], olen, list, S.nmat[tid], mcap, ex, no,
-                              nm, fl, nullptr, 0, S.win_first);
+            decode_span<true>(pw, total_bits, L, S.ll, S.dl, lit_codes, dist_codes, S.start[tid], my_limit, ob, S.nout[tid], olen, list, S.nmat[tid], mcap,
+                              ex, no, nm, fl, S.win_first);
         }
         __threadfence_block();
         __syncthreads();
@@ -1127,8 +1091,11 @@ template <int NT>
 static size_t inflate2_lds(uint32_t max_in_len) {
     return ((sizeof(v2::Lds2<NT>) + 15) & ~(size_t)15) + ((size_t)((max_in_len + 3) / 4) + 4) * 4 + 65536 + 16 + 2 * QD_INFLATE2_Q;
 }
+// The kernel's statically declared LDS (build()'s counters) comes on top of the dynamic part: a launch 60 bytes under the CU's
+// 160 KB by its dynamic size alone was refused by the runtime.
+constexpr size_t STATIC_LDS = 256;
 // (what the narrowest instantiation needs: a launch that fits no form is the one-wave kernel's)
-size_t qd_inflate2_lds(uint32_t max_in_len) { return inflate2_lds<512>(max_in_len); }
+size_t qd_inflate2_lds(uint32_t max_in_len) { return inflate2_lds<512>(max_in_len) + STATIC_LDS; }
 
 template <int NT>
 static hipError_t launch_inflate2(const uint8_t* comp, const qd_inflate_block* blocks, uint32_t n_blocks, uint8_t* out, int32_t* status,
@@ -1164,14 +1131,14 @@ hipError_t qd_launch_inflate2(const uint8_t* comp, const qd_inflate_block* block
                               const uint32_t* expect_crc) {
     if (n_blocks == 0) return hipSuccess;
 #if QD_INFLATE2_THREADS == 1024 || QD_INFLATE2_THREADS == 0
-    if (inflate2_lds<1024>(max_in_len) <= 160 * 1024)
+    if (inflate2_lds<1024>(max_in_len) + STATIC_LDS <= 160 * 1024)
         return launch_inflate2<1024>(comp, blocks, n_blocks, out, status, matches, matches_per_block, max_in_len, st, rounds_out, expect_crc);
 #endif
 #if QD_INFLATE2_THREADS == 256
-    if (inflate2_lds<256>(max_in_len) <= 160 * 1024)
+    if (inflate2_lds<256>(max_in_len) + STATIC_LDS <= 160 * 1024)
         return launch_inflate2<256>(comp, blocks, n_blocks, out, status, matches, matches_per_block, max_in_len, st, rounds_out, expect_crc);
 #endif
-    if (inflate2_lds<512>(max_in_len) > 160 * 1024) return hipErrorInvalidValue;
+    if (inflate2_lds<512>(max_in_len) + STATIC_LDS > 160 * 1024) return hipErrorInvalidValue;
     return launch_inflate2<512>(comp, blocks, n_blocks, out, status, matches, matches_per_block, max_in_len, st, rounds_out, expect_crc);
 }
 
