@@ -618,6 +618,8 @@ struct qd_pipe {
     hipEvent_t slab_ev[3] = {nullptr, nullptr, nullptr};
     size_t window_max = WINDOW_MAX;                // text a window may hold (the index pass of a shared chunk raises it for its one window)
     bool reserved = false;                         // the buffers have been sized for batch_pairs (after the first scan)
+    std::thread reserve_thread;                    // allocates the output side meanwhile (reserve_output)
+    int reserve_rc = QD_OK;
     int64_t max_r1_bytes = 0;                      // size of the run's largest seq_R1 file
     bool r1_compressed = true;
     std::mutex om;
@@ -1085,11 +1087,55 @@ uint32_t piece_bytes_for(const qd_pipe* p, uint64_t text_bytes, uint64_t n_dest)
     return pb;
 }
 
+// The output side's buffers (two thirds of the bytes: text, member slots, packed members, the coder's scratch): allocated by a thread of
+// their own while the driver fills and scans the first batch's windows -- a device allocation costs ~10 ms per GB, 0.1-0.25 s for a
+// pipeline's 12 GB, and the first batch's inflate launches need none of these.  Joined before the first batch is processed.
+int reserve_output(qd_pipe* p, uint32_t n_dest, double out_text) {
+    if (hipSetDevice(p->device) != hipSuccess) return QD_ERR_HIP;
+    const size_t T = (size_t)out_text + (size_t)n_dest * 64;
+    const uint32_t piece_bytes = piece_bytes_for(p, T, n_dest);
+    const size_t n_pieces = T / piece_bytes + 2 * (size_t)n_dest + 2, n_subs = T / QD_LZ_SUB + n_pieces;
+    const size_t out_stride = (size_t)qd_huffman_member_bound(piece_bytes), sub_stride = (size_t)qd_huffman_member_bound(QD_LZ_SUB);
+    hipError_t e = hipSuccess;
+    auto need = [&](DevBuf& b, size_t n) {  // (first allocations: nothing to keep, no stream involved)
+        if (e == hipSuccess) e = b.need(n);
+    };
+    for (OutSet& o : p->out) {
+        need(o.text, T + 64);
+        need(o.pieces, n_pieces * sizeof(qd_deflate_piece));
+        need(o.members, n_pieces * out_stride);
+        need(o.member_len, n_pieces * 4);
+        need(o.member_off, (n_pieces + 1) * 8);
+        need(o.packed, n_pieces * out_stride);
+    }
+    need(p->subs, (n_subs + 1) * sizeof(qd_lz_sub));
+    need(p->ranges, (n_subs + 1) * sizeof(qd_crc_range));
+    need(p->crc, (n_subs + 1) * 4);
+    need(p->first_sub, (n_pieces + 1) * 4);
+    need(p->tokens, n_subs * QD_LZ_SUB * 4);
+    need(p->sub_out, n_subs * sub_stride);
+    need(p->sub_bytes, n_subs * 4);
+    return e == hipSuccess ? QD_OK : QD_ERR_HIP;
+}
+
+int join_reserve(qd_pipe* p) {
+    if (!p->reserve_thread.joinable()) return QD_OK;
+    {
+        Tick tick(g_alloc_seconds);
+        p->reserve_thread.join();
+    }
+    return p->reserve_rc == QD_OK ? QD_OK : pfail(p, QD_ERR_HIP, "device allocation of the output buffers failed");
+}
+
 // Every buffer at the size a full batch needs, in one go, once the first scan has told what a record of every stream weighs:
 // growing them one by one as the first batches arrive drains the compute stream each time (a quarter of a 16 M-pair run).
 int reserve_buffers(qd_pipe* p, uint32_t B, uint32_t n_dest) {
     const qd_layout& L = p->lay;
     double out_text = 0;
+    for (int s = 0; s < 2; ++s) out_text += (double)B * (p->win[s].avg > 0 ? p->win[s].avg : 400.0) * 1.06;
+    if (join_reserve(p) != QD_OK) return QD_ERR_HIP;
+    p->reserve_rc = QD_OK;
+    p->reserve_thread = std::thread([p, n_dest, out_text] { p->reserve_rc = reserve_output(p, n_dest, out_text); });
     for (int s = 0; s < p->n_streams; ++s) {
         Window& w = p->win[s];
         const double avg = w.avg > 0 ? w.avg : (s < 2 ? 400.0 : 64.0);
@@ -1106,7 +1152,6 @@ int reserve_buffers(qd_pipe* p, uint32_t B, uint32_t n_dest) {
         PCHK(p, w.expect.need(blocks * 4, 0, p->cs));
         PCHK(p, w.status.need(blocks * 4, 0, p->cs));
         PCHK(p, w.crc.need(blocks * 4, 0, p->cs));
-        if (s < 2) out_text += (double)B * avg * 1.06;
     }
     PCHK(p, p->matches.need((size_t)LAUNCH_BLOCKS * QD_INFLATE_MATCHES_PER_BLOCK * 8, 0, p->cs));
     if (p->n_is > 1) PCHK(p, p->matches_b.need((size_t)LAUNCH_BLOCKS * QD_INFLATE_MATCHES_PER_BLOCK * 8, 0, p->cs));
@@ -1125,25 +1170,6 @@ int reserve_buffers(qd_pipe* p, uint32_t B, uint32_t n_dest) {
     PCHK(p, p->dest.need(n * 2 + 64, 0, p->cs));
     PCHK(p, p->sdest.need(n * 2 + 64, 0, p->cs));
     PCHK(p, p->scan_tiles.need((n / 4096 + 4) * 4, 0, p->cs));
-    const size_t T = (size_t)out_text + (size_t)n_dest * 64;
-    const uint32_t piece_bytes = piece_bytes_for(p, T, n_dest);
-    const size_t n_pieces = T / piece_bytes + 2 * (size_t)n_dest + 2, n_subs = T / QD_LZ_SUB + n_pieces;
-    const size_t out_stride = (size_t)qd_huffman_member_bound(piece_bytes), sub_stride = (size_t)qd_huffman_member_bound(QD_LZ_SUB);
-    for (OutSet& o : p->out) {
-        PCHK(p, o.text.need(T + 64, 0, p->cs));
-        PCHK(p, o.pieces.need(n_pieces * sizeof(qd_deflate_piece), 0, p->cs));
-        PCHK(p, o.members.need(n_pieces * out_stride, 0, p->cs));
-        PCHK(p, o.member_len.need(n_pieces * 4, 0, p->cs));
-        PCHK(p, o.member_off.need((n_pieces + 1) * 8, 0, p->cs));
-        PCHK(p, o.packed.need(n_pieces * out_stride, 0, p->cs));
-    }
-    PCHK(p, p->subs.need((n_subs + 1) * sizeof(qd_lz_sub), 0, p->cs));
-    PCHK(p, p->ranges.need((n_subs + 1) * sizeof(qd_crc_range), 0, p->cs));
-    PCHK(p, p->crc.need((n_subs + 1) * 4, 0, p->cs));
-    PCHK(p, p->first_sub.need((n_pieces + 1) * 4, 0, p->cs));
-    PCHK(p, p->tokens.need(n_subs * QD_LZ_SUB * 4, 0, p->cs));
-    PCHK(p, p->sub_out.need(n_subs * sub_stride, 0, p->cs));
-    PCHK(p, p->sub_bytes.need(n_subs * 4, 0, p->cs));
     return QD_OK;
 }
 
@@ -1159,6 +1185,7 @@ int take_out_set(qd_pipe* p, int b) {
 
 // pairs [0, n) of the four windows: rows -> codes -> sorted by destination -> formatted -> coded; members to the collector
 int process_batch(qd_pipe* p, uint32_t n, qd_sink* sink, int64_t batch_index) {
+    if (join_reserve(p) != QD_OK) return QD_ERR_HIP;
     const qd_layout& L = p->lay;
     const qdio::SinkInfo si = qdio::sink_info(sink);
     const uint32_t S = si.n_samples, nd = 2 * S + 1;
@@ -1884,6 +1911,7 @@ int qd_pipe_run(qd_pipe* p, const qd_pipe_chunk* chunks, int32_t n_chunks, qd_pi
 
 int qd_pipe_destroy(qd_pipe* p) {
     if (!p) return QD_OK;
+    if (p->reserve_thread.joinable()) p->reserve_thread.join();
     (void)hipSetDevice(p->device);
     if (p->cs) (void)hipStreamSynchronize(p->cs);
     if (p->ds) (void)hipStreamSynchronize(p->ds);
