@@ -277,14 +277,14 @@ hipError_t qd_launch_huffman(const uint8_t* text, const qd_deflate_piece* pieces
 // on fastq text: the read names (a record's name repeats most of its predecessor's) and the quality lines (runs, and
 // stretches shared with earlier lines).
 //
-// A piece (~2 MB of formatted records) is cut into sub-blocks of 64 KiB; one workgroup (4 waves) per sub-block makes one
+// A piece (1 MiB of formatted records in the pipeline) is cut into sub-blocks of 64 KiB; one workgroup (QD_LZ_WAVES = 8 waves) per sub-block makes one
 // dynamic-Huffman block that ends on a byte boundary (an empty stored block behind it, as pigz joins the work of its
 // threads); a second kernel strings a piece's sub-blocks together behind the gzip header and closes the member with an
 // empty final block, CRC-32 (made on the host) and ISIZE.
 //
-//  1. candidates, for every position of the sub-block (text staged in LDS): rounds of 256 positions, a stretch of 64 per
+//  1. candidates, for every position of the sub-block (text staged in LDS): rounds of 64 x waves positions, a stretch of 64 per
 //     wave, one barrier per round (so a look-up sees every position up to the round before its own -- what the parse
-//     needs is the NEAREST earlier occurrence; four waves on four quarters of the sub-block, the first form, made files
+//     needs is the NEAREST earlier occurrence; the waves on separate parts of the sub-block, the first form, made files
 //     60 % larger).  Each lane hashes the 4 bytes at its position into a table of 2 048 buckets x the 2 last positions with
 //     that hash (16 bit each; an entry is only a guess), compares both candidates and the position before its own
 //     (distance 1: runs) with its own next 32 bytes, keeps the longest (the nearest on a tie), and enters its own
@@ -293,18 +293,19 @@ hipError_t qd_launch_huffman(const uint8_t* text, const qd_deflate_piece* pieces
 //     the sub-block's byte histogram) against 13 + log2(distance) -- short matches inside the sequence lines and inside
 //     lines of random qualities cost more than their literals.  (length <= 32, distance) per position goes to the
 //     sub-block's scratch.
-//  2. the parse: every wave walks a quarter of the sub-block (a match never crosses into the next quarter), 64
+//  2. the parse: every wave walks its part of the sub-block (a match never crosses into the next part), 64
 //     positions at a time, as a scalar loop: a position with a match is deferred by one literal when its successor's
 //     match is longer (lazy evaluation on the 32-byte views); a 32-byte match is extended by all 64 lanes comparing 4
 //     bytes each (256 bytes in one step: ballot + count of trailing zeros = the length); the walk jumps behind the
 //     match; positions without a match are literals and are skipped in one step up to the next candidate.  Tokens
 //     (literal | length, distance) replace the candidates in the scratch, in text order; their symbols go into two LDS
 //     histograms.
-//  3. the two length-limited codes: symbols ranked by (count, symbol) by all threads, the two-queue merge and the Kraft
-//     repair of the Huffman-only kernel by one; the header carries the code lengths run-length coded with a fixed
-//     code-length code (~65 bytes per block).
-//  4. 256 tokens per step are coded in parallel: bits and bit count per lane, workgroup scan, OR into an LDS word buffer,
-//     whole words leave coalesced.
+//  3. the two length-limited codes: symbols ranked by (count, symbol), leaf depths, the lengths' hand-out and the canonical
+//     codes by all threads, the two-queue merge and the Kraft repair by one; the header carries the code lengths
+//     run-length coded with a fixed code-length code (~65 bytes per block; one lane).
+//  4. four tokens per lane and step are coded in parallel: bits and bit counts per lane, workgroup scan, OR into an LDS word
+//     buffer, whole words leave coalesced.
+// Where a sub-block's time goes: build with -DQD_LZ_TIMING.
 // Against the host's coders on 2 MB of fastq text (tools/lz_model.cpp is the parse on the CPU; tools/lz_bench.py the device):
 // binned qualities 18.7 % of the text (zlib level 1: 22.5 %, level 6: 19.0 %), uniform random qualities 49.7 % (52.2 / 47.8).
 // Nothing is read or written outside the piece's text, the scratch slots and the output slots; a sub-block or member
