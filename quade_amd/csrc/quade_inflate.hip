@@ -327,7 +327,9 @@ __device__ __forceinline__ uint32_t dist_entry(uint32_t ds, uint32_t nbits) {
 //  boundaries per lane so that a re-decode which meets one takes the old result from there -- 192 us of rounds per block with it,
 //  180 without: the bookkeeping ran on every token; and letting every lane decode 1 / 3 / 6 spans ahead of its own first, for a
 //  start that is already in step -- 16.5 -> 14.6 / 11.0 / 7.4 rounds per block, 191 -> 197 / 233 / 306 us: a round's cost is
-//  its decode, not its barriers.)
+//  its decode, not its barriers.  One CODE per turn instead of one token -- a uniform short turn, the table chosen by a state flag,
+//  so that a wave with literals and matches side by side does not run the long match path on every turn: 158 -> 182 us; four of
+//  ten tokens of these blocks are matches, and each then costs two turns.)
 template <bool WRITE>
 __device__ __forceinline__ void decode_span(const uint32_t* pw, uint32_t total_bits, const Lds& L, const uint32_t* ll, const uint32_t* dl, int nlsym,
                                             int ndsym, uint32_t pos, uint32_t limit, uint8_t* ob, uint32_t o, uint32_t olen, unsigned long long* list,
