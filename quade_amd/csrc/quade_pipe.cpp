@@ -1087,6 +1087,10 @@ uint32_t piece_bytes_for(const qd_pipe* p, uint64_t text_bytes, uint64_t n_dest)
     return pb;
 }
 
+// The coder's scratch of candidates / tokens is 4 bytes per byte of text: a batch's sub-blocks go through it a quarter at a time (a
+// launch of some thousand workgroups still fills the device several times over), which keeps 2.5 GB of a 2 M-pair batch's 3.3 unallocated.
+uint32_t lz_slice_subs(uint32_t n_subs) { return std::max<uint32_t>(2048, (n_subs + 3) / 4); }
+
 // The output side's buffers (two thirds of the bytes: text, member slots, packed members, the coder's scratch): allocated by a thread of
 // their own while the driver fills and scans the first batch's windows -- a device allocation costs ~10 ms per GB, 0.1-0.25 s for a
 // pipeline's 12 GB, and the first batch's inflate launches need none of these.  Joined before the first batch is processed.
@@ -1112,7 +1116,7 @@ int reserve_output(qd_pipe* p, uint32_t n_dest, double out_text) {
     need(p->ranges, (n_subs + 1) * sizeof(qd_crc_range));
     need(p->crc, (n_subs + 1) * 4);
     need(p->first_sub, (n_pieces + 1) * 4);
-    need(p->tokens, n_subs * QD_LZ_SUB * 4);
+    need(p->tokens, (size_t)lz_slice_subs((uint32_t)std::min<size_t>(n_subs, 0xFFFFFFFFu)) * QD_LZ_SUB * 4);
     need(p->sub_out, n_subs * sub_stride);
     need(p->sub_bytes, n_subs * 4);
     return e == hipSuccess ? QD_OK : QD_ERR_HIP;
@@ -1394,12 +1398,14 @@ int process_batch(qd_pipe* p, uint32_t n, qd_sink* sink, int64_t batch_index) {
     static_assert(sizeof(qd_deflate_piece) == 16 && offsetof(qd_deflate_piece, crc32) == 12, "the combined CRCs land in the piece table");
     uint32_t* piece_crc = reinterpret_cast<uint32_t*>(o.pieces.p) + 3;
     if (si.level == 1) {
-        PCHK(p, p->tokens.need((size_t)n_subs * QD_LZ_SUB * 4, 0, p->cs));
+        const uint32_t slice = lz_slice_subs(n_subs);
+        PCHK(p, p->tokens.need((size_t)slice * QD_LZ_SUB * 4, 0, p->cs));
         PCHK(p, p->sub_out.need((size_t)n_subs * (size_t)sub_stride, 0, p->cs));
         PCHK(p, p->sub_bytes.need((size_t)n_subs * 4, 0, p->cs));
         // the sub-blocks' CRC-32s come out of the coder (taken while a sub-block's text is staged), the pieces' are combined from them
-        PCHK(p, qd_launch_lz_subblocks(o.text.p, p->subs.as<qd_lz_sub>(), n_subs, p->tokens.as<uint32_t>(), p->sub_out.p, sub_stride, p->sub_bytes.as<uint32_t>(),
-                                       p->crc.as<uint32_t>(), p->cs));
+        for (uint32_t at = 0; at < n_subs; at += slice)
+            PCHK(p, qd_launch_lz_subblocks(o.text.p, p->subs.as<qd_lz_sub>() + at, std::min(slice, n_subs - at), p->tokens.as<uint32_t>(), p->sub_out.p + (size_t)at * sub_stride,
+                                           sub_stride, p->sub_bytes.as<uint32_t>() + at, p->crc.as<uint32_t>() + at, p->cs));
         PCHK(p, qd_text_crc32_combine(p->ranges.as<qd_crc_range>(), p->crc.as<uint32_t>(), p->first_sub.as<uint32_t>(), n_pieces, piece_crc, 4, p->cs));
         PCHK(p, qd_launch_lz_members(o.pieces.as<qd_deflate_piece>(), n_pieces, p->subs.as<qd_lz_sub>(), p->first_sub.as<uint32_t>(), n_subs, p->sub_out.p, sub_stride,
                                      p->sub_bytes.as<uint32_t>(), o.members.p, out_stride, o.member_len.as<uint32_t>(), p->cs));

@@ -204,6 +204,27 @@ __global__ void recs_done(const uint32_t* rec_tile, uint32_t n_tiles_max, const 
     r->tail_start = n_rec ? lines[4 * n_rec - 1] + 1 : 0u;
 }
 
+// qd_name_of() for a lane: the token's end is looked for eight bytes per load (the byte loop is one dependent trip to memory per
+// character: ~30 per name, most of this kernel's time).  Reads up to 7 bytes behind the line: inside the window's padding.
+__device__ __forceinline__ void name_of_wide(const uint8_t* text, uint32_t head, uint32_t line_end, uint32_t* name_off, uint32_t* name_len) {
+    uint32_t h = head + (line_end > head ? 1u : 0u);
+    while (h < line_end && qd_is_blank(text[h])) ++h;
+    uint32_t e = h;
+    while (e < line_end) {
+        uint64_t v;
+        __builtin_memcpy(&v, text + e, 8);  // (one unaligned 8-byte load)
+        uint32_t k = 8;
+#pragma unroll
+        for (int i = 7; i >= 0; --i)
+            if (qd_is_blank((uint8_t)(v >> (8 * i)))) k = (uint32_t)i;
+        e += k;
+        if (k < 8) break;
+    }
+    if (e > line_end) e = line_end;
+    *name_off = h;
+    *name_len = e - h;
+}
+
 __global__ __launch_bounds__(256) void rec_write(const uint8_t* text, const uint32_t* lines, const qd_scan_result* res, int want_names,
                                                  const uint32_t* rec_tile, qd_rec* recs) {
     __shared__ uint32_t lds[4];
@@ -234,7 +255,7 @@ __global__ __launch_bounds__(256) void rec_write(const uint8_t* text, const uint
         q.qual = l[i].e2 + 1;
         q.name_off = q.head;
         q.name_len = 0;
-        if (want_names) qd_name_of(text, l[i].head, l[i].e0, &q.name_off, &q.name_len);
+        if (want_names) name_of_wide(text, l[i].head, l[i].e0, &q.name_off, &q.name_len);
         recs[at++] = q;
     }
 }
@@ -530,8 +551,16 @@ __global__ __launch_bounds__(256) void dest_bounds(const uint16_t* sdest, const 
 
 // ---- format ---------------------------------------------------------------------------------------------------------------
 // 16 lanes per output record: '@' name ':' IDX [':' MOL] '\n' seq "\n+\n" qual '\n' (src/FastqWriter.py:61-69)
+// (eight bytes per lane and step where the piece is long enough -- unaligned 8-byte loads and stores are the hardware's business --
+//  and the rest byte by byte: a read's 150 bases are two steps and six bytes instead of ten steps)
 __device__ __forceinline__ void put(uint8_t* out, const uint8_t* src, uint32_t len, uint32_t sub) {
-    for (uint32_t i = sub; i < len; i += 16) out[i] = src[i];
+    const uint32_t whole = len & ~7u;
+    for (uint32_t i = sub * 8u; i < whole; i += 128) {
+        uint64_t v;
+        __builtin_memcpy(&v, src + i, 8);
+        __builtin_memcpy(out + i, &v, 8);
+    }
+    for (uint32_t i = whole + sub; i < len; i += 16) out[i] = src[i];
 }
 
 __global__ __launch_bounds__(256) void format_records(PlanParams p, qd_format_args a, uint32_t n) {

@@ -70,6 +70,24 @@ def test_device_inflate_equals_zlib(level, strategy):
         assert inf.run(b"", 0) == b""
 
 
+def test_payload_sizes_around_the_forms_lds_limits():
+    """The inflater picks 1 024 lanes, 512 lanes or the one-wave form by the LDS the launch's longest payload leaves (payload + 64 KiB of
+    text + parents + tables in a CU's 160 KB, the kernel's static LDS included: a launch 60 bytes under the limit by its dynamic size alone
+    was once refused).  Payloads in steps of a few bytes across both limits (~35.9 KB and ~46.2 KB): every size inflates."""
+    from quade_amd.hip_backend import Inflater
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(bytes(range(48, 112)), np.uint8)  # 64 symbols, Huffman only: 0.7525 of the text
+    seen = set()
+    with Inflater(0) as inf:
+        for lo, hi in ((47300, 48050), (60950, 61750)):
+            for L in range(lo, hi, 5):
+                text = bytes(rng.choice(alpha, L))
+                blk = _bgzf_block(text, 6, zlib.Z_HUFFMAN_ONLY)
+                seen.add((len(blk) - 26) // 4)
+                assert inf.run(blk, L) == text, (L, len(blk) - 26)
+    assert len(seen) > 200  # (distinct payload sizes in words)
+
+
 def test_device_inflate_of_library_written_bgzf_and_damage(tmp_path):
     """Files as synth / qd_write_gzip_file write them (libdeflate raw deflate per block, EOF block at the end);
     a flipped payload byte, a wrong CRC and a wrong ISIZE are refused with the block's index."""
