@@ -658,43 +658,39 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
                 if (eff < 4) eff = 0;
             }
             const uint32_t lit = (tw[p >> 2] >> (8 * (p & 3u))) & 0xFFu;
-            const uint64_t cm = __ballot(eff != 0);
-            uint32_t tlen = 0, tdist = 0;
+            // What the walk decides at a position does not depend on how it got there: a lane knows by itself whether a match is
+            // taken at its position if the walk lands on it (a candidate that its successor's longer one does not defer by one
+            // literal: lazy evaluation on the 32-byte views).  The walk -- a scalar loop, the part of the parse that cannot be
+            // spread over the lanes -- then only hops: one lane read per match, one bit scan per run of literals.
+            const uint32_t eff_next = (uint32_t)__shfl_down((int)eff, 1, 64);
+            const bool deferred = eff != 0 && (int)lane + 1 < limit && eff_next > eff && eff < (uint32_t)LZ_NICE;  // (eff_next > eff >= 4: a candidate)
+            const uint64_t mm = __ballot(eff != 0 && !deferred);               // a match starts here if the walk comes by
+            const uint64_t xm = __ballot(eff >= (uint32_t)LZ_NICE && !deferred);  // ... one whose 32-byte view all lanes extend
+            uint32_t tlen = eff;
+            const uint32_t tdist = dist;
             uint64_t starts = 0;
             int s = carry;
             while (s < limit) {
-                bool matched = false;
-                if ((cm >> s) & 1ull) {
-                    const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)eff, s);
-                    bool defer = false;
-                    if (s + 1 < limit && ((cm >> (s + 1)) & 1ull) && e0 < (uint32_t)LZ_NICE)
-                        defer = (uint32_t)__builtin_amdgcn_readlane((int)eff, s + 1) > e0;  // a literal now, the longer match next
-                    if (!defer) {
+                if ((mm >> s) & 1ull) {
+                    uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)eff, s);
+                    if ((xm >> s) & 1ull) {  // the lane's view ended at 32 bytes: all lanes extend it, 4 bytes each
                         const uint32_t D = (uint32_t)__builtin_amdgcn_readlane((int)dist, s);
-                        uint32_t len = e0;
-                        if (e0 >= (uint32_t)LZ_NICE) {  // the lane's view ended at 32 bytes: all lanes extend it, 4 bytes each
-                            const uint32_t ps = base + (uint32_t)s;
-                            const uint32_t x = rd32(tw, ps + 4 * lane) ^ rd32(tw, ps - D + 4 * lane);
-                            const uint64_t nz = __ballot(x != 0);
-                            len = LZ_MAXLEN;
-                            if (nz) {
-                                const int fl = __builtin_ctzll(nz);
-                                const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, fl);
-                                len = 4u * (uint32_t)fl + ((uint32_t)__builtin_ctz(xf) >> 3);
-                            }
-                            len = min(len, rend - ps);
+                        const uint32_t ps = base + (uint32_t)s;
+                        const uint32_t x = rd32(tw, ps + 4 * lane) ^ rd32(tw, ps - D + 4 * lane);
+                        const uint64_t nz = __ballot(x != 0);
+                        len = LZ_MAXLEN;
+                        if (nz) {
+                            const int fl = __builtin_ctzll(nz);
+                            const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, fl);
+                            len = 4u * (uint32_t)fl + ((uint32_t)__builtin_ctz(xf) >> 3);
                         }
-                        if ((int)lane == s) {
-                            tlen = len;
-                            tdist = D;
-                        }
-                        starts |= 1ull << s;
-                        s += (int)len;
-                        matched = true;
+                        len = min(len, rend - ps);
+                        if ((int)lane == s) tlen = len;
                     }
-                }
-                if (!matched) {  // literals up to the next candidate
-                    const uint64_t rest = s + 1 < 64 ? (cm >> (s + 1)) << (s + 1) : 0ull;
+                    starts |= 1ull << s;
+                    s += (int)len;
+                } else {  // literals up to the next match that is taken
+                    const uint64_t rest = (mm >> s) << s;
                     int nxt = rest ? __builtin_ctzll(rest) : 64;
                     if (nxt > limit) nxt = limit;
                     const uint64_t upto = nxt >= 64 ? ~0ull : ((1ull << nxt) - 1);
@@ -702,6 +698,7 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
                     s = nxt;
                 }
             }
+            if (!((mm >> lane) & 1ull)) tlen = 0;  // (a literal)
             carry = s - 64;
             if ((starts >> lane) & 1ull) {
                 uint32_t t;
