@@ -33,6 +33,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -1139,7 +1140,12 @@ int reserve_buffers(qd_pipe* p, uint32_t B, uint32_t n_dest) {
     for (int s = 0; s < 2; ++s) out_text += (double)B * (p->win[s].avg > 0 ? p->win[s].avg : 400.0) * 1.06;
     if (join_reserve(p) != QD_OK) return QD_ERR_HIP;
     p->reserve_rc = QD_OK;
-    p->reserve_thread = std::thread([p, n_dest, out_text] { p->reserve_rc = reserve_output(p, n_dest, out_text); });
+    try {
+        p->reserve_thread = std::thread([p, n_dest, out_text] { p->reserve_rc = reserve_output(p, n_dest, out_text); });
+    } catch (const std::system_error&) {  // (no thread to be had: on this one)
+        p->reserve_rc = reserve_output(p, n_dest, out_text);
+        if (p->reserve_rc != QD_OK) return pfail(p, QD_ERR_HIP, "device allocation of the output buffers failed");
+    }
     for (int s = 0; s < p->n_streams; ++s) {
         Window& w = p->win[s];
         const double avg = w.avg > 0 ? w.avg : (s < 2 ? 400.0 : 64.0);
