@@ -549,17 +549,19 @@ __global__ __launch_bounds__(LZ_BLOCK) void lz_subblocks(const uint8_t* text, co
         reinterpret_cast<uint4*>(tw)[i] = v;
         if (b < L) {
             const uint32_t q[4] = {v.x, v.y, v.z, v.w}, nby = min(16u, L - b);
-            uint32_t* rep = table + ((tid & 7u) << 8);
+            // (the replicas of one byte value side by side: eight banks -- replica-major, 256 words apart, they all lay in ONE bank, and a
+            //  text's commonest byte is a third of it)
+            uint32_t* rep = table + (tid & 7u);
 #pragma unroll
             for (uint32_t k = 0; k < 16; ++k)
-                if (k < nby) atomicAdd(&rep[(q[k >> 2] >> (8 * (k & 3))) & 0xFFu], 1u);
+                if (k < nby) atomicAdd(&rep[((q[k >> 2] >> (8 * (k & 3))) & 0xFFu) << 3], 1u);
         }
     }
     __syncthreads();
     if (tid < 256) {  // bits of a literal of this byte under an ideal code, 1 .. 12 (a byte the text does not hold: 12)
         uint32_t h = 0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) h += table[(r << 8) + tid];
+        for (int r = 0; r < 8; ++r) h += table[(tid << 3) + r];
         const int c = h ? (int)(__log2f((float)L / (float)h) + 0.5f) : 12;
         bcost[tid] = (uint8_t)(c < 1 ? 1 : (c > 12 ? 12 : c));
     }
