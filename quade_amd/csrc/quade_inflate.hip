@@ -553,25 +553,36 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
                 if (tid == 0) L.lengths[CLORDER[k]] = (uint8_t)v;
             }
             __syncthreads();
-            // (the code-length code's 7-bit table goes where the distance table will be; the literal table's space holds a table of
-            //  PAIRS meanwhile: 10 bits of the stream -> two plain lengths at once where two codes fit -- the walk over the ~300
-            //  code lengths is one dependent look-up after the other, by every wave alike, and was a sixth of a block's time)
+            // (the code-length code's 7-bit table goes where the distance table will be; the span decode's literal table holds a table
+            //  of GROUPS meanwhile: 10 bits of the stream -> up to four plain lengths at once, as many codes as fit -- the walk over the
+            //  ~300 code lengths is one dependent look-up after the other, by every wave alike, and was a sixth of a block's time)
             static_assert(DBITS >= 7 && LBITS >= 10, "the header's two tables borrow the code tables' space");
             if (b.cnt < 0 || build(L.lengths, 19, L.lcount, L.lsym, L.dlut, 7, 9, tid) != 0) {
                 err = b.cnt < 0 ? QD_INFLATE_TRUNCATED : QD_INFLATE_BAD_TABLE;
                 break;
             }
-            // entry: first symbol (5 bits) | its code's bits (3: 1..7, 0 = no code) | second symbol (4) | both codes' bits (4: 0 = no pair)
+            // entry: first symbol (5 bits) | its code's bits (3: 1..7, 0 = no code) | second, third, fourth symbol (4 bits each) | how many
+            // plain lengths (3 bits) | their codes' bits together (4)
             for (uint32_t i = tid; i < 1024u; i += NT) {
                 const uint32_t e1 = L.dlut[i & 127u];
                 uint32_t e = 0;
                 if (e1 >> 9) {
                     const uint32_t s1 = e1 & 511u, n1 = e1 >> 9;
                     e = s1 | (n1 << 5);
-                    const uint32_t e2 = L.dlut[(i >> n1) & 127u];
-                    if (s1 < 16 && (e2 >> 9) && (e2 & 511u) < 16 && n1 + (e2 >> 9) <= 10) e |= ((e2 & 511u) << 8) | ((n1 + (e2 >> 9)) << 12);
+                    if (s1 < 16) {
+                        uint32_t cnt = 1, used = n1;
+#pragma unroll
+                        for (int j = 1; j < 4; ++j) {
+                            const uint32_t ej = L.dlut[(i >> used) & 127u];
+                            if (cnt != (uint32_t)j || !(ej >> 9) || (ej & 511u) >= 16 || used + (ej >> 9) > 10) continue;
+                            e |= (ej & 511u) << (4 + 4 * j);
+                            used += ej >> 9;
+                            cnt = (uint32_t)j + 1;
+                        }
+                        e |= (cnt << 20) | (used << 23);
+                    }
                 }
-                L.llut[i] = (uint16_t)e;
+                S.ll[i] = e;
             }
             __syncthreads();
             int idx = 0, prev = 0;
@@ -579,22 +590,22 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
             while (idx < nlen + ndist && !err) {
                 refill(b);
                 int sym;
-                const uint32_t e = uni(L.llut[(uint32_t)b.buf & 1023u]);
-                if ((e >> 12) && idx + 2 <= nlen + ndist) {  // two plain lengths
-                    const int s1 = (int)(e & 31u), s2 = (int)((e >> 8) & 15u);
-                    const uint32_t used = e >> 12;
+                const uint32_t e = uni(S.ll[(uint32_t)b.buf & 1023u]);
+                const int cnt = (int)((e >> 20) & 7u);
+                if (cnt >= 2 && idx + cnt <= nlen + ndist) {  // several plain lengths
+                    const uint32_t used = (e >> 23) & 15u;
                     b.buf >>= used;
                     b.cnt -= (int)used;
                     if (b.cnt < 0) {
                         err = QD_INFLATE_TRUNCATED;
                         break;
                     }
-                    if (tid < 2) {
+                    if ((int)tid < cnt) {
                         const int at = idx + (int)tid;
-                        L.lengths[at < nlen ? at : 288 + (at - nlen)] = (uint8_t)(tid ? s2 : s1);
+                        L.lengths[at < nlen ? at : 288 + (at - nlen)] = (uint8_t)(tid ? (e >> (4 + 4 * tid)) & 15u : e & 31u);
                     }
-                    idx += 2;
-                    prev = s2;
+                    idx += cnt;
+                    prev = (int)((e >> (4 + 4 * (cnt - 1))) & 15u);
                     continue;
                 }
                 if ((e >> 5) & 7u) {
