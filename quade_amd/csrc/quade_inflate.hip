@@ -320,6 +320,80 @@ __device__ __forceinline__ uint32_t dist_entry(uint32_t ds, uint32_t nbits) {
     return nbits | (de << 4) | (base << 8);
 }
 
+// build() for the literal/length and the distance code of a deflate block at once, straight into the span decode's widened tables:
+// the two codes share the four barriers, their one-lane parts (Kraft check, first codes, offsets per length) run on two
+// waves side by side, and the 16-bit tables + their conversion fall away.  verdict[k]: 0 complete, > 0 incomplete, < 0
+// over-subscribed (k = 0 literal/length, 1 distance); L.lcount / lsym / dcount / dsym as build() leaves them (the slow path's).
+template <int NT>
+__device__ void build2(Lds& L, int nlen, int ndist, uint32_t* ll, uint32_t* dl, int (&verdict_out)[2]) {
+    static_assert(NT >= 352, "literal lanes [0, 288), distance lanes [320, 352)");
+    __shared__ uint32_t cnt32[2][16];
+    __shared__ uint16_t offs[2][16], next[2][16];
+    __shared__ int verdict[2], usable[2];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < (1u << LBITS); i += NT) ll[i] = 0;
+    for (uint32_t i = tid; i < (1u << DBITS); i += NT) dl[i] = 0;
+    if (tid < 32) cnt32[tid >> 4][tid & 15u] = 0;
+    __syncthreads();
+    const bool is_lit = tid < (uint32_t)nlen, is_dist = tid >= 320 && tid < 320u + (uint32_t)ndist;
+    const uint8_t* length = L.lengths + (is_dist ? 288 : 0);
+    const uint32_t sym = is_dist ? tid - 320u : tid, which = is_dist ? 1u : 0u;
+    const uint32_t l = (is_lit || is_dist) ? (uint32_t)(length[sym] & 15) : 0u;
+    if (is_lit || is_dist) atomicAdd(&cnt32[which][l], 1u);
+    __syncthreads();
+    if (tid == 0 || tid == 64) {  // (two waves)
+        const uint32_t k = tid ? 1u : 0u;
+        const int n = k ? ndist : nlen;
+        uint16_t* count = k ? L.dcount : L.lcount;
+        int left = 1;
+        for (int q = 0; q <= 15; ++q) count[q] = (uint16_t)cnt32[k][q];
+        for (int q = 1; q <= 15; ++q) {
+            left <<= 1;
+            left -= count[q];
+            if (left < 0) break;
+        }
+        usable[k] = left >= 0 && count[0] != n;
+        if (usable[k]) {
+            offs[k][1] = 0;
+            int code = 0;
+            next[k][0] = 0;
+            for (int q = 1; q <= 15; ++q) {
+                code = (code + (q > 1 ? count[q - 1] : 0)) << 1;
+                next[k][q] = (uint16_t)code;
+                if (q < 15) offs[k][q + 1] = offs[k][q] + count[q];
+            }
+        }
+        count[0] = (uint16_t)(count[0] == n ? 0xFFFF : count[0]);  // no codes at all: marked
+        verdict[k] = left;
+    }
+    __syncthreads();
+    if ((is_lit || is_dist) && l && usable[which]) {
+        uint32_t rank = 0;
+        {
+            const uint32_t* lw = reinterpret_cast<const uint32_t*>(length);
+            const uint32_t pat = l * 0x01010101u, whole = sym >> 2;
+            auto equal_bytes = [&](uint32_t w) {
+                const uint32_t x = w ^ pat;
+                return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+            };
+            for (uint32_t q = 0; q < whole; ++q) rank += (uint32_t)__popc(equal_bytes(lw[q]));
+            if (sym & 3u) rank += (uint32_t)__popc(equal_bytes(lw[whole]) & ((1u << (8u * (sym & 3u))) - 1u));
+        }
+        (which ? L.dsym : L.lsym)[offs[which][l] + rank] = (uint16_t)sym;
+        const uint32_t c = next[which][l] + rank;
+        const uint32_t bits = which ? (uint32_t)DBITS : (uint32_t)LBITS;
+        if (l <= bits) {
+            const uint32_t rev = __brev(c) >> (32 - l);
+            const uint32_t e = which ? dist_entry(sym, l) : lit_entry(sym, l);
+            uint32_t* tab = which ? dl : ll;
+            for (uint32_t k = rev; k < (1u << bits); k += 1u << l) tab[k] = e;
+        }
+    }
+    __syncthreads();
+    verdict_out[0] = verdict[0];
+    verdict_out[1] = verdict[1];
+}
+
 // Tokens from bit `pos` on while they start before `limit`.  WRITE: literals -> ob[o...], matches -> list[m...], and win_first[w]
 // = the lowest list index of a match whose first byte lies in window w of the text (the match stage's windows).  ll / dl: the
 // widened tables above; L: the canonical tables behind them, for codes longer than the first-level look-up.
@@ -557,7 +631,31 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
             //  of GROUPS meanwhile: 10 bits of the stream -> up to four plain lengths at once, as many codes as fit -- the walk over the
             //  ~300 code lengths is one dependent look-up after the other, by every wave alike, and was a sixth of a block's time)
             static_assert(DBITS >= 7 && LBITS >= 10, "the header's two tables borrow the code tables' space");
-            if (b.cnt < 0 || build(L.lengths, 19, L.lcount, L.lsym, L.dlut, 7, 9, tid) != 0) {
+            // (the code-length code: 19 symbols of at most 7 bits -- one wave builds its table from ballots, no barrier inside; build()'s four
+            //  barriers and one lane's pass over the lengths were a fifth of the tables' time.  The code must be complete: Kraft sum 128.)
+            if (tid < 64) {
+                const uint32_t l = tid < 19 ? (uint32_t)L.lengths[tid] : 0u;
+                uint32_t start = 0, mine = 0, kraft = 0, rank = 0;
+#pragma unroll
+                for (uint32_t len = 1; len <= 7; ++len) {
+                    const uint64_t m = __ballot(l == len);
+                    const uint32_t c = (uint32_t)__popcll(m);
+                    if (l == len) {
+                        mine = start;
+                        rank = (uint32_t)__popcll(m & ((1ull << tid) - 1ull));
+                    }
+                    kraft += c << (7u - len);
+                    start = (start + c) << 1;
+                }
+                if (kraft == 128u && l) {
+                    const uint32_t rev = __brev(mine + rank) >> (32u - l);
+                    const uint16_t e = (uint16_t)(tid | (l << 9));
+                    for (uint32_t k = rev; k < 128u; k += 1u << l) L.dlut[k] = e;
+                }
+                if (tid == 0) S.ctl[0] = kraft;
+            }
+            __syncthreads();
+            if (b.cnt < 0 || S.ctl[0] != 128u) {
                 err = b.cnt < 0 ? QD_INFLATE_TRUNCATED : QD_INFLATE_BAD_TABLE;
                 break;
             }
@@ -653,29 +751,14 @@ __global__ __launch_bounds__(NT) void inflate_bgzf_blocks2(const uint8_t* comp, 
             }
         }
         stamp(8, since);  // block header, code lengths
-        int r = build(L.lengths, nlen, L.lcount, L.lsym, L.llut, LBITS, 9, tid);
+        int r2[2];
+        build2<NT>(L, nlen, ndist, S.ll, S.dl, r2);
         const int lit_codes = L.lcount[0] == 0xFFFF ? 0 : nlen - (int)L.lcount[0];
-        if (type == 2 && (r < 0 || (r > 0 && lit_codes != 1))) {
-            err = QD_INFLATE_BAD_TABLE;
-            break;
-        }
-        r = build(L.lengths + 288, ndist, L.dcount, L.dsym, L.dlut, DBITS, 5, tid);
         const int dist_codes = L.dcount[0] == 0xFFFF ? 0 : ndist - (int)L.dcount[0];
-        if (type == 2 && (r < 0 || (r > 0 && dist_codes > 1))) {
+        if (type == 2 && (r2[0] < 0 || (r2[0] > 0 && lit_codes != 1) || r2[1] < 0 || (r2[1] > 0 && dist_codes > 1))) {
             err = QD_INFLATE_BAD_TABLE;
             break;
         }
-#pragma unroll 1
-        for (uint32_t i = tid; i < (1u << LBITS); i += NT) {
-            const uint32_t e = L.llut[i];
-            S.ll[i] = (e >> 9) ? lit_entry(e & 511u, e >> 9) : 0u;
-        }
-#pragma unroll 1
-        for (uint32_t i = tid; i < (1u << DBITS); i += NT) {
-            const uint32_t e = L.dlut[i];
-            S.dl[i] = (e >> 5) ? dist_entry(e & 31u, e >> 5) : 0u;
-        }
-        __syncthreads();
         stamp(2, since);  // the two tables
         // ---- the block's symbols: 256 spans, guessed starts, rounds until the chain from lane 0 is confirmed up to the end-of-block symbol
         const uint32_t bitpos = 8u * (b.pos - b.ahead_bytes) - (uint32_t)b.cnt;  // (cnt >= 0: checked above)
@@ -1105,7 +1188,7 @@ static size_t inflate2_lds(uint32_t max_in_len) {
 }
 // The kernel's statically declared LDS (build()'s counters) comes on top of the dynamic part: a launch 60 bytes under the CU's
 // 160 KB by its dynamic size alone was refused by the runtime.
-constexpr size_t STATIC_LDS = 256;
+constexpr size_t STATIC_LDS = 512;
 // (what the narrowest instantiation needs: a launch that fits no form is the one-wave kernel's)
 size_t qd_inflate2_lds(uint32_t max_in_len) { return inflate2_lds<512>(max_in_len) + STATIC_LDS; }
 
