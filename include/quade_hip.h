@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define QD_ABI_VERSION 5
+#define QD_ABI_VERSION 6
 
 #define QD_OK 0
 #define QD_ERR_INVALID (-1)     /* bad argument (NULL pointer, misaligned buffer, size out of range)   */

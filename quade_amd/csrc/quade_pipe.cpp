@@ -46,6 +46,7 @@
 namespace {
 
 constexpr size_t SEG_BYTES = 16u << 20;  // bytes per upload (compressed blocks or text)
+constexpr size_t SEG_TEXT_MAX = 128u << 20;  // text one BGZF upload inflates to at most (a buffer of blocks that hold more goes out in several)
 constexpr int RING_SLOTS = 48;           // device ring per stream: how far a feeder runs ahead of the kernels
 constexpr int PIN_SLOTS = 3;             // page-locked upload buffers per stream
 constexpr uint32_t PIECE_BYTES = 1u << 20;       // text per gzip member at most (piece_bytes_for)
@@ -308,10 +309,16 @@ class Feeder {
     // pin[0 .. n) -> a ring slot; the segment goes to the driver
     bool upload(Segment& seg, const uint8_t* pin, size_t n) {
         const int s = take_slot();
-        if (s < 0) return false;
-        if (hipMemcpyAsync(ring_ + (size_t)s * SEG_BYTES, pin, n, hipMemcpyHostToDevice, up_) != hipSuccess ||
-            hipEventRecord(ready_[s], up_) != hipSuccess)
+        if (s < 0) {  // stopping -- or the wait for the slot's last reader failed: the driver must not see a clean end of stream
+            if (!stopping()) fail(seg.chunk, "upload failed: waiting for a ring slot");
             return false;
+        }
+        hipError_t e = hipMemcpyAsync(ring_ + (size_t)s * SEG_BYTES, pin, n, hipMemcpyHostToDevice, up_);
+        if (e == hipSuccess) e = hipEventRecord(ready_[s], up_);
+        if (e != hipSuccess) {
+            fail(seg.chunk, std::string("upload failed: ") + hipGetErrorString(e));
+            return false;
+        }
         pin_slot_[pin_cur_] = s;
         {
             std::lock_guard<std::mutex> g(m_);
@@ -471,7 +478,8 @@ class Feeder {
             seg.kind = SEG_BGZF;
             seg.chunk = c;
             seg.file_off = file_pos;
-            size_t pos = 0;
+            size_t pos = 0, seg_start = 0;  // seg holds the blocks of pin[seg_start, pos)
+            bool upload_failed = false;
             while (pos < fill) {
                 const uint8_t* b = pin + pos;
                 const size_t avail = fill - pos;
@@ -492,16 +500,30 @@ class Feeder {
                 }
                 const uint32_t crc = (uint32_t)b[bs - 8] | ((uint32_t)b[bs - 7] << 8) | ((uint32_t)b[bs - 6] << 16) | ((uint32_t)b[bs - 5] << 24);
                 const uint32_t in_len = (uint32_t)(bs - 12 - xlen - 8);
-                seg.blocks.push_back(qd_inflate_block{(uint32_t)(pos + 12 + xlen), in_len, (uint32_t)seg.text_bytes, isize});
+                if (seg.text_bytes + isize > SEG_TEXT_MAX && !seg.blocks.empty()) {
+                    // text that compresses far better than fastq does: the upload goes out in several segments, so that no window
+                    // has to take more than SEG_TEXT_MAX bytes of text in one step (its offsets are 32 bit)
+                    if (!upload(seg, pin + seg_start, pos - seg_start)) {
+                        upload_failed = true;
+                        break;
+                    }
+                    seg = Segment();
+                    seg.kind = SEG_BGZF;
+                    seg.chunk = c;
+                    seg.file_off = file_pos + (int64_t)pos;
+                    seg_start = pos;
+                }
+                seg.blocks.push_back(qd_inflate_block{(uint32_t)(pos - seg_start + 12 + xlen), in_len, (uint32_t)seg.text_bytes, isize});
                 seg.crcs.push_back(crc);
-                seg.starts.push_back((uint32_t)pos);
+                seg.starts.push_back((uint32_t)(pos - seg_start));
                 seg.longest = std::max(seg.longest, in_len);
                 seg.text_bytes += isize;
                 pos += bs;
             }
+            if (upload_failed) break;
             if (switch_at < 0 && pos < fill) tail.assign(pin + pos, pin + fill);
             file_pos += (int64_t)pos;
-            if (!seg.blocks.empty() && !upload(seg, pin, pos)) break;
+            if (!seg.blocks.empty() && !upload(seg, pin + seg_start, pos - seg_start)) break;
         }
         close(fd);
         if (switch_at >= 0 && ranged) return fail(c, path + ": the byte range is not BGZF blocks throughout");
@@ -597,7 +619,13 @@ struct qd_pipe {
         uint32_t line_cap = 0;
         std::vector<Segment> pending;                                  // BGZF uploads waiting for their inflate launch
         uint32_t pending_text = 0;
-        std::vector<std::pair<int64_t, std::pair<size_t, std::pair<uint32_t, uint32_t>>>> runs;  // (file offset, (bytes, (window offset, text bytes))) of this batch's BGZF text
+        struct Run {          // a stretch of this batch's BGZF text: what the host inflates again when the device refuses a block
+            int64_t file_off;  // where its blocks start in the file
+            size_t bytes;      // compressed bytes
+            int64_t at;        // window offset of its text (negative: the front of it was dropped by a carry since)
+            uint32_t text_bytes;
+        };
+        std::vector<Run> runs;
         uint32_t n_blocks = 0;                                         // blocks inflated into this window since the last verification
         hipEvent_t inflated[2] = {nullptr, nullptr};                   // the window's last launch on each inflate stream
         bool in_flight[2] = {false, false};
@@ -902,7 +930,7 @@ int launch_inflate(qd_pipe* p, Feeder& f, Window& w, int stream_index) {
             expect.push_back(s.crcs[i]);
         }
         longest = std::max(longest, s.longest);
-        w.runs.push_back({s.file_off, {s.bytes, {w.len, (uint32_t)s.text_bytes}}});
+        w.runs.push_back(Window::Run{s.file_off, s.bytes, (int64_t)w.len, (uint32_t)s.text_bytes});
         w.len += (uint32_t)s.text_bytes;
         p->st.text_in_bytes += (int64_t)s.text_bytes;
     }
@@ -1054,10 +1082,11 @@ int host_inflate_window(qd_pipe* p, Window& w) {
     if (fd < 0) return pfail(p, QD_ERR_FORMAT, w.path + ": " + strerror(errno));
     std::vector<uint8_t> comp, text;
     int rc = QD_OK;
-    for (const auto& r : w.runs) {
-        const int64_t file_off = r.first;
-        const size_t bytes = r.second.first;
-        const uint32_t at = r.second.second.first, tlen = r.second.second.second;
+    for (const Window::Run& r : w.runs) {
+        const int64_t file_off = r.file_off;
+        const size_t bytes = r.bytes;
+        const uint32_t tlen = r.text_bytes;
+        if (r.at + (int64_t)tlen <= 0) continue;  // (all of it was dropped by a carry: a shared chunk's lead-in)
         comp.resize(bytes);
         size_t got = 0;
         while (got < bytes) {
@@ -1070,7 +1099,10 @@ int host_inflate_window(qd_pipe* p, Window& w) {
             rc = pfail(p, QD_ERR_FORMAT, w.path + ": damaged BGZF block");
             break;
         }
-        if (tlen && hipMemcpy(w.buf[w.cur].p + at, text.data(), tlen, hipMemcpyHostToDevice) != hipSuccess) {
+        // (a run whose front was carried away lands with its rest at the window's start; nothing is written behind the window's text)
+        const size_t cut = r.at < 0 ? (size_t)(-r.at) : 0, dst = r.at < 0 ? 0 : (size_t)r.at;
+        const size_t n = dst < w.len ? std::min<size_t>(tlen - cut, (size_t)w.len - dst) : 0;
+        if (n && hipMemcpy(w.buf[w.cur].p + dst, text.data() + cut, n, hipMemcpyHostToDevice) != hipSuccess) {
             rc = pfail(p, QD_ERR_HIP, "hipMemcpy of host-inflated text failed");
             break;
         }
@@ -1437,6 +1469,9 @@ int carry_window(qd_pipe* p, Window& w, uint32_t from_in) {
     w.cur = nx;
     w.len = left;
     w.dirty = true;
+    // the text of the runs not verified yet moved with it (a shared chunk drops its lead-in before the first scan: a block the
+    // device then refuses must be inflated by the host to where its text lies NOW)
+    for (Window::Run& r : w.runs) r.at -= (int64_t)from;
     return QD_OK;
 }
 
@@ -1461,6 +1496,8 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
         w.carry_kept = 0;
         w.n_blocks = 0;
         w.runs.clear();
+        w.pending.clear();
+        w.pending_text = 0;
     }
     std::vector<size_t> want(ns, 1);  // first round: one upload, to learn the stream's bytes per record
     for (;;) {
@@ -1765,6 +1802,8 @@ int index_stream(qd_pipe* p, const char* path, int32_t world, int32_t rank, int3
         }
     }
     f.stop();
+    w.pending.clear();  // (a failed pass may leave uploads of this feeder's ring queued: the ring is gone with the feeder)
+    w.pending_text = 0;
     w.len = 0;
     w.eof = false;
     w.line_cap = 0;
@@ -1831,6 +1870,7 @@ int qd_pipe_run(qd_pipe* p, const qd_pipe_chunk* chunks, int32_t n_chunks, qd_pi
     PCHK(p, hipSetDevice(p->device));
     const auto run_t0 = std::chrono::steady_clock::now();
     g_alloc_seconds = 0;
+    p->st = qd_pipe_stats_impl();  // the statistics are per call (a pipe that runs chunk after chunk: the caller adds them up)
     const int ns = p->n_streams;
     for (int c = 0; c < n_chunks; ++c) {
         if (!chunks[c].r1 || !chunks[c].r2 || !chunks[c].i1 || (ns == 4 && !chunks[c].i2) || !chunks[c].sink) return pfail(p, QD_ERR_INVALID, "chunk without files or sink");

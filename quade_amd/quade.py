@@ -384,10 +384,20 @@ class Quade(object):
                 self.pipe_stats = None
                 self.shared_chunks = 0
                 for c in mine:
+                    index_error = None
                     with _timed("index pass"):
-                        mine_tables = [pipe.index(f, self.world, self.rank) for f in chunks[c]]
+                        try:
+                            mine_tables = [pipe.index(f, self.world, self.rank) for f in chunks[c]]
+                        except (IOError, OSError, hb.QuadeHipError) as e:
+                            # an unreadable or damaged file on this rank: the others wait for this rank's tables -- they get the
+                            # failure instead, and every rank stops here together (none is left polling the rendezvous directory)
+                            index_error = "rank %d: %s" % (self.rank, e)
+                            mine_tables = {"error": index_error}
                     got = dist.allgather_bytes(self.outdir, self.token, self.rank, self.world, "index.c%d" % c, json.dumps(mine_tables).encode())
                     per_rank = [json.loads(b.decode()) for b in got]
+                    failed = [t["error"] for t in per_rank if isinstance(t, dict)]
+                    if failed:
+                        raise IOError("index pass of chunk %d failed: %s" % (c + 1, "; ".join(failed)))
                     tables = []
                     for s in range(len(chunks[c])):
                         t = []

@@ -261,6 +261,24 @@ def test_pipeline_large_bgzf_chunks_vs_oracle(tmp_path):
     assert st["pairs"] >= 2 * n - 4 and st["bgzf_blocks"] > 300 and st["host_coded_pieces"] == 0 and st["host_inflated_runs"] == 0
 
 
+@pytest.mark.parametrize("level", [1, -1])
+def test_clean_bgzf_input_never_touches_the_host_fallbacks(tmp_path, level):
+    """The pipeline hides a refused block (the host inflates it) and a member the coder gives up (the host codes it) by design: a
+    kernel regression that refused everything would pass every parity test at host speed.  On clean BGZF input, at both levels the
+    device codes, none of the fallbacks may fire and no window may be scanned twice (VERDICT r04 weak #11)."""
+    rng = np.random.default_rng(16)
+    data = tmp_path / "data"
+    data.mkdir()
+    n = 60000
+    files, samples = _dataset(str(data), rng, 2, n, 12, fmt="bgzf", read_len=100)
+    st = _run_and_compare(tmp_path, files, samples, "[gpu]\nbatch_pairs : 25000\ngzip_level : %d\n" % level)
+    assert st["pairs"] == 2 * n and st["bgzf_blocks"] > 200 and st["pieces"] > 0
+    assert st["host_inflated_runs"] == 0, st
+    assert st["host_coded_pieces"] == 0, st
+    assert st["rescans"] == 0, st
+    assert st["text_segments"] == 0, st
+
+
 def test_pipeline_write_flags_and_level_minus_one(tmp_path):
     rng = np.random.default_rng(13)
     data = tmp_path / "data"
@@ -425,6 +443,63 @@ def test_shared_chunk_three_ranks_vs_oracle(tmp_path):
     _compare_dirs(str(my_dir), str(ref_dir))
     with open(my_dir / "Quade_report.csv") as fh:
         assert "Total pair\t%d" % sset.counts()[0] in fh.read()
+
+
+def test_shared_chunk_part_with_a_refused_block_in_its_first_window(tmp_path):
+    """A rank's part of a shared chunk starts skip_bytes into the text behind a block boundary: that lead-in is dropped before the
+    first scan.  When the device then refuses a block of that first window, the host's text must land where the window's text lies
+    AFTER the drop (the runs' offsets were the pre-skip layout).  Two parts, each with its first batch's blocks declared
+    refused, against oracle.run_quade: counters and every output file, part 0's bytes followed by part 1's."""
+    from quade_amd import dist
+    from quade_amd import hip_backend as hb
+    from quade_amd.conf import QuadeConf
+    from quade_amd.sample import Sample, WriterSet
+    from tests.test_gpu_e2e import _conf
+    rng = np.random.default_rng(43)
+    data = tmp_path / "data"
+    data.mkdir()
+    n = 9000
+    files, samples = _dataset(str(data), rng, 1, n, 6, fmt="bgzf", read_len=100, malformed={(0, "seq_R1", 10), (0, "index_R2", 6100)})
+    conf = tmp_path / "conf.txt"
+    _conf(str(conf), files, True, ((1, 8), (1, 8), (9, 14), None), 25, samples, (True, True, True), "[gpu]\nbatch_pairs : 1500\n")
+    ref_dir = tmp_path / "ref"
+    ref_dir.mkdir()
+    sset, _ = qo.run_quade(str(conf), outdir=str(ref_dir))
+    cf = QuadeConf(str(conf))
+    Sample.RESET()
+    Sample.CLASS_INIT(True, True, True, cf.minimal_qual, outdir=str(tmp_path), gzip_level=1)
+    for name, index in cf.samples:
+        Sample(name=name, index=index)
+    streams = [cf.seq_R1[0], cf.seq_R2[0], cf.index_R1[0], cf.index_R2[0]]
+    world = 2
+    outs = []
+    with hb.Engine(0) as eng:
+        eng.set_plan(cf.plan())
+        eng.set_barcodes(Sample.BARCODES())
+        with hb.Pipe(eng, 1500) as pipe:
+            tables = [sum((pipe.index(f, world, r) for r in range(world)), []) for f in streams]
+        parts = dist.plan_parts(tables, world)
+        assert all(parts) and any(v > 0 for v in parts[1]["skip_bytes"])
+        total_host_runs = 0
+        for r in range(world):
+            out = tmp_path / ("part%d" % r)
+            out.mkdir()
+            outs.append(out)
+            ws = WriterSet(str(out), 1, deflate_device=-1)
+            with hb.Pipe(eng, 1500) as pipe:
+                pipe.set_option("test_fail_inflate_batch", 0)
+                st = pipe.run([(streams[0], streams[1], streams[2], streams[3], ws.handle(), None, None, dict(parts[r]))])
+            ws.close()
+            assert st["pairs"] == parts[r]["max_pairs"]
+            total_host_runs += st["host_inflated_runs"]
+        assert total_host_runs >= 8
+        assert [int(x) for x in eng.counts()] == sset.counts()
+    for f in sorted(os.listdir(ref_dir)):
+        if not f.endswith(".fastq.gz"):
+            continue
+        mine = b"".join(gzip.open(o / f).read() for o in outs if (o / f).exists())
+        assert mine == gzip.open(ref_dir / f).read(), f
+    Sample.RESET()
 
 
 def test_pipeline_many_samples_and_empty_streams(tmp_path):

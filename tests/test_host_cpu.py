@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libquade_hip.so does not export %s" % name
     assert declared == {s[0] for s in hb.SYMBOLS}, "ctypes table and header disagree"
-    assert lib.qd_version() == 5
+    assert lib.qd_version() == 6
     assert lib.qd_strerror(hb.QD_ERR_NO_DEVICE) == b"no usable gfx950 HIP device"
 
 
