@@ -392,8 +392,9 @@ int qd_inflater_run_pinned(qd_inflater* inflater, const uint8_t* comp, int64_t c
                            int32_t* bad_block);
 void* qd_pinned_alloc(int64_t bytes); /* NULL on failure */
 void qd_pinned_free(void* p);
-/* ABI v4.  Which kernel inflates the blocks: 2 (the default) = 512 lanes per block (spans decoded from guessed starts that synchronise,
- * matches resolved by pointer jumping: quade_inflate.hip); 1 = one wave per block, one symbol after the other (r02).  Same results, same status codes.
+/* ABI v4 (form 3: v6).  Which kernel inflates the blocks: 3 (the default) = one LANE decodes a block's symbols once into tokens, 64 blocks
+ * per wave, then a workgroup per block resolves the tokens (quade_inflate3.hip); 2 = 1 024 lanes per block (spans decoded from guessed starts
+ * that synchronise, matches resolved by pointer jumping: quade_inflate.hip); 1 = one wave per block, one symbol after the other (r02).  Same results, same status codes.
  * The environment variable QUADE_INFLATE_FORM sets the form new inflaters start with. */
 int qd_inflater_set_form(qd_inflater* inflater, int32_t form);
 int qd_inflater_destroy(qd_inflater* inflater);
@@ -498,7 +499,9 @@ int qd_pipe_index(qd_pipe* pipe, const char* path, int32_t world, int32_t rank, 
 /* "batch_pairs": pairs per batch at most (default 2 000 000; windows of text are sized from it, at most 1 GiB per stream);
  * "member_slots_bytes": device memory the member slots of one batch may take (default 12 GiB): a member holds 1 MiB of one destination's
  * text, less (down to 64 KiB) when thousands of destinations would need more slots than that;
- * "inflate_streams": 1 (default) = the BGZF inflate launches go down the compute stream one after the other; 2 = they alternate between
+ * "inflate_form": 3 (default) = every DEFLATE symbol decoded once, one lane per block, the blocks of all four streams' uploads in one
+ * launch, a workgroup per block resolves the tokens (quade_inflate3.hip); 2 = speculative spans, a launch per stream and eight uploads;
+ * "inflate_streams" (form 2): 1 (default) = the BGZF inflate launches go down the compute stream one after the other; 2 = they alternate between
  * two streams of their own, so one launch's last blocks and the next one's first share the device (measured slower: DESIGN.md 4.4);
  * "test_fail_inflate_batch": tests -- the device's BGZF result of that batch is treated as refused;
  * "test_host_code_every": tests -- every k-th member is coded by the host, as one that did not fit its slot on the device would be */

@@ -17,6 +17,7 @@
 #include "quade_common.h"
 #include "quade_kernels.h"
 #include "quade_inflate.h"
+#include "quade_inflate3.h"
 #include "quade_deflate.h"
 
 typedef uint64_t u64;
@@ -1100,9 +1101,12 @@ struct qd_inflater {
     size_t cap_blk = 0, cap_st = 0;
     std::vector<uint32_t> crc;
     // which kernel: 2 (the default) = 512 lanes per block, 1 = one wave per block (QUADE_INFLATE_FORM / qd_inflater_set_form); the second form's match lists
-    int form = 2;
+    int form = 3;
     unsigned long long* d_matches = nullptr;
     size_t cap_matches = 0;  // blocks the scratch holds
+    // the third form (3: one lane decodes a block's symbols once, a workgroup resolves its tokens -- quade_inflate3.hip): its scratch
+    void* d_scratch3 = nullptr;
+    size_t cap_scratch3 = 0;  // bytes
 };
 
 namespace {
@@ -1172,7 +1176,7 @@ int qd_inflater_create(int device_id, qd_inflater** out) {
         delete f;
         return QD_ERR_HIP;
     }
-    if (const char* e = getenv("QUADE_INFLATE_FORM")) f->form = atoi(e) == 1 ? 1 : 2;
+    if (const char* e = getenv("QUADE_INFLATE_FORM")) f->form = atoi(e) == 1 ? 1 : (atoi(e) == 2 ? 2 : 3);
     *out = f;
     return QD_OK;
 }
@@ -1196,12 +1200,13 @@ int qd_inflater_destroy(qd_inflater* f) {
     if (f->h_st) (void)hipHostFree(f->h_st);
     if (f->d_st) (void)hipFree(f->d_st);
     if (f->d_matches) (void)hipFree(f->d_matches);
+    if (f->d_scratch3) (void)hipFree(f->d_scratch3);
     delete f;
     return QD_OK;
 }
 
 int qd_inflater_set_form(qd_inflater* f, int32_t form) {
-    if (!f || (form != 1 && form != 2)) return QD_ERR_INVALID;
+    if (!f || form < 1 || form > 3) return QD_ERR_INVALID;
     f->form = form;
     return QD_OK;
 }
@@ -1276,7 +1281,19 @@ static int inflater_run(qd_inflater* f, const uint8_t* comp, int64_t comp_len, u
     INFCHK(f, hipMemcpyAsync(f->d_blk, f->h_blk, blk.size() * sizeof(qd_inflate_block), hipMemcpyHostToDevice, f->stream));
     uint32_t longest = 0;
     for (const qd_inflate_block& bk : blk) longest = std::max(longest, bk.in_len);
-    if (f->form == 2 && qd_inflate2_lds(longest) <= 160 * 1024) {  // (a run with a payload beyond ~52 KB -- stored blocks -- takes the first form)
+    bool form3_ran = false;
+    if (f->form == 3) {
+        const size_t need = qd_inflate3_scratch_bytes((uint32_t)blk.size());
+        if (need > f->cap_scratch3) {
+            if (f->d_scratch3) (void)hipFree(f->d_scratch3);
+            f->d_scratch3 = nullptr;
+            f->cap_scratch3 = 0;
+            INFCHK(f, hipMalloc(&f->d_scratch3, need + need / 4));
+            f->cap_scratch3 = need + need / 4;
+        }
+        INFCHK(f, qd_launch_inflate3(f->d_comp, (size_t)comp_len, f->d_blk, (uint32_t)blk.size(), f->d_out, f->d_st, f->d_scratch3, f->stream));
+        form3_ran = true;
+    } else if (f->form == 2 && qd_inflate2_lds(longest) <= 160 * 1024) {  // (a run with a payload beyond ~52 KB -- stored blocks -- takes the first form)
         if (blk.size() > f->cap_matches) {
             if (f->d_matches) (void)hipFree(f->d_matches);
             f->d_matches = nullptr;
@@ -1313,6 +1330,48 @@ static int inflater_run(qd_inflater* f, const uint8_t* comp, int64_t comp_len, u
         INFCHK(f, qd_launch_inflate(f->d_comp, f->d_blk, (uint32_t)blk.size(), f->d_out, f->d_st, f->stream));
     }
     INFCHK(f, hipMemcpyAsync(f->h_st, f->d_st, blk.size() * 4, hipMemcpyDeviceToHost, f->stream));
+    if (form3_ran) {
+        // blocks whose Huffman codes hold more long symbols than a lane's table takes (byte soup, not fastq) go through the second
+        // form -- or the first, when their payload leaves no room for it: a second launch over just those blocks
+        INFCHK(f, hipEventRecord(f->done, f->stream));
+        INFCHK(f, wait_event_napping(f->done));
+        std::vector<qd_inflate_block> redo;
+        std::vector<size_t> redo_at;
+        uint32_t redo_longest = 0;
+        for (size_t i = 0; i < blk.size(); ++i)
+            if (f->h_st[i] == QD_INFLATE_TABLE_SPACE) {
+                redo.push_back(blk[i]);
+                redo_at.push_back(i);
+                redo_longest = std::max(redo_longest, blk[i].in_len);
+            }
+        if (!redo.empty()) {
+            qd_inflate_block* d_redo = nullptr;
+            int32_t* d_rst = nullptr;
+            INFCHK(f, hipMalloc((void**)&d_redo, redo.size() * sizeof(qd_inflate_block)));
+            INFCHK(f, hipMalloc((void**)&d_rst, redo.size() * 4));
+            INFCHK(f, hipMemcpy(d_redo, redo.data(), redo.size() * sizeof(qd_inflate_block), hipMemcpyHostToDevice));
+            hipError_t e2;
+            if (qd_inflate2_lds(redo_longest) <= 160 * 1024) {
+                if (redo.size() > f->cap_matches) {
+                    if (f->d_matches) (void)hipFree(f->d_matches);
+                    f->d_matches = nullptr;
+                    f->cap_matches = 0;
+                    INFCHK(f, hipMalloc((void**)&f->d_matches, (redo.size() + 16) * (size_t)QD_INFLATE_MATCHES_PER_BLOCK * 8));
+                    f->cap_matches = redo.size() + 16;
+                }
+                e2 = qd_launch_inflate2(f->d_comp, d_redo, (uint32_t)redo.size(), f->d_out, d_rst, f->d_matches, QD_INFLATE_MATCHES_PER_BLOCK, redo_longest, f->stream);
+            } else {
+                e2 = qd_launch_inflate(f->d_comp, d_redo, (uint32_t)redo.size(), f->d_out, d_rst, f->stream);
+            }
+            std::vector<int32_t> rst(redo.size());
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(rst.data(), d_rst, redo.size() * 4, hipMemcpyDeviceToHost, f->stream);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(f->stream);
+            (void)hipFree(d_redo);
+            (void)hipFree(d_rst);
+            INFCHK(f, e2);
+            for (size_t k = 0; k < redo.size(); ++k) f->h_st[redo_at[k]] = rst[k];
+        }
+    }
     if (out_len) INFCHK(f, hipMemcpyAsync(text, f->d_out, (size_t)out_len, hipMemcpyDeviceToHost, f->stream));
     INFCHK(f, hipEventRecord(f->done, f->stream));
     INFCHK(f, wait_event_napping(f->done));

@@ -13,6 +13,9 @@
 #define QD_INFLATE_OVERRUN 7       /* more output than the block's ISIZE                              */
 #define QD_INFLATE_LENGTH 8        /* less output than the block's ISIZE                              */
 #define QD_INFLATE_CRC 9           /* the text's CRC-32 is not the one in the block's trailer (checked on the device when asked) */
+#define QD_INFLATE_TABLE_SPACE 10  /* third form: more symbols with long codes than a lane's table holds -- another form takes the block */
+#define QD_INFLATE_TOKEN_SPACE 11  /* third form: more tokens than the unit's slot region holds                                          */
+#define QD_INFLATE_CHAIN 12        /* third form, a stretch of a gzip member: the decode passed its stop position, no block starts there   */
 
 struct qd_inflate_block {
     uint32_t in_off, in_len;    // raw deflate payload of the block inside the compressed buffer

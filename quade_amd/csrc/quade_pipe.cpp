@@ -40,6 +40,7 @@
 #include "../../include/quade_hip.h"
 #include "quade_deflate.h"
 #include "quade_inflate.h"
+#include "quade_inflate3.h"
 #include "quade_io_internal.h"
 #include "quade_text.h"
 
@@ -205,7 +206,7 @@ class Feeder {
         hipError_t e = hipSetDevice(device_);
         if (e != hipSuccess) return e;
         if ((e = hipStreamCreateWithFlags(&up_, hipStreamNonBlocking)) != hipSuccess) return e;
-        if ((e = hipMalloc((void**)&ring_, (size_t)RING_SLOTS * SEG_BYTES)) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&ring_, (size_t)RING_SLOTS * SEG_BYTES + 4096)) != hipSuccess) return e;  // (the third inflater's lanes read up to 512 bytes ahead of a payload)
         for (int i = 0; i < RING_SLOTS; ++i) {
             if ((e = hipEventCreateWithFlags(&ready_[i], hipEventDisableTiming)) != hipSuccess) return e;
             if ((e = hipEventCreateWithFlags(&consumed_[i], hipEventDisableTiming)) != hipSuccess) return e;
@@ -604,6 +605,20 @@ struct qd_pipe {
     hipEvent_t tables_up = nullptr;  // the launch's block tables are on the device (recorded on cs)
     int n_is = QD_PIPE_INFLATE_STREAMS, next_is = 0;
     DevBuf matches_b;                // the second stream's match lists
+    // Option "inflate_form" (default 3): which kernels inflate the BGZF blocks.  3 = quade_inflate3.hip: every symbol decoded once, one
+    // lane per block, the blocks of ALL streams' pending uploads in ONE launch (the token kernel's throughput is the number of
+    // blocks in flight), then a workgroup per block resolves the tokens; 2 = the speculative spans of quade_inflate.hip, a launch per
+    // window and eight uploads.
+    int inflate_form = 3;
+    struct Queued3 {  // blocks of one window waiting for the next launch
+        int stream;
+        Feeder* feeder;
+        std::vector<int> slots;
+        uint32_t first, n, block_base;
+    };
+    std::vector<qd_inflate3_job> q3_jobs;   // (out: the offset inside the window's text until the launch -- the buffer may still grow)
+    std::vector<Queued3> q3_parts;
+    DevBuf jobs3, status3, scratch3;
     StagePool stage;
     qd_pipe_stats_impl st;
 
@@ -909,11 +924,77 @@ int window_room(qd_pipe* p, Window& w, size_t extra) {
     return QD_OK;
 }
 
+constexpr uint32_t LAUNCH_BLOCKS3 = 32768;  // blocks per launch of the third inflater at most (sizes its token scratch: 131 KB a block)
+constexpr size_t FLUSH_SEGMENTS3 = RING_SLOTS / 2;  // uploads one window may queue before a launch frees their ring slots
+
+// the third inflater: everything queued goes down in one launch (more when it exceeds LAUNCH_BLOCKS3), every window's blocks are checked
+int flush_inflate3(qd_pipe* p) {
+    if (p->q3_jobs.empty()) return QD_OK;
+    const size_t n = p->q3_jobs.size();
+    for (const qd_pipe::Queued3& q : p->q3_parts) {
+        Window& w = p->win[q.stream];
+        for (uint32_t i = q.first; i < q.first + q.n; ++i) p->q3_jobs[i].out = w.buf[w.cur].p + reinterpret_cast<uintptr_t>(p->q3_jobs[i].out);
+        for (int slot : q.slots) PCHK(p, hipStreamWaitEvent(p->cs, q.feeder->ready(slot), 0));
+    }
+    PCHK(p, p->jobs3.need(n * sizeof(qd_inflate3_job), 0, p->cs));
+    PCHK(p, p->status3.need(n * 4, 0, p->cs));
+    PCHK(p, p->scratch3.need(qd_inflate3_scratch_bytes((uint32_t)std::min<size_t>(n, LAUNCH_BLOCKS3)), 0, p->cs));
+    PCHK(p, p->stage.upload(p->jobs3.p, p->q3_jobs.data(), n * sizeof(qd_inflate3_job), p->cs));
+    for (size_t at = 0; at < n; at += LAUNCH_BLOCKS3) {
+        const uint32_t m = (uint32_t)std::min<size_t>(LAUNCH_BLOCKS3, n - at);
+        PCHK(p, qd_launch_inflate3_jobs(p->jobs3.as<qd_inflate3_job>() + at, m, p->status3.as<int32_t>() + at, p->scratch3.p, p->cs));
+    }
+    for (const qd_pipe::Queued3& q : p->q3_parts) {
+        for (int slot : q.slots) PCHK(p, q.feeder->consumed(slot, p->cs));
+        const uint32_t* st = p->status3.as<uint32_t>() + q.first;  // (a block's CRC-32 is checked by its resolve kernel: the statuses say it all)
+        PCHK(p, qd_text_check_blocks(p->status3.as<int32_t>() + q.first, st, st, q.n, q.block_base, &p->d_res.as<qd_scan_result>()[q.stream].first_bad, p->cs));
+    }
+    p->q3_jobs.clear();
+    p->q3_parts.clear();
+    return QD_OK;
+}
+
 // the pending BGZF uploads of a window -> inflate launches (+ CRC-32 check of every block), text appended to the window
 int launch_inflate(qd_pipe* p, Feeder& f, Window& w, int stream_index) {
     if (w.pending.empty()) return QD_OK;
     int rc = window_room(p, w, w.pending_text);
     if (rc != QD_OK) return rc;
+    if (p->inflate_form == 3) {  // queued: flush_inflate3 launches every window's blocks together
+        qd_pipe::Queued3 q;
+        q.stream = stream_index;
+        q.feeder = &f;
+        q.first = (uint32_t)p->q3_jobs.size();
+        q.block_base = w.n_blocks;
+        for (Segment& s : w.pending) {
+            const uint8_t* base = f.ring() + (size_t)s.slot * SEG_BYTES;
+            for (size_t i = 0; i < s.blocks.size(); ++i) {
+                const qd_inflate_block& b = s.blocks[i];
+                qd_inflate3_job j;
+                j.payload = base + b.in_off;
+                j.out = reinterpret_cast<uint8_t*>((uintptr_t)w.len + b.out_off);
+                j.in_len = b.in_len;
+                j.out_len = b.out_len;
+                j.expect_crc = s.crcs[i];
+                j.check_crc = 1;
+                p->q3_jobs.push_back(j);
+            }
+            q.slots.push_back(s.slot);
+            w.runs.push_back(Window::Run{s.file_off, s.bytes, (int64_t)w.len, (uint32_t)s.text_bytes});
+            w.len += (uint32_t)s.text_bytes;
+            p->st.text_in_bytes += (int64_t)s.text_bytes;
+        }
+        q.n = (uint32_t)p->q3_jobs.size() - q.first;
+        w.n_blocks += q.n;
+        p->st.bgzf_blocks += (int64_t)q.n;
+        w.pending.clear();
+        w.pending_text = 0;
+        w.dirty = true;
+        p->q3_parts.push_back(std::move(q));
+        size_t queued = 0;
+        for (const qd_pipe::Queued3& x : p->q3_parts)
+            if (x.stream == stream_index) queued += x.slots.size();
+        return queued >= FLUSH_SEGMENTS3 ? flush_inflate3(p) : QD_OK;
+    }
     std::vector<qd_inflate_block> blk;
     std::vector<uint32_t> expect;
     uint32_t longest = 0;
@@ -1195,8 +1276,19 @@ int reserve_buffers(qd_pipe* p, uint32_t B, uint32_t n_dest) {
         PCHK(p, w.status.need(blocks * 4, 0, p->cs));
         PCHK(p, w.crc.need(blocks * 4, 0, p->cs));
     }
-    PCHK(p, p->matches.need((size_t)LAUNCH_BLOCKS * QD_INFLATE_MATCHES_PER_BLOCK * 8, 0, p->cs));
-    if (p->n_is > 1) PCHK(p, p->matches_b.need((size_t)LAUNCH_BLOCKS * QD_INFLATE_MATCHES_PER_BLOCK * 8, 0, p->cs));
+    if (p->inflate_form == 3) {  // a batch's blocks of all streams go down together: ~a block per 64 KiB of text
+        size_t blocks3 = 0;
+        for (int s = 0; s < p->n_streams; ++s) {
+            const double avg = p->win[s].avg > 0 ? p->win[s].avg : (s < 2 ? 400.0 : 64.0);
+            blocks3 += (size_t)((double)B * avg * 1.08 / 60000.0) + 64 + 3 * (SEG_BYTES * 5 / 60000);  // (+ the uploads a top-up overshoots by)
+        }
+        PCHK(p, p->jobs3.need(blocks3 * sizeof(qd_inflate3_job), 0, p->cs));
+        PCHK(p, p->status3.need(blocks3 * 4, 0, p->cs));
+        PCHK(p, p->scratch3.need(qd_inflate3_scratch_bytes((uint32_t)std::min<size_t>(blocks3, LAUNCH_BLOCKS3)), 0, p->cs));
+    } else {
+        PCHK(p, p->matches.need((size_t)LAUNCH_BLOCKS * QD_INFLATE_MATCHES_PER_BLOCK * 8, 0, p->cs));
+        if (p->n_is > 1) PCHK(p, p->matches_b.need((size_t)LAUNCH_BLOCKS * QD_INFLATE_MATCHES_PER_BLOCK * 8, 0, p->cs));
+    }
     const size_t n = B;
     for (int k = 0; k < L.n_streams; ++k) {
         PCHK(p, p->rows_seq[k].need(n * L.seq_stride[k] + 64, 0, p->cs));
@@ -1506,6 +1598,10 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
             const int rc = top_up(p, *feeders[s], p->win[s], s, chunk, want[s]);
             if (rc != QD_OK) return rc;
         }
+        {
+            const int rc = flush_inflate3(p);  // (the third inflater: the blocks of every stream's uploads in one launch)
+            if (rc != QD_OK) return rc;
+        }
         // (a shared chunk: the text in front of this rank's first record goes before anything is scanned)
         {
             bool more = false;
@@ -1748,6 +1844,11 @@ int index_stream(qd_pipe* p, const char* path, int32_t world, int32_t rank, int3
         }
     }
     if (rc == QD_OK) rc = launch_inflate(p, f, w, 0);
+    if (rc == QD_OK) rc = flush_inflate3(p);
+    if (rc != QD_OK) {  // (what was queued refers to this feeder's ring)
+        p->q3_jobs.clear();
+        p->q3_parts.clear();
+    }
     if (rc == QD_OK && (int64_t)text_at.size() != b_to - b_from) rc = pfail(p, QD_ERR_FORMAT, std::string(path) + ": block walk and reader disagree");
     const bool at_eof = b_to == nb;
     w.eof = at_eof;
@@ -1838,6 +1939,7 @@ int qd_pipe_create(qd_ctx* ctx, qd_pipe** out) {
     p->lay = L;
     p->plan = P;
     p->n_streams = 2 + L.n_streams;
+    if (const char* e = getenv("QUADE_PIPE_INFLATE_FORM")) p->inflate_form = atoi(e) == 2 ? 2 : 3;  // (measurement: A/B of the inflaters inside the pipeline)
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&p->cs, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&p->ds, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&p->is[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p->is[1], hipStreamNonBlocking) != hipSuccess ||
@@ -1860,6 +1962,7 @@ int qd_pipe_set_option(qd_pipe* p, const char* name, int64_t value) {
     else if (n == "test_host_code_every" && value >= 0) p->test_host_code_every = value;
     else if (n == "member_slots_bytes" && value >= (1 << 20)) p->member_slots_bytes = value;
     else if (n == "inflate_streams" && (value == 1 || value == 2)) p->n_is = (int)value;
+    else if (n == "inflate_form" && (value == 2 || value == 3)) p->inflate_form = (int)value;
     else return pfail(p, QD_ERR_INVALID, "unknown option " + n);
     return QD_OK;
 }
@@ -1871,6 +1974,8 @@ int qd_pipe_run(qd_pipe* p, const qd_pipe_chunk* chunks, int32_t n_chunks, qd_pi
     const auto run_t0 = std::chrono::steady_clock::now();
     g_alloc_seconds = 0;
     p->st = qd_pipe_stats_impl();  // the statistics are per call (a pipe that runs chunk after chunk: the caller adds them up)
+    p->q3_jobs.clear();  // (a run that failed half way may have left blocks queued: their ring is gone)
+    p->q3_parts.clear();
     const int ns = p->n_streams;
     for (int c = 0; c < n_chunks; ++c) {
         if (!chunks[c].r1 || !chunks[c].r2 || !chunks[c].i1 || (ns == 4 && !chunks[c].i2) || !chunks[c].sink) return pfail(p, QD_ERR_INVALID, "chunk without files or sink");
@@ -1974,6 +2079,7 @@ int qd_pipe_destroy(qd_pipe* p) {
             if (ev) (void)hipEventDestroy(ev);
         for (DevBuf* b : {&w.buf[0], &w.buf[1], &w.tile_counts, &w.tile_base, &w.lines, &w.rec_tile, &w.recs, &w.status, &w.crc, &w.blk, &w.expect}) b->release();
     }
+    for (DevBuf* b : {&p->jobs3, &p->status3, &p->scratch3}) b->release();
     for (DevBuf* b : {&p->d_res, &p->matches, &p->matches_b, &p->rows_seq[0], &p->rows_seq[1], &p->rows_qual[0], &p->rows_qual[1], &p->rows_len[0], &p->rows_len[1], &p->codes, &p->mol,
                       &p->short_idx, &p->dest, &p->len1, &p->len2, &p->hist, &p->tmp, &p->perm, &p->sdest, &p->g1, &p->g2, &p->scan_tiles, &p->first, &p->g1_first,
                       &p->g2_first, &p->subs, &p->first_sub, &p->ranges, &p->crc, &p->tokens, &p->sub_out, &p->sub_bytes, &p->base1, &p->base2})

@@ -575,6 +575,12 @@ class Inflater(object):
             raise QuadeHipError(r, self.lib.qd_inflater_last_error(None).decode())
         self._h = h
 
+    def set_form(self, form):
+        """1: one wave per block; 2: speculative spans; 3: one lane decodes a block's symbols once, a workgroup resolves the tokens."""
+        r = self.lib.qd_inflater_set_form(self._h, int(form))
+        if r != QD_OK:
+            raise QuadeHipError(r, "no such inflater form: %r" % (form,))
+
     def run(self, comp, out_len):
         """comp: bytes of whole BGZF blocks; out_len: the sum of their ISIZE fields.  Returns the text (bytes)."""
         src = np.frombuffer(comp, dtype=np.uint8)

@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["1", "2"])
+@pytest.fixture(autouse=True, params=["1", "2", "3"])
 def inflater_form(request, monkeypatch):
     """Every test runs with both kernels: 1 = one wave per block, one symbol after the other; 2 = 512 lanes per block (spans decoded
     from guessed starts that synchronise, matches resolved by pointer jumping)."""
