@@ -433,6 +433,18 @@ const char* qd_deflater_last_error(const qd_deflater* deflater);
 int qd_sink_set_device_deflate(qd_sink* sink, int32_t device_id);
 int qd_sink_device_members(qd_sink* sink, int64_t* device_members); /* of qd_sink_stats' members: made on the device */
 
+/* ---- ordinary gzip files on the device (ABI v6) ----------------------------------------------------------------------
+ * What it replaces: the gunzip inside pyFastq.FastqReader for the reference's real input format -- src/Quade.py:203-206, 234-236 open
+ * plain .fastq.gz files, and its fixtures test/dataset/[*].fastq.gz are single gzip members.  The pipeline (qd_pipe_run) feeds such
+ * files through these kernels; this entry point inflates a whole file image for tests and measurements: gz[0 .. gz_len) = one or more
+ * gzip members -> out (at most out_cap bytes), *out_len = the text's size.  Every member's CRC-32 and ISIZE are checked.  step_bytes:
+ * compressed bytes per step (what the pipeline takes per batch and stream); stretch_bytes / unit_text: 0 = the defaults (32 KiB of
+ * compressed bytes per decoding lane, 1 MiB of text per resolving workgroup).  stats (may be NULL): int64[6] = members, steps,
+ * stretches probed, units decoded, units decoded again (a false block start in front of them), steps that ended inside a block.
+ * QD_ERR_FORMAT: not gzip, damaged, or beyond what the device decodes (the pipeline then hands the file to the host's inflater). */
+int qd_dev_gunzip(int device_id, const uint8_t* gz, int64_t gz_len, uint8_t* out, int64_t out_cap, int64_t* out_len, int64_t step_bytes,
+                  int64_t stretch_bytes, int64_t unit_text, int64_t* stats);
+
 /* ---- device-resident chunk pipeline (ABI v5) ---------------------------------------------------------------------
  * Replaces, for whole chunks, the per-pair loop of Quade.double_index_parser / simple_index_parser and everything it
  * calls (src/Quade.py:195-254: four FastqReader.next(), slice + fuse, Sample.FINDER; src/FastqWriter.py:48-90: name tag,
@@ -475,6 +487,11 @@ typedef struct qd_pipe_stats {
     /* wall seconds: the whole call; the driver waiting for input from the feeders, for its read-backs from the device, for an
      * output set the collector still holds, in device allocations; the collector waiting for the device, downloading, appending */
     double run_s, wait_input_s, wait_sync_s, wait_out_set_s, alloc_s, collector_wait_s, download_s, append_s;
+    /* ABI v6: ordinary gzip files (the reference's input format) inflated on the device */
+    int64_t gzip_steps;      /* inflate steps of such streams (one per stream and top-up) */
+    int64_t gzip_units;      /* stretches decoded by a lane each, from a block start that the chain from the member's start proved */
+    int64_t gzip_members;    /* members whose CRC-32 and ISIZE were checked */
+    int64_t gzip_fallbacks;  /* streams the device gave up (damaged, or beyond what it decodes): the host's inflater took them over */
 } qd_pipe_stats;
 int qd_pipe_create(qd_ctx* ctx, qd_pipe** out); /* the context holds plan and barcodes */
 /* A chunk that several ranks share ("large single chunks are split into contiguous row ranges").  The reference pairs
@@ -499,6 +516,8 @@ int qd_pipe_index(qd_pipe* pipe, const char* path, int32_t world, int32_t rank, 
 /* "batch_pairs": pairs per batch at most (default 2 000 000; windows of text are sized from it, at most 1 GiB per stream);
  * "member_slots_bytes": device memory the member slots of one batch may take (default 12 GiB): a member holds 1 MiB of one destination's
  * text, less (down to 64 KiB) when thousands of destinations would need more slots than that;
+ * "device_gunzip": 1 (default) = ordinary gzip files (one or more members that are not BGZF blocks) are inflated on the device too
+ * (gz_probe / inflate3_tokens / gz_resolve / gz_windows / gz_fixup); 0 = by the host's parallel inflater, uploaded as text;
  * "inflate_form": 3 (default) = every DEFLATE symbol decoded once, one lane per block, the blocks of all four streams' uploads in one
  * launch, a workgroup per block resolves the tokens (quade_inflate3.hip); 2 = speculative spans, a launch per stream and eight uploads;
  * "inflate_streams" (form 2): 1 (default) = the BGZF inflate launches go down the compute stream one after the other; 2 = they alternate between

@@ -113,9 +113,8 @@ struct Lane {
     uint64_t bit_stop, bit_end;
     uint32_t* lens;  // LENS_DW dwords of scratch (global memory)
     uint32_t lim_l[C::NL], bas_l[C::NL], lim_d[C::ND], bas_d[C::ND];
-    uint64_t *op, *op0, *op_end;
-    uint64_t lo;
-    uint32_t hi, nacc;
+    uint16_t* tok;              // the launch's token buffer (wave-uniform): a lane's slots are tok[on0 .. on_end)
+    uint32_t on, on0, on_end;   // next slot, first slot, end of the region
     uint32_t text_len, pend, stored_left;
     uint32_t state, status, final_seen;
     uint64_t blk_bit;
@@ -212,24 +211,7 @@ QD3_HD void fail(Lane<C>& L, uint32_t code) {
 // ---- tokens out ------------------------------------------------------------------------------------------------------------------
 template <class C>
 QD3_HD uint32_t slots_made(const Lane<C>& L) {
-    return (uint32_t)(L.op - L.op0) * 4u + L.nacc;
-}
-// v: one slot, or two (a match: length slot | distance slot << 16); four slots leave as one 8-byte store
-template <class C>
-QD3_HD void emit(Lane<C>& L, uint32_t v, uint32_t ns) {
-    L.lo |= (uint64_t)v << (16u * L.nacc);
-    if (L.nacc + ns > 4u) L.hi = v >> 16;
-    L.nacc += ns;
-    if (L.nacc >= 4u) {
-        if (L.op < L.op_end) {
-            *L.op++ = L.lo;
-        } else {
-            fail(L, QD_INFLATE_TOKEN_SPACE);
-        }
-        L.lo = L.hi;
-        L.hi = 0;
-        L.nacc -= 4u;
-    }
+    return L.on - L.on0;
 }
 
 // ---- fifteen 16-bit fields in four registers (a lane cannot index an array by a variable without it going to scratch memory) -----
@@ -249,13 +231,14 @@ QD3_HD void pk_add(Pk& p, uint32_t l, uint32_t v) {
 }
 
 // table entries
+constexpr uint32_t E_NONE = 0x30u;  // kind 3, zero bits: a longer code, or no code
 QD3_HD uint32_t lit_entry(uint32_t sym, uint32_t nbits) {
     if (sym < 256) return nbits | (sym << 6);
     if (sym == 256) return nbits | (2u << 4);
-    return nbits | (1u << 4) | ((sym - 257u) << 6);  // (286, 287: refused when met)
+    if (sym >= 286) return E_NONE;  // (the fixed code's two unused symbols: refused when met, like a code that does not exist)
+    return nbits | (1u << 4) | ((sym - 257u) << 6);
 }
-QD3_HD uint32_t dist_entry(uint32_t sym, uint32_t nbits) { return nbits | (1u << 4) | (sym << 6); }
-constexpr uint32_t E_NONE = 0x30u;  // kind 3, zero bits: a longer code, or no code
+QD3_HD uint32_t dist_entry(uint32_t sym, uint32_t nbits) { return sym >= 30 ? E_NONE : nbits | (1u << 4) | (sym << 6); }
 
 // One Huffman code from n code lengths (nibbles in lens[]): first-level table t[2^XB], the longer codes' symbols appended to
 // lng[] from *long_used on, their limits / bases to lim[] / bas[].  0, or a QD_INFLATE_* code.
@@ -342,9 +325,11 @@ QD3_HD void header(Lane<C>& L, uint16_t* tab, uint32_t* ring, uint32_t lane) {
     uint16_t* const dst = tab + C::LIT_N;
     uint16_t* const lng = tab + C::LIT_N + C::DST_N;
     const uint64_t at = bitpos(L);
-    L.blk_bit = at;
-    L.blk_slots = slots_made(L);
-    L.blk_text = L.text_len;
+    if (at <= L.bit_end) {  // (a block that "ended" behind the input's end was decoded from bytes that are not the stream's)
+        L.blk_bit = at;
+        L.blk_slots = slots_made(L);
+        L.blk_text = L.text_len;
+    }
     if (at == L.bit_stop) {  // the next unit starts here
         L.state = ST_DONE;
         return;
@@ -466,67 +451,58 @@ QD3_HD void header(Lane<C>& L, uint16_t* tab, uint32_t* ring, uint32_t lane) {
     refill(L, ring, lane);  // (a turn starts with at least 33 bits in hand)
 }
 
-// One turn of a decoding lane: a literal/length code, a distance code, or a stored byte.  At least 33 bits are in hand when it
-// starts; it takes at most 28 and moves the stream's next dword in behind them when fewer than 33 are left.  That dword is read
-// from the ring at the start of the turn, needed or not: its trip to LDS runs beside the table look-up's.
+// One turn of a decoding lane: a literal/length code or a distance code.  At least 33 bits are in hand when it starts; it takes at
+// most 28 and moves the stream's next dword in behind them when fewer than 33 are left.  That dword is read from the ring at the
+// start of the turn, needed or not: its trip to LDS runs beside the table look-up's.
 // Straight-line code: what a lane holds decides by selects, not branches -- a wave's lanes hold everything at once, so every
 // branch of a turn written with if / else was executed on every turn (510 instructions per turn, 1 800 cycles:
-// profiles/r05_inflate3_first_form.txt).  The branches left: a code longer than the first level, four slots ready to leave.
+// profiles/r05_inflate3_first_form.txt).  The one branch left: a code longer than the first level.  Tokens leave as they are made
+// (a 2-byte store per literal, two per match, at the lane's own place: nothing is gathered in registers first).
 template <class C>
 QD3_HD void turn(Lane<C>& L, const uint16_t* tab, const uint32_t* ring, uint32_t lane) {
     const uint32_t next_word = ring[ring_at(L.rd, lane)];
     const uint32_t lo32 = (uint32_t)L.buf;
-    const bool dist = L.state == ST_DIST, stored = L.state == ST_STORED;
+    const bool dist = L.state == ST_DIST;
     uint32_t e = tab[(dist ? (uint32_t)C::LIT_N : 0u) + (lo32 & (dist ? (uint32_t)C::DST_N - 1u : (uint32_t)C::LIT_N - 1u))];
-    if ((e & 0x3Fu) == E_NONE && !stored) {  // a code longer than the first level, or none: the next 15 bits MSB first against the lengths' limits
+    if ((e & 0x3Fu) == E_NONE) {  // a code longer than the first level, or none: the next 15 bits MSB first against the lengths' limits
         const uint32_t x = brev32(lo32) >> 17;
         uint32_t at = 0xFFFFFFFFu;
+        if (dist) {
 #pragma unroll
-        for (int k = C::ND - 1; k >= 0; --k)  // (the limits rise with the length: the last one that holds is the shortest length)
-            if (k >= C::ND - C::NL) {
-                const uint32_t lim = dist ? L.lim_d[k] : L.lim_l[k - (C::ND - C::NL)], bas = dist ? L.bas_d[k] : L.bas_l[k - (C::ND - C::NL)];
-                if (x < lim) at = (bas + (x >> (14 - C::DB - k))) & 0xFFFFu;
-            } else if (dist) {
+            for (int k = C::ND - 1; k >= 0; --k)  // (the limits rise with the length: the last one that holds is the shortest length)
                 if (x < L.lim_d[k]) at = (L.bas_d[k] + (x >> (14 - C::DB - k))) & 0xFFFFu;
-            }
+        } else {
+#pragma unroll
+            for (int k = C::NL - 1; k >= 0; --k)
+                if (x < L.lim_l[k]) at = (L.bas_l[k] + (x >> (14 - C::LB - k))) & 0xFFFFu;
+        }
         e = at < (uint32_t)C::NLONG ? tab[C::LIT_N + C::DST_N + at] : E_NONE;
     }
-    if (stored) e = 8u | ((lo32 & 255u) << 6);  // a stored byte: a literal of eight bits
     const uint32_t nb = e & 15u, kind = (e >> 4) & 3u, val = e >> 6;
-    const bool is_lit = !dist && kind == 0u, is_len = !dist && kind == 1u, is_eob = !dist && kind == 2u;
+    const bool is_lit = kind == 0u, is_len = !dist && kind == 1u, is_eob = kind == 2u;  // (the distance table holds kind 1 only)
     // a length's or a distance's base and extra bits (RFC 1951's tables are regular: computed)
-    const uint32_t eb_l = (val < 8u || val == 28u) ? 0u : ((val >> 2) - 1u) & 7u;
+    const uint32_t eb_l = (val < 8u || val == 28u) ? 0u : ((val >> 2) - 1u) & 7u;  // (masked: a literal's value runs through here too)
     const uint32_t base_l = val < 8u ? 3u + val : (val == 28u ? 258u : 3u + ((4u + (val & 3u)) << eb_l));
     const uint32_t eb_d = val < 4u ? 0u : ((val >> 1) - 1u) & 15u;
     const uint32_t base_d = val < 4u ? 1u + val : 1u + ((2u + (val & 1u)) << eb_d);
     const uint32_t eb = dist ? eb_d : (is_len ? eb_l : 0u);
     const uint32_t value = (dist ? base_d : base_l) + ((lo32 >> nb) & ((1u << eb) - 1u));  // (code + extra bits <= 28: inside the low dword)
-    const bool bad = nb == 0u || (is_len && val >= 29u) || (dist && (kind != 1u || val >= 30u)) || (!dist && kind == 3u);
     drop(L, nb + eb);
-    // the token: a literal is one slot, a match leaves when its distance is known
+    // the token: a literal is one slot; a match leaves when its distance is known, two slots
     const uint32_t ns = dist ? 2u : (is_lit ? 1u : 0u);
-    const uint32_t v = dist ? ((TOK_MATCH | (L.pend - 3u)) | ((value - 1u) << 16)) : (is_lit ? val : 0u);
-    L.lo |= (uint64_t)v << (16u * L.nacc);
-    if (L.nacc + ns > 4u) L.hi = v >> 16;
-    L.nacc += ns;
-    bool full = false;
-    if (L.nacc >= 4u) {
-        if (L.op < L.op_end) *L.op++ = L.lo;
-        else full = true;
-        L.lo = L.hi;
-        L.hi = 0;
-        L.nacc -= 4u;
+    const bool room = L.on + ns <= L.on_end;
+    if (is_lit && room) L.tok[L.on] = (uint16_t)val;
+    if (dist && room) {
+        L.tok[L.on] = (uint16_t)(TOK_MATCH | (L.pend - 3u));
+        L.tok[L.on + 1u] = (uint16_t)(value - 1u);
     }
+    L.on += room ? ns : 0u;
     L.text_len += dist ? L.pend : (is_lit ? 1u : 0u);
     L.pend = is_len ? value : L.pend;
-    L.stored_left -= stored ? 1u : 0u;
-    const bool block_ends = is_eob || (stored && L.stored_left == 0u);
-    uint32_t st = L.state;
-    st = is_len ? (uint32_t)ST_DIST : st;
-    st = dist ? (uint32_t)ST_LIT : st;
-    st = block_ends ? (L.final_seen ? (uint32_t)ST_DONE : (uint32_t)ST_HEADER) : st;
-    if (bad || full) {
-        if (!L.status) L.status = bad ? (uint32_t)QD_INFLATE_BAD_CODE : (uint32_t)QD_INFLATE_TOKEN_SPACE;
+    uint32_t st = is_len ? (uint32_t)ST_DIST : (uint32_t)ST_LIT;
+    st = is_eob ? (L.final_seen ? (uint32_t)ST_DONE : (uint32_t)ST_HEADER) : st;
+    if (nb == 0u || !room) {
+        if (!L.status) L.status = nb == 0u ? (uint32_t)QD_INFLATE_BAD_CODE : (uint32_t)QD_INFLATE_TOKEN_SPACE;
         st = ST_DONE;
     }
     L.state = st;
@@ -534,6 +510,26 @@ QD3_HD void turn(Lane<C>& L, const uint16_t* tab, const uint32_t* ring, uint32_t
     L.buf |= more ? (uint64_t)next_word << (L.have & 63u) : 0ull;
     L.have += more ? 32u : 0u;
     L.rd += more ? 1u : 0u;
+}
+// A turn of a lane inside a stored block: a byte of it leaves as a literal (rare in fastq: a loop of its own, so that the turns
+// above do not carry it).
+template <class C>
+QD3_HD void turn_stored(Lane<C>& L, const uint32_t* ring, uint32_t lane) {
+    const uint32_t next_word = ring[ring_at(L.rd, lane)];
+    if (L.on < L.on_end) {
+        L.tok[L.on++] = (uint16_t)((uint32_t)L.buf & 255u);
+    } else {
+        if (!L.status) L.status = QD_INFLATE_TOKEN_SPACE;
+        L.state = ST_DONE;
+    }
+    drop(L, 8);
+    ++L.text_len;
+    if (--L.stored_left == 0 && L.state != ST_DONE) L.state = L.final_seen ? (uint32_t)ST_DONE : (uint32_t)ST_HEADER;
+    if (L.have <= 32) {
+        L.buf |= (uint64_t)next_word << L.have;
+        L.have += 32;
+        ++L.rd;
+    }
 }
 
 template <class C>
@@ -543,10 +539,9 @@ QD3_HD void lane_init(Lane<C>& L, const Unit& u, uint16_t* tokens, uint32_t* len
     L.bit_stop = u.bit_stop;
     L.bit_end = u.bit_end;
     L.lens = lens;
-    L.op0 = L.op = reinterpret_cast<uint64_t*>(tokens + u.tok_off);
-    L.op_end = L.op0 + u.tok_cap / 4u;
-    L.lo = 0;
-    L.hi = L.nacc = 0;
+    L.tok = tokens;
+    L.on0 = L.on = (uint32_t)u.tok_off;  // (slot indices are 32 bit: a launch's token buffer holds less than 2^32 slots)
+    L.on_end = L.on0 + u.tok_cap;
     L.text_len = L.pend = L.stored_left = 0;
     L.state = ST_HEADER;
     L.status = L.final_seen = 0;
@@ -567,10 +562,6 @@ QD3_HD void lane_init(Lane<C>& L, const Unit& u, uint16_t* tokens, uint32_t* len
 template <class C>
 QD3_HD void lane_finish(Lane<C>& L, Result* r) {
     const uint32_t n = slots_made(L);
-    if (L.nacc) {
-        if (L.op < L.op_end) *L.op = L.lo;
-        else if (!L.status) L.status = QD_INFLATE_TOKEN_SPACE;
-    }
     if (!L.status && L.state == ST_DONE && bitpos(L) > L.bit_end) L.status = QD_INFLATE_TRUNCATED;
     r->status = L.status;
     r->final_seen = (L.final_seen && !L.status) ? 1u : 0u;

@@ -1087,6 +1087,7 @@ int qd_comm_destroy(qd_comm* cm) {
 
 // ---- BGZF inflate on the device (include/quade_hip.h; kernel: quade_inflate.hip) ------------------------------
 uint32_t qd_io_crc32(const uint8_t* p, size_t n);  // quade_io.cpp: libdeflate's when loaded, else zlib's
+uint32_t qd_crc32_combine_host(uint32_t crc1, uint32_t crc2, uint64_t len2);  // quade_io.cpp (zlib's)
 
 struct qd_inflater {
     int device = -1;
@@ -1587,3 +1588,133 @@ int qd_deflater_run(qd_deflater* f, int32_t n_pieces, const uint8_t* const* text
 }
 
 }  // extern "C"
+
+// ---- a whole gzip file image through the device's gzip inflater (include/quade_hip.h: qd_dev_gunzip) -----------------------------------
+namespace {
+// bytes of a gzip member's header at p[0 .. n) (RFC 1952), 0 when it is none or does not end inside n
+size_t gzip_header_bytes(const uint8_t* p, size_t n) {
+    if (n < 10 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xe0)) return 0;
+    const int flg = p[3];
+    size_t at = 10;
+    if (flg & 4) {
+        if (at + 2 > n) return 0;
+        at += 2 + (p[at] | ((size_t)p[at + 1] << 8));
+    }
+    for (int bit : {8, 16})
+        if (flg & bit) {
+            while (at < n && p[at]) ++at;
+            ++at;
+        }
+    if (flg & 2) at += 2;
+    return at <= n ? at : 0;
+}
+}  // namespace
+
+extern "C" int qd_dev_gunzip(int device_id, const uint8_t* gz, int64_t gz_len, uint8_t* out, int64_t out_cap, int64_t* out_len, int64_t step_bytes,
+                             int64_t stretch_bytes, int64_t unit_text, int64_t* stats) {
+    if (!gz || gz_len < 0 || !out_len || (out_cap > 0 && !out) || step_bytes < 4096) return QD_ERR_INVALID;
+    *out_len = 0;
+    if (hipSetDevice(device_id) != hipSuccess) return QD_ERR_NO_DEVICE;
+    hipStream_t st = nullptr;
+    uint8_t *d_gz = nullptr, *d_out = nullptr, *d_win = nullptr;
+    int rc = QD_OK;
+    qd_gz G;
+    if (stretch_bytes > 0) G.stretch_bytes = (uint64_t)stretch_bytes;
+    if (unit_text > 0) G.unit_text = (uint64_t)unit_text;
+    int64_t members = 0, steps_run = 0;
+    auto done = [&](int code) {
+        if (st) (void)hipStreamSynchronize(st);
+        if (d_gz) (void)hipFree(d_gz);
+        if (d_out) (void)hipFree(d_out);
+        if (d_win) (void)hipFree(d_win);
+        if (st) (void)hipStreamDestroy(st);
+        if (stats) {
+            const qd_gz_stats s = G.stats();
+            stats[0] = members;
+            stats[1] = steps_run;
+            stats[2] = s.stretches;
+            stats[3] = s.units;
+            stats[4] = s.chain_retries;
+            stats[5] = s.partial_last;
+        }
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return done(QD_ERR_HIP);
+    if (hipMalloc((void**)&d_gz, (size_t)gz_len + 4096) != hipSuccess || hipMalloc((void**)&d_out, (size_t)std::max<int64_t>(out_cap, 1) + 4096) != hipSuccess ||
+        hipMalloc((void**)&d_win, 32768) != hipSuccess)
+        return done(QD_ERR_HIP);
+    if (hipMemset(d_gz + gz_len, 0, 4096) != hipSuccess || (gz_len && hipMemcpy(d_gz, gz, (size_t)gz_len, hipMemcpyHostToDevice) != hipSuccess) ||
+        hipMemset(d_win, 0, 32768) != hipSuccess)
+        return done(QD_ERR_HIP);
+    int64_t pos = 0, opos = 0;  // next member's header; text so far
+    while (pos < gz_len && rc == QD_OK) {
+        const size_t hb = gzip_header_bytes(gz + pos, (size_t)(gz_len - pos));
+        if (!hb) {
+            rc = QD_ERR_FORMAT;
+            break;
+        }
+        uint64_t bit = 8 * (uint64_t)(pos + (int64_t)hb);  // absolute bit position of the next block header
+        uint32_t crc = 0;
+        uint64_t member_text = 0;
+        qd_gz_step s{};
+        s.carried = d_win;
+        s.carried_valid = 0;
+        int64_t step = step_bytes;
+        bool ended = false;
+        while (!ended) {
+            const uint64_t byte0 = (bit >> 3) & ~(uint64_t)15;
+            s.comp = d_gz + byte0;
+            s.comp_bytes = (uint64_t)std::min<int64_t>(step, gz_len - (int64_t)byte0);
+            s.bit_start = bit - 8 * byte0;
+            s.at_end = (int64_t)byte0 + (int64_t)s.comp_bytes >= gz_len;
+            if (G.decode(&s, 1, st) != hipSuccess) return done(QD_ERR_HIP);
+            ++steps_run;
+            if (s.failed) {
+                rc = QD_ERR_FORMAT;
+                break;
+            }
+            if (s.bit_next == s.bit_start && !s.member_end) {  // a block longer than the step: more input, if there is any
+                if (s.at_end) {
+                    rc = QD_ERR_FORMAT;
+                    break;
+                }
+                step *= 2;
+                continue;
+            }
+            if (opos + (int64_t)s.text_len > out_cap) {
+                rc = QD_ERR_INVALID;
+                break;
+            }
+            uint8_t* dst = d_out + opos;
+            if (G.resolve(&s, 1, &dst, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess || G.finish(&s, 1) != hipSuccess) return done(QD_ERR_HIP);
+            if (s.failed) {
+                rc = QD_ERR_FORMAT;
+                break;
+            }
+            crc = member_text ? qd_crc32_combine_host(crc, s.crc32, s.text_len) : s.crc32;
+            if (s.text_len == 0 && member_text == 0) crc = 0;
+            member_text += s.text_len;
+            opos += (int64_t)s.text_len;
+            bit = 8 * byte0 + s.bit_next;
+            ended = s.member_end != 0;
+        }
+        if (rc != QD_OK) break;
+        const int64_t tr = (int64_t)((bit + 7) >> 3);  // the trailer: CRC-32 and ISIZE of the member's text
+        if (tr + 8 > gz_len) {
+            rc = QD_ERR_FORMAT;
+            break;
+        }
+        const uint32_t want_crc = gz[tr] | ((uint32_t)gz[tr + 1] << 8) | ((uint32_t)gz[tr + 2] << 16) | ((uint32_t)gz[tr + 3] << 24);
+        const uint32_t want_len = gz[tr + 4] | ((uint32_t)gz[tr + 5] << 8) | ((uint32_t)gz[tr + 6] << 16) | ((uint32_t)gz[tr + 7] << 24);
+        if (want_crc != crc || want_len != (uint32_t)member_text) {
+            if (getenv("QUADE_GZ_DEBUG")) fprintf(stderr, "[qd_dev_gunzip] trailer at %lld: crc %08x (text's %08x), isize %u (text %llu)\n", (long long)tr, want_crc, crc, want_len, (unsigned long long)member_text);
+            rc = QD_ERR_FORMAT;
+            break;
+        }
+        ++members;
+        pos = tr + 8;
+    }
+    if (rc == QD_OK && opos && hipMemcpy(out, d_out, (size_t)opos, hipMemcpyDeviceToHost) != hipSuccess) rc = QD_ERR_HIP;
+    if (rc == QD_OK) *out_len = opos;
+    return done(rc);
+}

@@ -26,3 +26,50 @@ hipError_t qd_launch_inflate3_jobs(const qd_inflate3_job* d_jobs, uint32_t n_blo
 // comp_bytes; expect_crc (device, per block) may be null
 hipError_t qd_launch_inflate3(const uint8_t* comp, size_t comp_bytes, const qd_inflate_block* blocks, uint32_t n_blocks, uint8_t* out, int32_t* status, void* scratch,
                               hipStream_t st, const uint32_t* expect_crc = nullptr);
+
+// ---- ordinary gzip members on the device (quade_inflate3.hip, second half) -----------------------------------------------------------
+// One step of one stream: the compressed bytes the caller holds on the device, decoding from a known block header on.
+struct qd_gz_step {
+    // in
+    const uint8_t* comp;     // device; 16-byte aligned; readable up to 512 bytes behind comp_bytes
+    uint64_t comp_bytes;
+    uint64_t bit_start;      // a deflate block header starts here (bits from comp)
+    int32_t at_end;          // no more input exists behind comp_bytes
+    int32_t pad0;
+    uint8_t* carried;        // device, 32 KiB: the text in front of bit_start's block (in), in front of the next step's (out of qd_gz::resolve)
+    uint32_t carried_valid;  // how much of it exists (0 at a member's start); updated by resolve
+    uint32_t pad1;
+    // out of decode()
+    uint64_t text_len;       // the text this step makes
+    uint64_t bit_next;       // where the next step starts: a block boundary behind bit_start (== bit_start: nothing was decoded)
+    int32_t member_end;      // the member's last block is inside: bit_next lies behind it (the trailer follows at the next byte boundary)
+    int32_t failed;          // != 0: the device gives this stream up (a QD_INFLATE_* code): nothing of this step counts
+    // out of finish(): CRC-32 of this step's text (combined over its units)
+    uint32_t crc32;
+    uint32_t pad2;
+};
+struct qd_gz_stats {
+    int64_t stretches, probed_bits_est, units, chain_retries, partial_last;
+};
+class qd_gz_impl;
+// Several streams advance together (one token launch for all of them: its throughput is the number of stretches in flight).
+class qd_gz {
+  public:
+    qd_gz();
+    ~qd_gz();
+    qd_gz(const qd_gz&) = delete;
+    qd_gz& operator=(const qd_gz&) = delete;
+    // probe + tokens + chain check; synchronises `st` twice.  Fills text_len / bit_next / member_end / failed of every step.
+    hipError_t decode(qd_gz_step* steps, int n, hipStream_t st);
+    // the decoded steps' text -> out[i][0 .. text_len) (device); asynchronous on `st`; carried windows updated on the device
+    hipError_t resolve(qd_gz_step* steps, int n, uint8_t* const* out, hipStream_t st);
+    // after `st` has run resolve(): the steps' CRC-32s, and failed != 0 for a stream whose tokens did not resolve (a damaged stream)
+    hipError_t finish(qd_gz_step* steps, int n);
+    qd_gz_stats stats() const;
+    // knobs (tests: small values make many stretches and units out of small inputs)
+    uint64_t stretch_bytes = 32u << 10;  // compressed bytes per stretch: a lane decodes one
+    uint64_t unit_text = 1u << 20;       // text per resolve unit, about
+
+  private:
+    qd_gz_impl* p_;
+};

@@ -81,12 +81,24 @@ __global__ __launch_bounds__(64) void inflate3_tokens(const qd3::Unit* units, co
             waited = 0;
             continue;
         }
+        // (a lane that has run past its input's end -- the last stretch of a gzip step, inside a block that needs bytes not there yet,
+        //  or a damaged block -- would decode whatever lies behind until its slots are full: it stops here; what it says counts up
+        //  to the last block boundary inside the input)
+        if (dec && qd3::bitpos(L) > L.bit_end + 64u) qd3::fail(L, QD_INFLATE_TRUNCATED);
         qd3::ring_wait();  // what the last round requested is there ...
         qd3::landed_all(L);
         qd3::topup(L, ring, lane, dec);  // ... what it used up is requested again, and lands while this round runs
+        if (__ballot(L.state == qd3::ST_STORED)) {  // (stored blocks: byte soup, not fastq)
 #pragma unroll 1
-        for (int t = 0; t < qd3::ROUND_TURNS; ++t)
-            if (L.state <= qd3::ST_STORED) qd3::turn<C>(L, tab, ring, lane);
+            for (int t = 0; t < qd3::ROUND_TURNS; ++t) {
+                if (L.state == qd3::ST_STORED) qd3::turn_stored<C>(L, ring, lane);
+                else if (L.state <= qd3::ST_DIST) qd3::turn<C>(L, tab, ring, lane);
+            }
+        } else {
+#pragma unroll 1
+            for (int t = 0; t < qd3::ROUND_TURNS; ++t)
+                if (L.state <= qd3::ST_DIST) qd3::turn<C>(L, tab, ring, lane);
+        }
         if (mh) ++waited;
     }
     if (u < n_units) qd3::lane_finish(L, res + u);
@@ -285,6 +297,373 @@ __global__ __launch_bounds__(NT) void inflate3_resolve_bgzf(const qd_inflate3_jo
     if (tid == 0) status[i] = err;
 }
 
+// ======================================================================================================================================
+// Ordinary gzip members (the reference's input format: src/Quade.py:203-206 opens plain .fastq.gz; its test/dataset files are single
+// members): one DEFLATE stream of any length.  The published two-pass scheme (pugz / rapidgzip; quade_pgz.cpp is the host's form of
+// it) on the device:
+//   gz_probe          the stream's bytes are cut into stretches; a wave per stretch tries every bit offset for a block header that holds
+//                     (type 2, counts in range, the code-length code complete, both codes complete, an end-of-block code);
+//   inflate3_tokens   a lane per stretch decodes from its block start to the next stretch's: tokens, as for BGZF blocks;
+//   (host)            a stretch counts only if it began exactly where its predecessor stopped: every accepted boundary is proven by
+//                     the chain from the stream's true start, never guessed; text offsets by prefix sums of the stretches' lengths;
+//   gz_resolve        a workgroup per unit (~1 MB of text: a run of stretches) turns tokens into 16-bit symbols -- a byte, or a marker
+//                     "byte i of the 32 KiB before this unit" -- through a ring of the last 32 KiB + one window in LDS;
+//   gz_windows        one workgroup per stream walks its units in order: a unit's last 32 KiB resolved against its predecessor's (the
+//                     only serial step: 64 KB read, 32 KB written per unit);
+//   gz_fixup          symbols -> bytes with every unit's resolved window.
+// The member's CRC-32 and ISIZE are checked from per-unit CRCs (qd_text_crc32 + combine).
+struct GzStretch {
+    const uint32_t* base;  // 16-byte aligned; bit positions count from here
+    uint64_t bit_from;     // first position to try
+    uint64_t bit_to;       // positions tried are < bit_to
+    uint64_t bit_end;      // the input ends here
+};
+
+__device__ __forceinline__ uint64_t gz_bits(const uint32_t* base, uint64_t bit) {  // 57+ valid bits from `bit` on
+    const uint64_t w = bit >> 5;
+    const uint32_t sh = (uint32_t)bit & 31u;
+    const uint64_t lo = base[w], mid = base[w + 1], hi = base[w + 2];
+    return sh ? ((lo | (mid << 32)) >> sh) | (hi << (64u - sh)) : (lo | (mid << 32));
+}
+
+// does a dynamic block's header hold at `bit`?  clt: 128 bytes of the lane's own LDS
+__device__ bool gz_header_holds(const uint32_t* base, uint64_t bit, uint64_t bit_end, uint8_t* clt) {
+    if (bit + 17 + 12 > bit_end) return false;
+    uint64_t x = gz_bits(base, bit);
+    if ((x & 7u) != 4u) return false;  // not the last block, dynamic codes
+    const uint32_t nlit = ((uint32_t)(x >> 3) & 31u) + 257u, ndist = ((uint32_t)(x >> 8) & 31u) + 1u, ncl = ((uint32_t)(x >> 13) & 15u) + 4u;
+    if (nlit > 286u || ndist > 30u) return false;
+    uint64_t pos = bit + 17;
+    x = gz_bits(base, pos);
+    uint64_t cl = 0, cc = 0;
+    for (uint32_t k = 0; k < ncl; ++k) {
+        const uint32_t sym = (uint32_t)((k < 12 ? qd3::CLORDER_LO >> (5u * k) : qd3::CLORDER_HI >> (5u * (k - 12u))) & 31u);
+        const uint32_t l = (uint32_t)(x >> (3u * k)) & 7u;
+        cl |= (uint64_t)l << (3u * sym);
+        if (l) cc += 1ull << (8u * l);
+    }
+    pos += 3u * ncl;
+    uint64_t nx = 0;
+    {
+        uint32_t code = 0, kraft = 0;
+#pragma unroll
+        for (uint32_t l = 1; l <= 7; ++l) {
+            code = (code + (l > 1 ? (uint32_t)(cc >> (8u * (l - 1u))) & 255u : 0u)) << 1;
+            nx |= (uint64_t)code << (8u * l);
+            kraft += ((uint32_t)(cc >> (8u * l)) & 255u) << (7u - l);
+        }
+        if (kraft != 128u) return false;  // (zlib wants this code complete)
+    }
+    for (uint32_t s = 0; s < 19; ++s) {
+        const uint32_t l = (uint32_t)(cl >> (3u * s)) & 7u;
+        if (!l) continue;
+        const uint32_t c = (uint32_t)(nx >> (8u * l)) & 255u;
+        nx += 1ull << (8u * l);
+        const uint32_t rev = __brev(c) >> (32u - l);
+        for (uint32_t k = rev; k < 128u; k += 1u << l) clt[k] = (uint8_t)(s | (l << 5));
+    }
+    // the two codes' lengths: only their Kraft sums, the end-of-block code's length and the longest length are kept
+    const uint32_t total = nlit + ndist;
+    uint32_t idx = 0, prev = 0, sum_l = 0, sum_d = 0, max_l = 0, max_d = 0, n_l = 0, n_d = 0, eob = 0;
+    while (idx < total) {
+        if (pos + 14 > bit_end) return false;
+        x = gz_bits(base, pos);
+        const uint32_t e = clt[(uint32_t)x & 127u], nb = e >> 5, s = e & 31u;
+        x >>= nb;
+        pos += nb;
+        uint32_t rep = 1, v = s;
+        if (s == 16) {
+            if (idx == 0) return false;
+            v = prev;
+            rep = 3u + ((uint32_t)x & 3u);
+            pos += 2;
+        } else if (s == 17) {
+            v = 0;
+            rep = 3u + ((uint32_t)x & 7u);
+            pos += 3;
+        } else if (s == 18) {
+            v = 0;
+            rep = 11u + ((uint32_t)x & 127u);
+            pos += 7;
+        }
+        if (idx + rep > total) return false;
+        if (v) {
+            const uint32_t in_l = idx < nlit ? min(rep, nlit - idx) : 0u, in_d = rep - in_l;
+            sum_l += in_l << (15u - v);
+            sum_d += in_d << (15u - v);
+            n_l += in_l;
+            n_d += in_d;
+            if (in_l) max_l = max(max_l, v);
+            if (in_d) max_d = max(max_d, v);
+            if (idx <= 256u && idx + rep > 256u) eob = v;
+            if (sum_l > 32768u || sum_d > 32768u) return false;  // over-subscribed
+        }
+        idx += rep;
+        prev = v;
+    }
+    if (!eob) return false;
+    if (sum_l != 32768u && !(n_l == 1u && max_l == 1u)) return false;
+    if (sum_d != 32768u && n_d != 0u && !(n_d == 1u && max_d == 1u)) return false;
+    return true;
+}
+
+// found[i] = the first position in [bit_from, bit_to) of stretch i at which a dynamic block's header holds, or ~0
+__global__ __launch_bounds__(64) void gz_probe(const GzStretch* stretches, uint32_t n, uint64_t* found) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t probe_lds[];
+    const uint32_t i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n) return;
+    const GzStretch st = stretches[i];
+    uint8_t* clt = probe_lds + 128u * lane;
+    uint64_t hit = ~0ull;
+#pragma unroll 1
+    for (uint64_t at = st.bit_from; at < st.bit_to; at += 64) {
+        const uint64_t bit = at + lane;
+        const bool ok = bit < st.bit_to && gz_header_holds(st.base, bit, st.bit_end, clt);
+        const uint64_t m = __ballot(ok);
+        if (m) {
+            hit = at + (uint64_t)__builtin_ctzll(m);
+            break;
+        }
+    }
+    if (lane == 0) found[i] = hit;
+}
+
+// ---- tokens -> 16-bit symbols, a workgroup per unit -------------------------------------------------------------------------------------
+struct GzUnit {              // a run of consecutive stretches of one stream: ~1 MB of text
+    uint32_t first, n;       // its stretches: results / token regions [first, first + n)
+    uint32_t stream, pad;
+    uint64_t sym_off;        // where its symbols go in the launch's symbol buffer (= where its text goes, counted over the launch)
+    uint64_t text_len;
+};
+constexpr uint32_t GZ_MARK = 0x8000u;  // symbol: a byte, or GZ_MARK + i = byte i of the 32 KiB in front of the unit (i = 32767: the last one)
+constexpr uint32_t GZ_WIN = 32768u;
+
+template <int NT, int Q>
+struct GzLds {
+    uint16_t ring[GZ_WIN + Q];  // the last 32 Ki symbols + the window being made; position p lives at (p + GZ_WIN) mod (GZ_WIN + Q)
+    uint16_t par[Q];
+    uint32_t wsum[NT / 64 + 1];
+    uint32_t ctl[8];
+};
+
+template <int NT, int Q>
+__global__ __launch_bounds__(NT) void gz_resolve(const GzUnit* units, uint32_t n_units, const qd3::Unit* stretches, const qd3::Result* res, const uint32_t* use_slots,
+                                                 const uint16_t* tokens, uint16_t* sym, uint16_t* wout, int32_t* status) {
+    static_assert(Q % NT == 0 && Q / NT <= 32 && GZ_WIN % Q == 0, "a lane's share of a window");
+    constexpr int K = Q / NT;
+    constexpr uint32_t RN = GZ_WIN + Q;
+    extern __shared__ __attribute__((aligned(16))) uint8_t gz_lds_raw[];
+    GzLds<NT, Q>& S = *reinterpret_cast<GzLds<NT, Q>*>(gz_lds_raw);
+    typedef volatile __attribute__((address_space(3))) uint16_t lds_vu16;
+    lds_vu16* const ring = (lds_vu16*)S.ring;
+    lds_vu16* const par = (lds_vu16*)S.par;
+    const uint32_t ui = blockIdx.x, tid = threadIdx.x;
+    if (ui >= n_units) return;
+    const GzUnit U = units[ui];
+    for (uint32_t k = tid; k < GZ_WIN; k += NT) ring[k] = (uint16_t)(GZ_MARK | k);
+    if (tid < 8) S.ctl[tid] = 0;
+    __syncthreads();
+    auto rix = [](uint32_t p) { return (p + GZ_WIN) % RN; };  // (p: position in the unit's text; p + GZ_WIN >= 0 for what a match may reach)
+    auto init_par = [&](uint32_t w) {
+        const uint32_t rb = rix(w * Q);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t i = tid + (uint32_t)k * NT;
+            par[i] = (uint16_t)(rb + i);
+        }
+        __syncthreads();
+    };
+    uint16_t* const out = sym + U.sym_off;
+    const uint32_t olen = (uint32_t)U.text_len;
+    // chains resolved inside window w (quade_inflate.hip's match stage, on ring indices), then the window's symbols leave
+    auto finalize = [&](uint32_t w) {
+        const uint32_t qb = w * Q, hi = min(qb + (uint32_t)Q, olen), rb = rix(qb);
+        if (tid == 0) S.ctl[5] = S.ctl[6] = S.ctl[7] = 0;
+        __syncthreads();
+        uint32_t pend = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t i = tid + (uint32_t)k * NT;
+            if (qb + i < hi && par[i] != (uint16_t)(rb + i)) pend |= 1u << k;
+        }
+        constexpr int MATCH_ROUNDS = 24;
+#pragma unroll 1
+        for (int round = 0; round < MATCH_ROUNDS; ++round) {
+#pragma unroll 1
+            for (uint32_t left = pend; left; left &= left - 1u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(left), i = tid + k * NT;
+                const uint32_t q = par[i];
+                const bool outside = q < rb || q >= rb + (uint32_t)Q;  // (the ring's other pages: final)
+                if (outside || par[q - rb] == q) {
+                    ring[rb + i] = ring[q];
+                    par[i] = (uint16_t)(rb + i);
+                    pend &= ~(1u << k);
+                } else {
+                    par[i] = par[q - rb];
+                }
+            }
+            uint32_t* flag = &S.ctl[5];
+            if (pend) flag[round % 3] = 1;
+            __syncthreads();
+            const uint32_t more = flag[round % 3];
+            if (tid == 0) flag[(round + 2) % 3] = 0;
+            if (!more) break;
+            if (round == MATCH_ROUNDS - 1 && tid == 0) S.ctl[4] = 1;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; qb + i < hi; i += NT) out[qb + i] = ring[rb + i];
+        __syncthreads();
+    };
+    uint32_t base_pos = 0, cur_win = 0;
+    init_par(0);
+#pragma unroll 1
+    for (uint32_t su = U.first; su < U.first + U.n; ++su) {
+        const uint16_t* tk = tokens + stretches[su].tok_off;
+        const uint32_t n_slots = use_slots[su];
+#pragma unroll 1
+        for (uint32_t c0 = 0; c0 < n_slots; c0 += NT * 4u) {
+            const uint32_t s0 = c0 + 4u * tid;
+            uint64_t four = 0;
+            uint32_t prev = 0, next = 0;
+            if (s0 < n_slots) {
+                four = *reinterpret_cast<const uint64_t*>(tk + s0);
+                if (s0) prev = tk[s0 - 1];
+                if (s0 + 4u < n_slots) next = tk[s0 + 4u];
+            }
+            uint32_t sl[5], ln[4], at[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sl[j] = (uint32_t)(four >> (16 * j)) & 0xFFFFu;
+            sl[4] = next;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool valid = s0 + (uint32_t)j < n_slots;
+                const bool is_dist = ((j ? sl[j - 1] : prev) & qd3::TOK_MATCH) != 0;
+                ln[j] = (!valid || is_dist) ? 0u : ((sl[j] & qd3::TOK_MATCH) ? (sl[j] & 0xFFu) + 3u : 1u);
+                sum += ln[j];
+            }
+            uint32_t total;
+            uint32_t pos = base_pos + block_scan_excl<NT>(sum, S.wsum, total);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                at[j] = pos;
+                pos += ln[j];
+            }
+            const uint32_t chunk_hi = min(base_pos + total, olen);
+            const uint32_t w_first = cur_win, w_last = max(w_first, chunk_hi ? (chunk_hi - 1u) / (uint32_t)Q : 0u);
+#pragma unroll 1
+            for (uint32_t w = w_first; w <= w_last; ++w) {
+                if (w != cur_win) {
+                    finalize(cur_win);
+                    cur_win = w;
+                    init_par(w);
+                }
+                const uint32_t wlo = w * Q, whi = min(wlo + (uint32_t)Q, olen), rb = rix(wlo);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t d0 = at[j], len = ln[j];
+                    if (len == 1u) {  // a literal: into its window's page when that window is the current one
+                        if (d0 >= wlo && d0 < whi) ring[rb + (d0 - wlo)] = (uint16_t)sl[j];
+                        continue;
+                    }
+                    if (len < 3u) continue;
+                    const uint32_t dist = sl[j + 1] + 1u;
+                    if (dist > d0 + GZ_WIN || d0 + len > olen) {  // reaches further back than DEFLATE's window, or beyond the unit's text
+                        S.ctl[4] = 1;
+                        continue;
+                    }
+                    const uint32_t a = max(d0, wlo), z = min(d0 + len, whi);
+                    for (uint32_t p = a; p < z; ++p) par[p - wlo] = (uint16_t)rix(p - dist);  // (p - dist may be "negative": rix adds the window)
+                }
+            }
+            base_pos += total;
+        }
+    }
+    finalize(cur_win);
+    // the unit's last 32 Ki symbols: what the next unit's markers refer to
+    {
+        uint16_t* wo = wout + (size_t)ui * GZ_WIN;
+        for (uint32_t j = tid; j < GZ_WIN; j += NT) wo[j] = ring[rix(olen - GZ_WIN + j)];  // (wraps below zero into the markers of this unit's own window)
+    }
+    if (tid == 0) status[ui] = (S.ctl[4] || base_pos != olen) ? QD_INFLATE_BAD_DISTANCE : 0;
+}
+
+// one workgroup per stream: its units in order; win_in[u] = the 32 KiB of text in front of unit u (bytes), carried[stream] = those behind
+// the stream's last unit (for the next launch).  valid[stream]: how many bytes of the incoming window exist (a marker further back: error)
+struct GzChain {
+    uint32_t first_unit, n_units;  // the stream's units of this launch
+    uint32_t valid;                // bytes of text in front of the first unit that exist (<= 32 Ki)
+    uint32_t pad;
+    uint8_t* carried;              // 32 KiB: in: the text in front of the first unit (its last `valid` bytes count); out: in front of the next launch
+};
+__global__ __launch_bounds__(1024) void gz_windows(const GzChain* chains, const GzUnit* units, const uint16_t* wout, uint8_t* win_in, int32_t* chain_status) {
+    __shared__ uint8_t W[2][GZ_WIN];
+    __shared__ uint32_t bad;
+    const GzChain C = chains[blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    for (uint32_t j = tid; j < GZ_WIN / 4; j += 1024) reinterpret_cast<uint32_t*>(W[0])[j] = reinterpret_cast<const uint32_t*>(C.carried)[j];
+    __syncthreads();
+    uint32_t cur = 0;
+    uint64_t have = C.valid;  // text that exists in front of the current unit (saturates at 32 Ki)
+    for (uint32_t u = C.first_unit; u < C.first_unit + C.n_units; ++u) {
+        uint32_t* wi = reinterpret_cast<uint32_t*>(win_in + (size_t)u * GZ_WIN);
+        for (uint32_t j = tid; j < GZ_WIN / 4; j += 1024) wi[j] = reinterpret_cast<const uint32_t*>(W[cur])[j];
+        const uint16_t* wo = wout + (size_t)u * GZ_WIN;
+        const uint32_t floor_idx = have >= GZ_WIN ? 0u : GZ_WIN - (uint32_t)have;  // markers below it point in front of the stream's start
+        for (uint32_t j = tid; j < GZ_WIN; j += 1024) {
+            const uint32_t s = wo[j];
+            uint32_t b = s;
+            if (s & GZ_MARK) {
+                const uint32_t i = s & 0x7FFFu;
+                if (i < floor_idx) {
+                    // (a marker in front of the stream's start can only be one of this unit's own untouched window slots when the
+                    //  unit's text is shorter than 32 Ki: those bytes do not exist and nobody may refer to them)
+                    b = 0;
+                    if (j >= GZ_WIN - min((uint64_t)GZ_WIN, units[u].text_len + have)) bad = 1;
+                } else {
+                    b = W[cur][i];
+                }
+            }
+            W[cur ^ 1][j] = (uint8_t)b;
+        }
+        __syncthreads();
+        cur ^= 1;
+        have = min<uint64_t>(GZ_WIN, have + units[u].text_len);
+    }
+    for (uint32_t j = tid; j < GZ_WIN / 4; j += 1024) reinterpret_cast<uint32_t*>(C.carried)[j] = reinterpret_cast<const uint32_t*>(W[cur])[j];
+    __syncthreads();
+    if (tid == 0) chain_status[blockIdx.x] = bad ? QD_INFLATE_BAD_DISTANCE : 0;
+}
+
+// symbols -> bytes: out[stream text] = a byte, or the unit's window byte a marker names.  One workgroup per GZ_FIX_TILE symbols of a unit.
+constexpr uint32_t GZ_FIX_TILE = 16384;
+struct GzFixTile {
+    uint32_t unit, off;  // symbols [off, off + GZ_FIX_TILE) of the unit
+};
+__global__ __launch_bounds__(256) void gz_fixup(const GzFixTile* tiles, uint32_t n_tiles, const GzUnit* units, uint8_t* const* stream_out, const uint64_t* unit_out_off,
+                                                const uint16_t* sym, const uint8_t* win_in, const uint32_t* unit_floor, int32_t* unit_status) {
+    const uint32_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const GzFixTile T = tiles[t];
+    const GzUnit U = units[T.unit];
+    const uint16_t* s = sym + U.sym_off + T.off;
+    uint8_t* o = stream_out[U.stream] + unit_out_off[T.unit] + T.off;
+    const uint8_t* W = win_in + (size_t)T.unit * GZ_WIN;
+    const uint32_t n = (uint32_t)min<uint64_t>(GZ_FIX_TILE, U.text_len - T.off), floor_idx = unit_floor[T.unit];
+    bool bad = false;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t v = s[i];
+        uint32_t b = v;
+        if (v & GZ_MARK) {
+            const uint32_t k = v & 0x7FFFu;
+            bad = bad || k < floor_idx;
+            b = W[k];
+        }
+        o[i] = (uint8_t)b;
+    }
+    if (bad) unit_status[T.unit] = QD_INFLATE_BAD_DISTANCE;
+}
+
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e && *e ? atoi(e) : dflt;
@@ -373,4 +752,485 @@ hipError_t qd_launch_inflate3(const uint8_t* comp, size_t comp_bytes, const qd_i
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return qd_launch_inflate3_jobs(c.jobs, n_blocks, status, scratch, st);
+}
+
+// ======================================================================================================================================
+// qd_gz: the host side of the gzip kernels above
+#include <algorithm>
+#include <vector>
+
+#include "quade_text.h"
+
+namespace {
+struct GBuf {  // grow-only device allocation
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    hipError_t need(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(p);
+        }
+        p = nullptr;
+        cap = 0;
+        const size_t want = n + n / 4 + 65536;
+        const hipError_t e = hipMalloc((void**)&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    ~GBuf() {
+        if (p) (void)hipFree(p);
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+struct HBuf {  // grow-only page-locked host allocation
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    hipError_t need(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = n + n / 4 + 4096;
+        const hipError_t e = hipHostMalloc((void**)&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    ~HBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+#define GZCHK(call)                     \
+    do {                                \
+        const hipError_t e_ = (call);   \
+        if (e_ != hipSuccess) return e_; \
+    } while (0)
+}  // namespace
+
+class qd_gz_impl {
+  public:
+    // per step, between decode() and resolve()
+    struct Acc {
+        std::vector<uint32_t> stretch;  // accepted stretches (indices into units_), in order
+        std::vector<uint32_t> use_slots, text;
+    };
+    std::vector<qd3::Unit> units_;
+    std::vector<Acc> acc_;
+    GBuf d_stretch, d_found, d_units, d_res, d_tokens, d_lens, d_use, d_gzunits, d_chains, d_tiles, d_sym, d_wout, d_winin, d_ustat, d_cstat, d_outptr, d_uoff, d_floor,
+        d_ranges, d_crc;
+    HBuf h_found, h_res, h_back, h_up;
+    std::vector<GzUnit> gzunits_;
+    std::vector<uint32_t> unit_step_;  // R-unit -> step
+    std::vector<qd_crc_range> ranges_;
+    size_t n_runits_ = 0, n_chains_ = 0;
+    qd_gz_stats st_{};
+};
+
+qd_gz::qd_gz() : p_(new qd_gz_impl()) {}
+qd_gz::~qd_gz() { delete p_; }
+qd_gz_stats qd_gz::stats() const { return p_->st_; }
+
+hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st) {
+    qd_gz_impl& G = *p_;
+    const uint64_t STRETCH = std::max<uint64_t>(stretch_bytes, 256);
+    G.acc_.assign((size_t)n, qd_gz_impl::Acc());
+    // 1. stretches: a known start per stream, a search range for every further one
+    std::vector<GzStretch> probe;
+    std::vector<std::pair<int, uint32_t>> probe_of;  // (step, stretch number)
+    std::vector<uint32_t> n_st((size_t)n, 0);
+    for (int i = 0; i < n; ++i) {
+        qd_gz_step& s = steps[i];
+        s.text_len = 0;
+        s.bit_next = s.bit_start;
+        s.member_end = 0;
+        s.failed = 0;
+        s.crc32 = 0;
+        if (((uintptr_t)s.comp & 15u) || s.bit_start >= 8 * s.comp_bytes) {
+            if ((uintptr_t)s.comp & 15u) s.failed = QD_INFLATE_TRUNCATED;
+            continue;
+        }
+        const uint64_t byte0 = s.bit_start >> 3;
+        const uint64_t k_max = (s.comp_bytes - byte0 + STRETCH - 1) / STRETCH;
+        n_st[(size_t)i] = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(k_max, 1u << 20));
+        for (uint32_t k = 1; k < n_st[(size_t)i]; ++k) {
+            GzStretch q;
+            q.base = reinterpret_cast<const uint32_t*>(s.comp);
+            q.bit_from = 8 * (byte0 + k * STRETCH);
+            q.bit_to = std::min<uint64_t>(8 * (byte0 + (k + 1) * STRETCH), 8 * s.comp_bytes);
+            q.bit_end = 8 * s.comp_bytes;
+            probe.push_back(q);
+            probe_of.push_back({i, k});
+        }
+    }
+    std::vector<uint64_t> found(probe.size(), ~0ull);
+    if (!probe.empty()) {
+        GZCHK(G.d_stretch.need(probe.size() * sizeof(GzStretch)));
+        GZCHK(G.d_found.need(probe.size() * 8));
+        GZCHK(G.h_found.need(probe.size() * std::max(sizeof(GzStretch), (size_t)8)));
+        memcpy(G.h_found.p, probe.data(), probe.size() * sizeof(GzStretch));
+        GZCHK(hipMemcpyAsync(G.d_stretch.p, G.h_found.p, probe.size() * sizeof(GzStretch), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(gz_probe, dim3((uint32_t)probe.size()), dim3(64), 64 * 128, st, G.d_stretch.as<GzStretch>(), (uint32_t)probe.size(), G.d_found.as<uint64_t>());
+        GZCHK(hipGetLastError());
+        GZCHK(hipStreamSynchronize(st));  // (the table above has been read: the staging buffer takes the answer)
+        GZCHK(hipMemcpyAsync(G.h_found.p, G.d_found.p, probe.size() * 8, hipMemcpyDeviceToHost, st));
+        GZCHK(hipStreamSynchronize(st));
+        memcpy(found.data(), G.h_found.p, probe.size() * 8);
+        G.st_.stretches += (int64_t)probe.size();
+    }
+    // 2. units: from every start that was found to the next one
+    struct Span {
+        int step;
+        uint64_t start, stop;
+    };
+    std::vector<std::vector<uint64_t>> starts((size_t)n);
+    for (int i = 0; i < n; ++i)
+        if (n_st[(size_t)i]) starts[(size_t)i].push_back(steps[i].bit_start);
+    for (size_t q = 0; q < probe.size(); ++q)
+        if (found[q] != ~0ull) starts[(size_t)probe_of[q].first].push_back(found[q]);
+    auto make_unit = [&](const qd_gz_step& s, uint64_t start, uint64_t stop, uint64_t tok_off, uint32_t cap) {
+        qd3::Unit u;
+        u.base = reinterpret_cast<const uint32_t*>(s.comp);
+        u.bit_start = start;
+        u.bit_stop = stop;
+        u.bit_end = 8 * s.comp_bytes;
+        u.tok_off = tok_off;
+        u.tok_cap = cap;
+        u.wend = (uint32_t)std::min<uint64_t>((s.comp_bytes + 3) / 4 + 80, 0xFFFFFFF0u);
+        return u;
+    };
+    auto cap_for = [&](const qd_gz_step& s, uint64_t start, uint64_t stop) {
+        const uint64_t bytes = ((stop == ~0ull ? 8 * s.comp_bytes : stop) - start + 7) / 8;
+        return (uint32_t)std::min<uint64_t>((4 * bytes + 4096 + 3) & ~(uint64_t)3, 1u << 28);
+    };
+    G.units_.clear();
+    std::vector<std::pair<int, uint32_t>> unit_of;  // unit -> (step, index among the step's starts)
+    uint64_t tok_total = 0;
+    for (int i = 0; i < n; ++i) {
+        std::vector<uint64_t>& v = starts[(size_t)i];
+        std::sort(v.begin(), v.end());
+        for (size_t k = 0; k < v.size(); ++k) {
+            const uint64_t stop = k + 1 < v.size() ? v[k + 1] : ~0ull;
+            const uint32_t cap = cap_for(steps[i], v[k], stop);
+            if (tok_total + cap >= 0xFFFF0000ull) {  // a launch's slots are indexed with 32 bits: what does not fit waits for the next step
+                v.resize(k);
+                break;
+            }
+            G.units_.push_back(make_unit(steps[i], v[k], stop, tok_total, cap));
+            unit_of.push_back({i, (uint32_t)k});
+            tok_total += cap;
+        }
+        // (the last unit of a shortened list runs to the end of the input like any last unit: it stops for good at a block boundary)
+        if (!v.empty() && !G.units_.empty() && unit_of.back().first == i) G.units_.back().bit_stop = ~0ull;
+    }
+    if (G.units_.empty()) return hipSuccess;
+    const size_t nu0 = G.units_.size();
+    // 3. tokens; a unit that ran past its stop position (no block starts there: the candidate was not one) runs again to the next
+    std::vector<qd3::Result> res(nu0);
+    std::vector<uint8_t> dropped(nu0, 0);  // units whose start was not proven
+    auto run_units = [&](const std::vector<uint32_t>& which) -> hipError_t {
+        const size_t m = which.size();
+        std::vector<qd3::Unit> batch(m);
+        for (size_t q = 0; q < m; ++q) batch[q] = G.units_[which[q]];
+        GZCHK(G.d_units.need(m * sizeof(qd3::Unit)));
+        GZCHK(G.d_res.need(m * sizeof(qd3::Result)));
+        GZCHK(G.d_lens.need(m * qd3::LENS_DW * 4));
+        GZCHK(G.d_tokens.need((size_t)tok_total * 2 + 64));
+        GZCHK(G.h_res.need(m * std::max(sizeof(qd3::Unit), sizeof(qd3::Result))));
+        memcpy(G.h_res.p, batch.data(), m * sizeof(qd3::Unit));
+        GZCHK(hipMemcpyAsync(G.d_units.p, G.h_res.p, m * sizeof(qd3::Unit), hipMemcpyHostToDevice, st));
+        GZCHK(launch_tokens<CfgA>(G.d_units.as<qd3::Unit>(), nullptr, (uint32_t)m, G.d_tokens.as<uint16_t>(), G.d_lens.as<uint32_t>(), G.d_res.as<qd3::Result>(), st));
+        GZCHK(hipStreamSynchronize(st));
+        GZCHK(hipMemcpyAsync(G.h_res.p, G.d_res.p, m * sizeof(qd3::Result), hipMemcpyDeviceToHost, st));
+        GZCHK(hipStreamSynchronize(st));
+        for (size_t q = 0; q < m; ++q) res[which[q]] = G.h_res.as<qd3::Result>()[q];
+        return hipSuccess;
+    };
+    {
+        std::vector<uint32_t> all(nu0);
+        for (size_t q = 0; q < nu0; ++q) all[q] = (uint32_t)q;
+        GZCHK(run_units(all));
+    }
+    G.st_.units += (int64_t)nu0;
+    for (int iter = 0; iter < 6; ++iter) {
+        std::vector<uint32_t> redo;
+        for (size_t q = 0; q < nu0; ++q) {
+            if (!dropped[q] && res[q].status == QD_INFLATE_TOKEN_SPACE && G.units_[q].tok_cap < 8 * ((cap_for(steps[unit_of[q].first], G.units_[q].bit_start, G.units_[q].bit_stop) - 4096) / 4)) {
+                // text that compresses beyond four tokens a byte (one symbol repeated under a Huffman-only coder): a code has at least
+                // one bit and a token at most two slots -- eight slots a byte always hold
+                qd3::Unit& u = G.units_[q];
+                const uint64_t cap8 = 2ull * (cap_for(steps[unit_of[q].first], u.bit_start, u.bit_stop) - 4096) + 4096;
+                if (cap8 < (1u << 30) && tok_total + cap8 < 0xFFFF0000ull) {
+                    u.tok_off = tok_total;
+                    u.tok_cap = (uint32_t)cap8;
+                    tok_total += cap8;
+                    redo.push_back((uint32_t)q);
+                }
+                continue;
+            }
+            if (dropped[q] || res[q].status != QD_INFLATE_CHAIN) continue;
+            // the next unit of the same step that is still alive was started from a false candidate: this one takes its stretch over
+            size_t nx = q + 1;
+            while (nx < nu0 && unit_of[nx].first == unit_of[q].first && dropped[nx]) ++nx;
+            if (nx >= nu0 || unit_of[nx].first != unit_of[q].first) break;  // (cannot happen: the last unit has no stop position)
+            dropped[nx] = 1;
+            qd3::Unit& u = G.units_[q];
+            u.bit_stop = G.units_[nx].bit_stop;
+            const uint32_t cap = cap_for(steps[unit_of[q].first], u.bit_start, u.bit_stop);
+            if (tok_total + cap >= 0xFFFF0000ull) {
+                steps[unit_of[q].first].failed = QD_INFLATE_TOKEN_SPACE;
+                continue;
+            }
+            u.tok_off = tok_total;
+            u.tok_cap = cap;
+            tok_total += cap;
+            redo.push_back((uint32_t)q);
+        }
+        if (redo.empty()) break;
+        G.st_.chain_retries += (int64_t)redo.size();
+        // (the token buffer may have to grow: the earlier units' tokens must survive -- a rare path: everything is decoded again)
+        if ((size_t)tok_total * 2 + 64 > G.d_tokens.cap) {
+            redo.clear();
+            for (size_t q = 0; q < nu0; ++q)
+                if (!dropped[q]) redo.push_back((uint32_t)q);
+        }
+        GZCHK(run_units(redo));
+    }
+    static const bool debug = getenv("QUADE_GZ_DEBUG") != nullptr;
+    if (debug) {
+        size_t n_found = 0;
+        for (uint64_t f : found) n_found += f != ~0ull;
+        fprintf(stderr, "[qd_gz] decode: %d steps, %zu stretches probed, %zu block starts found, %zu units\n", n, probe.size(), n_found, nu0);
+        for (size_t q = 0; q < nu0; ++q)
+            if (res[q].status || dropped[q] || q < 3 || q + 2 >= nu0)
+                fprintf(stderr, "[qd_gz]   unit %zu step %d%s: bits [%llu, stop %llu) end %llu -> status %u final %u slots %u text %u next %llu blk %llu/%u/%u\n", q, unit_of[q].first,
+                        dropped[q] ? " (dropped)" : "", (unsigned long long)G.units_[q].bit_start, (unsigned long long)G.units_[q].bit_stop, (unsigned long long)G.units_[q].bit_end,
+                        res[q].status, res[q].final_seen, res[q].n_slots, res[q].text_len, (unsigned long long)res[q].bit_next, (unsigned long long)res[q].blk_bit, res[q].blk_slots,
+                        res[q].blk_text);
+    }
+    // 4. the chain from every stream's true start
+    for (int i = 0; i < n; ++i) {
+        qd_gz_step& s = steps[i];
+        if (s.failed || !n_st[(size_t)i]) continue;
+        qd_gz_impl::Acc& A = G.acc_[(size_t)i];
+        uint64_t at = s.bit_start;
+        bool stop_here = false;
+        for (size_t q = 0; q < nu0 && !stop_here; ++q) {
+            if (unit_of[q].first != i || dropped[q]) continue;
+            const qd3::Unit& u = G.units_[q];
+            const qd3::Result& r = res[q];
+            if (u.bit_start != at) {  // (cannot happen: every unit stops where the next live one starts)
+                s.failed = QD_INFLATE_CHAIN;
+                break;
+            }
+            if (r.status == 0 && (r.final_seen || r.bit_next == u.bit_stop)) {
+                A.stretch.push_back((uint32_t)q);
+                A.use_slots.push_back(r.n_slots);
+                A.text.push_back(r.text_len);
+                s.text_len += r.text_len;
+                at = r.bit_next;
+                if (r.final_seen) {
+                    s.member_end = 1;
+                    stop_here = true;
+                }
+                continue;
+            }
+            if (u.bit_stop == ~0ull) {  // the step's last unit ran out of input (or of room) inside a block: up to the last block boundary it passed
+                if (r.blk_bit > u.bit_start) {
+                    A.stretch.push_back((uint32_t)q);
+                    A.use_slots.push_back(r.blk_slots);
+                    A.text.push_back(r.blk_text);
+                    s.text_len += r.blk_text;
+                    at = r.blk_bit;
+                    ++G.st_.partial_last;
+                } else if (at == s.bit_start && (s.at_end || r.status == QD_INFLATE_TABLE_SPACE || r.status == QD_INFLATE_TOKEN_SPACE)) {
+                    s.failed = (int32_t)(r.status ? r.status : QD_INFLATE_TRUNCATED);  // nothing decoded, and more input will not help
+                }
+                stop_here = true;
+                continue;
+            }
+            // a unit in the middle, from a proven start, that does not decode: the stream is damaged there (or beyond what a lane's tables hold)
+            if (at == s.bit_start) s.failed = (int32_t)r.status;
+            stop_here = true;  // (else: what was proven so far counts, the next step fails at the damage and says so)
+        }
+        s.bit_next = at;
+        if (debug)
+            fprintf(stderr, "[qd_gz]   step %d: start %llu -> next %llu, text %llu, member_end %d, failed %d, %zu stretches accepted\n", i, (unsigned long long)s.bit_start,
+                    (unsigned long long)at, (unsigned long long)s.text_len, s.member_end, s.failed, A.stretch.size());
+        if (s.failed) {
+            s.text_len = 0;
+            s.bit_next = s.bit_start;
+            s.member_end = 0;
+            A = qd_gz_impl::Acc();
+        }
+    }
+    return hipSuccess;
+}
+
+hipError_t qd_gz::resolve(qd_gz_step* steps, int n, uint8_t* const* out, hipStream_t st) {
+    qd_gz_impl& G = *p_;
+    const uint64_t UNIT_TEXT = std::max<uint64_t>(unit_text, 1024);
+    // units of ~1 MB of text: runs of accepted stretches; chains: a stream's units in order
+    G.gzunits_.clear();
+    G.unit_step_.clear();
+    G.ranges_.clear();
+    std::vector<GzChain> chains;
+    std::vector<int> chain_step;
+    std::vector<uint32_t> use((size_t)G.units_.size(), 0);
+    std::vector<uint64_t> unit_out_off;
+    std::vector<uint32_t> unit_floor;
+    std::vector<GzFixTile> tiles;
+    std::vector<uint32_t> first_range;  // unit -> its first CRC range (one more entry behind the last unit)
+    uint64_t sym_total = 0;
+    for (int i = 0; i < n; ++i) {
+        const qd_gz_impl::Acc& A = G.acc_[(size_t)i];
+        if (steps[i].failed || A.stretch.empty() || steps[i].text_len == 0) continue;
+        GzChain c;
+        c.first_unit = (uint32_t)G.gzunits_.size();
+        c.valid = steps[i].carried_valid;
+        c.pad = 0;
+        c.carried = steps[i].carried;
+        uint64_t text_before = 0;
+        size_t k = 0;
+        while (k < A.stretch.size()) {
+            GzUnit u;
+            u.first = A.stretch[k];
+            u.n = 0;
+            u.stream = (uint32_t)chains.size();
+            u.pad = 0;
+            u.sym_off = sym_total;
+            u.text_len = 0;
+            // (stretches of a unit must be neighbours in the unit table: a dropped candidate between two of them ends the unit)
+            while (k < A.stretch.size() && A.stretch[k] == u.first + u.n && (u.n == 0 || u.text_len < UNIT_TEXT) && u.text_len + A.text[k] < 0xF0000000ull) {
+                use[A.stretch[k]] = A.use_slots[k];
+                u.text_len += A.text[k];
+                ++u.n;
+                ++k;
+            }
+            if (u.text_len == 0 && k < A.stretch.size()) continue;  // (stretches without text: nothing to resolve)
+            const uint64_t have = std::min<uint64_t>(GZ_WIN, (uint64_t)steps[i].carried_valid + text_before);
+            unit_floor.push_back((uint32_t)(GZ_WIN - have));
+            unit_out_off.push_back(text_before);
+            for (uint64_t o = 0; o < u.text_len; o += GZ_FIX_TILE) tiles.push_back(GzFixTile{(uint32_t)G.gzunits_.size(), (uint32_t)o});
+            first_range.push_back((uint32_t)G.ranges_.size());
+            for (uint64_t o = 0; o < u.text_len; o += 65536) G.ranges_.push_back(qd_crc_range{text_before + o, (uint32_t)std::min<uint64_t>(65536, u.text_len - o), 0});  // (the CRC kernel's ranges: <= 64 KiB)
+            G.gzunits_.push_back(u);
+            G.unit_step_.push_back((uint32_t)i);
+            sym_total += u.text_len;
+            text_before += u.text_len;
+        }
+        c.n_units = (uint32_t)G.gzunits_.size() - c.first_unit;
+        chains.push_back(c);
+        chain_step.push_back(i);
+        steps[i].carried_valid = (uint32_t)std::min<uint64_t>(GZ_WIN, (uint64_t)steps[i].carried_valid + steps[i].text_len);
+    }
+    const size_t nr = G.gzunits_.size();
+    G.n_runits_ = nr;
+    G.n_chains_ = chains.size();
+    if (!nr) return hipSuccess;
+    // device tables
+    const size_t nu = G.units_.size();
+    GZCHK(G.d_units.need(nu * sizeof(qd3::Unit)));
+    GZCHK(G.d_use.need(nu * 4));
+    GZCHK(G.d_gzunits.need(nr * sizeof(GzUnit)));
+    GZCHK(G.d_chains.need(chains.size() * sizeof(GzChain)));
+    GZCHK(G.d_tiles.need(tiles.size() * sizeof(GzFixTile)));
+    GZCHK(G.d_sym.need(sym_total * 2 + 64));
+    GZCHK(G.d_wout.need(nr * (size_t)GZ_WIN * 2));
+    GZCHK(G.d_winin.need(nr * (size_t)GZ_WIN));
+    GZCHK(G.d_ustat.need(nr * 4 * 2));
+    GZCHK(G.d_cstat.need(chains.size() * 4));
+    GZCHK(G.d_outptr.need(chains.size() * sizeof(uint8_t*)));
+    GZCHK(G.d_uoff.need(nr * 8));
+    GZCHK(G.d_floor.need(nr * 4));
+    first_range.push_back((uint32_t)G.ranges_.size());
+    const size_t n_ranges = G.ranges_.size();
+    GZCHK(G.d_ranges.need(n_ranges * sizeof(qd_crc_range) + (nr + 1) * 4 + 256));
+    GZCHK(G.d_crc.need((nr + n_ranges) * 4));
+    std::vector<uint8_t*> outp(chains.size());
+    for (size_t c = 0; c < chains.size(); ++c) outp[c] = out[chain_step[c]];
+    size_t up = 0;
+    auto stage = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        memcpy(G.h_up.p + up, src, bytes);
+        const hipError_t e = hipMemcpyAsync(dst, G.h_up.p + up, bytes, hipMemcpyHostToDevice, st);
+        up += (bytes + 255) & ~(size_t)255;
+        return e;
+    };
+    GZCHK(hipStreamSynchronize(st));  // (the staging buffer below may still be read by the previous step's copies)
+    GZCHK(G.h_up.need(nu * (sizeof(qd3::Unit) + 4) + nr * (sizeof(GzUnit) + 8 + 4 + 4) + n_ranges * sizeof(qd_crc_range) + chains.size() * (sizeof(GzChain) + 8) +
+                      tiles.size() * sizeof(GzFixTile) + 20 * 256));
+    GZCHK(stage(G.d_units.p, G.units_.data(), nu * sizeof(qd3::Unit)));
+    GZCHK(stage(G.d_use.p, use.data(), nu * 4));
+    GZCHK(stage(G.d_gzunits.p, G.gzunits_.data(), nr * sizeof(GzUnit)));
+    GZCHK(stage(G.d_chains.p, chains.data(), chains.size() * sizeof(GzChain)));
+    GZCHK(stage(G.d_tiles.p, tiles.data(), tiles.size() * sizeof(GzFixTile)));
+    GZCHK(stage(G.d_outptr.p, outp.data(), chains.size() * sizeof(uint8_t*)));
+    GZCHK(stage(G.d_uoff.p, unit_out_off.data(), nr * 8));
+    GZCHK(stage(G.d_floor.p, unit_floor.data(), nr * 4));
+    GZCHK(hipMemsetAsync(G.d_ustat.p, 0, nr * 4 * 2, st));
+    constexpr int RNT = 512, RQ = 2048;
+    const size_t lds = sizeof(GzLds<RNT, RQ>);
+    GZCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gz_resolve<RNT, RQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((gz_resolve<RNT, RQ>), dim3((uint32_t)nr), dim3(RNT), lds, st, G.d_gzunits.as<GzUnit>(), (uint32_t)nr, G.d_units.as<qd3::Unit>(), G.d_res.as<qd3::Result>(),
+                       G.d_use.as<uint32_t>(), G.d_tokens.as<uint16_t>(), G.d_sym.as<uint16_t>(), G.d_wout.as<uint16_t>(), G.d_ustat.as<int32_t>());
+    GZCHK(hipGetLastError());
+    hipLaunchKernelGGL(gz_windows, dim3((uint32_t)chains.size()), dim3(1024), 0, st, G.d_chains.as<GzChain>(), G.d_gzunits.as<GzUnit>(), G.d_wout.as<uint16_t>(), G.d_winin.p,
+                       G.d_cstat.as<int32_t>());
+    GZCHK(hipGetLastError());
+    hipLaunchKernelGGL(gz_fixup, dim3((uint32_t)tiles.size()), dim3(256), 0, st, G.d_tiles.as<GzFixTile>(), (uint32_t)tiles.size(), G.d_gzunits.as<GzUnit>(),
+                       G.d_outptr.as<uint8_t*>(), G.d_uoff.as<uint64_t>(), G.d_sym.as<uint16_t>(), G.d_winin.p, G.d_floor.as<uint32_t>(), G.d_ustat.as<int32_t>() + nr);
+    GZCHK(hipGetLastError());
+    // CRC-32 of every unit's text: ranges of 64 KiB (a stream's units lie in its own text buffer: one launch per stream), combined per unit
+    {
+        qd_crc_range* d_rg = G.d_ranges.as<qd_crc_range>();
+        uint32_t* d_first = reinterpret_cast<uint32_t*>(G.d_ranges.p + ((n_ranges * sizeof(qd_crc_range) + 255) & ~(size_t)255));
+        uint32_t* d_sub = G.d_crc.as<uint32_t>() + nr;
+        GZCHK(stage(d_rg, G.ranges_.data(), n_ranges * sizeof(qd_crc_range)));
+        GZCHK(stage(d_first, first_range.data(), (nr + 1) * 4));
+        for (size_t c = 0; c < chains.size(); ++c) {
+            const uint32_t r0 = first_range[chains[c].first_unit], r1 = first_range[chains[c].first_unit + chains[c].n_units];
+            GZCHK(qd_text_crc32(outp[c], d_rg + r0, r1 - r0, d_sub + r0, st));
+        }
+        GZCHK(qd_text_crc32_combine(d_rg, d_sub, d_first, (uint32_t)nr, G.d_crc.as<uint32_t>(), 1, st));
+    }
+    GZCHK(G.h_back.need(nr * 12 + chains.size() * 4 + 64));
+    GZCHK(hipMemcpyAsync(G.h_back.p, G.d_ustat.p, nr * 8, hipMemcpyDeviceToHost, st));
+    GZCHK(hipMemcpyAsync(G.h_back.p + nr * 8, G.d_crc.p, nr * 4, hipMemcpyDeviceToHost, st));
+    GZCHK(hipMemcpyAsync(G.h_back.p + nr * 12, G.d_cstat.p, chains.size() * 4, hipMemcpyDeviceToHost, st));
+    // (chain c belongs to step chain_step[c]: finish() needs it)
+    G.unit_step_.push_back(0xFFFFFFFFu);
+    for (size_t c = 0; c < chains.size(); ++c) G.unit_step_.push_back((uint32_t)chain_step[c]);
+    return hipSuccess;
+}
+
+uint32_t qd_crc32_combine_host(uint32_t crc1, uint32_t crc2, uint64_t len2);  // quade_io.cpp (zlib's)
+
+hipError_t qd_gz::finish(qd_gz_step* steps, int n) {
+    qd_gz_impl& G = *p_;
+    const size_t nr = G.n_runits_;
+    if (!nr) return hipSuccess;
+    const int32_t* ustat = G.h_back.as<int32_t>();
+    const uint32_t* crc = reinterpret_cast<const uint32_t*>(G.h_back.p + nr * 8);
+    const int32_t* cstat = reinterpret_cast<const int32_t*>(G.h_back.p + nr * 12);
+    std::vector<uint8_t> first((size_t)n, 1);
+    for (size_t u = 0; u < nr; ++u) {
+        const uint32_t i = G.unit_step_[u];
+        if (i >= (uint32_t)n) continue;
+        if (ustat[u] || ustat[nr + u]) steps[i].failed = ustat[u] ? ustat[u] : ustat[nr + u];
+        steps[i].crc32 = first[i] ? crc[u] : qd_crc32_combine_host(steps[i].crc32, crc[u], G.gzunits_[u].text_len);
+        first[i] = 0;
+    }
+    for (size_t c = 0; c < G.n_chains_; ++c) {
+        const uint32_t i = G.unit_step_[nr + 1 + c];
+        if (i < (uint32_t)n && cstat[c]) steps[i].failed = cstat[c];
+    }
+    if (getenv("QUADE_GZ_DEBUG")) {
+        for (size_t u = 0; u < nr; ++u)
+            if (ustat[u] || ustat[nr + u] || u < 2) fprintf(stderr, "[qd_gz] finish: unit %zu (step %u): resolve status %d, fixup status %d, crc %08x, text %llu\n", u, G.unit_step_[u], ustat[u],
+                                                            ustat[nr + u], crc[u], (unsigned long long)G.gzunits_[u].text_len);
+        for (size_t c = 0; c < G.n_chains_; ++c) fprintf(stderr, "[qd_gz] finish: chain %zu status %d\n", c, cstat[c]);
+    }
+    return hipSuccess;
 }

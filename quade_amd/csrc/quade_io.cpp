@@ -2348,3 +2348,6 @@ extern "C" int qd_write_gzip_file(const char* path, const uint8_t* data, int64_t
     if (close(fd) != 0) ok = false;
     return ok ? QD_OK : QD_ERR_FORMAT;
 }
+
+// zlib's combination of two CRC-32s (the third inflater's host side: a gzip member's CRC from its units')
+uint32_t qd_crc32_combine_host(uint32_t crc1, uint32_t crc2, uint64_t len2) { return (uint32_t)crc32_combine((uLong)crc1, (uLong)crc2, (z_off_t)len2); }

@@ -44,6 +44,8 @@
 #include "quade_io_internal.h"
 #include "quade_text.h"
 
+uint32_t qd_crc32_combine_host(uint32_t crc1, uint32_t crc2, uint64_t len2);  // quade_io.cpp (zlib's)
+
 namespace {
 
 constexpr size_t SEG_BYTES = 16u << 20;  // bytes per upload (compressed blocks or text)
@@ -177,7 +179,7 @@ class StagePool {
 };
 
 // ---- feeders: file -> page-locked buffer -> device ring ----------------------------------------------------------------------
-enum { SEG_BGZF, SEG_TEXT, SEG_END, SEG_ERROR };
+enum { SEG_BGZF, SEG_TEXT, SEG_END, SEG_ERROR, SEG_GZIP };
 struct Segment {
     int kind = SEG_END;
     int chunk = 0;
@@ -200,7 +202,7 @@ struct FileSpec {
 
 class Feeder {
   public:
-    Feeder(int device, std::vector<FileSpec> files) : device_(device), files_(std::move(files)) {}
+    Feeder(int device, std::vector<FileSpec> files, bool device_gunzip = false) : device_(device), files_(std::move(files)), device_gunzip_(device_gunzip) {}
     ~Feeder() { stop(); }
     hipError_t start() {
         hipError_t e = hipSetDevice(device_);
@@ -465,13 +467,49 @@ class Feeder {
                 }
                 if (range_end >= 0 && read_pos >= range_end) eof = true;
             }
-            if (first && !qdio::bgzf_block_size(pin, fill)) {  // ordinary gzip: the host's parallel inflater takes the file
+            if (first && !qdio::bgzf_block_size(pin, fill)) {  // ordinary gzip
                 if (ranged) {
                     fail(c, path + ": no BGZF block at the start of the byte range");
                     close(fd);
                     return;
                 }
-                switch_at = 0;
+                if (device_gunzip_ && fill >= 18 && pin[0] == 0x1f && pin[1] == 0x8b && pin[2] == 8) {
+                    // the device inflates it (quade_inflate3.hip): the file's bytes go up as they are, upload after upload
+                    int64_t at = 0;
+                    for (;;) {
+                        Segment seg;
+                        seg.kind = SEG_GZIP;
+                        seg.chunk = c;
+                        seg.file_off = at;
+                        if (!upload(seg, pin, fill)) break;
+                        at += (int64_t)fill;
+                        if (eof || skip_.load() > c || stopping()) break;
+                        pin = take_pin();
+                        if (!pin) {
+                            fail(c, "page-locked memory: allocation or upload failed");
+                            break;
+                        }
+                        fill = 0;
+                        while (fill < SEG_BYTES) {
+                            const ssize_t r = pread(fd, pin + fill, SEG_BYTES - fill, (off_t)(at + (int64_t)fill));
+                            if (r < 0 && errno == EINTR) continue;
+                            if (r < 0) {
+                                fail(c, path + ": read error");
+                                close(fd);
+                                return;
+                            }
+                            if (r == 0) {
+                                eof = true;
+                                break;
+                            }
+                            fill += (size_t)r;
+                        }
+                        if (fill == 0) break;
+                    }
+                    close(fd);
+                    return;
+                }
+                switch_at = 0;  // ... or the host's parallel inflater takes the file
                 break;
             }
             first = false;
@@ -533,6 +571,7 @@ class Feeder {
 
     int device_;
     std::vector<FileSpec> files_;
+    bool device_gunzip_ = false;
     hipStream_t up_ = nullptr;
     uint8_t* ring_ = nullptr;
     hipEvent_t ready_[RING_SLOTS] = {nullptr}, consumed_[RING_SLOTS] = {nullptr};
@@ -581,6 +620,7 @@ struct qd_pipe_stats_impl {
     int64_t text_in_bytes = 0, text_out_bytes = 0, gzip_bytes = 0, rescans = 0;
     // where the driver's and the collector's wall time goes (seconds)
     double wait_input = 0, wait_sync = 0, wait_out_set = 0, alloc = 0, collector_wait = 0, download = 0, append = 0, run = 0;
+    int64_t gzip_steps = 0, gzip_units = 0, gzip_members = 0, gzip_fallbacks = 0;
 };
 
 struct qd_pipe {
@@ -616,6 +656,10 @@ struct qd_pipe {
         std::vector<int> slots;
         uint32_t first, n, block_base;
     };
+    // Option "device_gunzip" (default 1): ordinary gzip files are inflated on the device as well (qd_gz, quade_inflate3.hip)
+    int device_gunzip = 1;
+    qd_gz* gz = nullptr;
+    int64_t gz_units0 = 0;
     std::vector<qd_inflate3_job> q3_jobs;   // (out: the offset inside the window's text until the launch -- the buffer may still grow)
     std::vector<Queued3> q3_parts;
     DevBuf jobs3, status3, scratch3;
@@ -646,6 +690,29 @@ struct qd_pipe {
         bool in_flight[2] = {false, false};
         std::string path;
         qd_scan_result res{};
+        // an ordinary gzip file on its way through the device's gzip kernels: the file's bytes [comp_off, comp_off + comp_len) lie in
+        // comp[ccur]; the next block header (or, need_header: the next member's header) is known exactly
+        struct Gz {
+            bool active = false;
+            DevBuf comp[2];
+            int ccur = 0;
+            uint64_t comp_off = 0, comp_len = 0;
+            bool file_done = false;   // the feeder has delivered the file's last byte
+            bool need_header = true;
+            uint64_t hdr_off = 0;     // file offset of the next member's header
+            uint64_t bit = 0;         // file position (bits) of the next block header
+            DevBuf carried;           // the 32 KiB of text in front of it
+            uint32_t carried_valid = 0;
+            uint32_t member_crc = 0;
+            uint64_t member_text = 0, member_off = 0;
+            double ratio = 3.5;       // text per compressed byte, learned
+            int fd = -1;
+            int64_t file_size = 0;
+            uint64_t stepped_end = ~0ull;  // comp_off + comp_len when the last step ran (nothing new since: no step)
+            bool stepped_done = false;
+            qd_reader* host = nullptr;  // the host's inflater took the stream over (the device gave it up)
+            uint64_t host_skip = 0;     // text of the current member that was delivered already
+        } gz;
     } win[4];
     int n_streams = 4;  // R1, R2, I1 [, I2]
     DevBuf d_res;       // qd_scan_result[4] + pack's short counter
@@ -1065,9 +1132,278 @@ int launch_inflate(qd_pipe* p, Feeder& f, Window& w, int stream_index) {
     return QD_OK;
 }
 
+// ---- ordinary gzip files through the device's gzip kernels (qd_gz) --------------------------------------------------------------------
+void gz_close(Window& w) {
+    Window::Gz& g = w.gz;
+    if (g.fd >= 0) close(g.fd);
+    if (g.host) qdio::raw_close(g.host);
+    g.fd = -1;
+    g.host = nullptr;
+    g.active = false;
+    g.comp_off = g.comp_len = 0;
+    g.file_done = false;
+    g.need_header = true;
+    g.hdr_off = g.bit = 0;
+    g.carried_valid = 0;
+    g.member_crc = 0;
+    g.member_text = g.member_off = g.host_skip = 0;
+    g.stepped_end = ~0ull;
+    g.stepped_done = false;
+}
+
+// bytes of a gzip member's header at p[0 .. n) (RFC 1952); 0: none, or it does not end inside n
+size_t gz_header_bytes(const uint8_t* h, size_t n) {
+    if (n < 10 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || (h[3] & 0xe0)) return 0;
+    const int flg = h[3];
+    size_t at = 10;
+    if (flg & 4) {
+        if (at + 2 > n) return 0;
+        at += 2 + (h[at] | ((size_t)h[at + 1] << 8));
+    }
+    for (int bit : {8, 16})
+        if (flg & bit) {
+            while (at < n && h[at]) ++at;
+            ++at;
+        }
+    if (flg & 2) at += 2;
+    return at <= n ? at : 0;
+}
+
+// an upload of the file's bytes joins the stream's compressed buffer
+int gz_append(qd_pipe* p, Feeder& f, Window& w, Segment& s) {
+    Window::Gz& g = w.gz;
+    if (!g.active) {
+        gz_close(w);
+        g.active = true;
+        g.fd = open(w.path.c_str(), O_RDONLY | O_CLOEXEC);
+        struct stat sb;
+        if (g.fd < 0 || fstat(g.fd, &sb) != 0) return pfail(p, QD_ERR_FORMAT, w.path + ": " + strerror(errno));
+        g.file_size = (int64_t)sb.st_size;
+        PCHK(p, g.carried.need(32768, 0, p->cs));
+        if (!p->gz) {
+            p->gz = new qd_gz();
+            p->gz_units0 = 0;
+        }
+    }
+    if ((uint64_t)s.file_off != g.comp_off + g.comp_len) return pfail(p, QD_ERR_STATE, w.path + ": uploads out of order");
+    PCHK(p, g.comp[g.ccur].need((size_t)g.comp_len + s.bytes + 8192, (size_t)g.comp_len, p->cs));
+    PCHK(p, hipStreamWaitEvent(p->cs, f.ready(s.slot), 0));
+    PCHK(p, hipMemcpyAsync(g.comp[g.ccur].p + g.comp_len, f.ring() + (size_t)s.slot * SEG_BYTES, s.bytes, hipMemcpyDeviceToDevice, p->cs));
+    PCHK(p, f.consumed(s.slot, p->cs));
+    g.comp_len += s.bytes;
+    return QD_OK;
+}
+
+// The device gave the stream up (damaged, or beyond what it decodes): the host's inflater reads the current member again from its
+// start, the text that was delivered already is skipped, and what follows reaches the window as text.  Counted (gzip_fallbacks).
+int gz_fallback(qd_pipe* p, Feeder& f, Window& w, int chunk) {
+    Window::Gz& g = w.gz;
+    ++p->st.gzip_fallbacks;
+    while (!g.file_done) {  // what the feeder still uploads of this file is dropped
+        Segment s = f.pop();
+        if (s.kind == SEG_ERROR) return pfail(p, QD_ERR_FORMAT, s.err);
+        if (s.kind == SEG_END) {
+            if (s.chunk == chunk) g.file_done = true;
+            continue;
+        }
+        PCHK(p, f.consumed(s.slot, p->cs));
+    }
+    std::string err;
+    g.host = qdio::raw_open(w.path.c_str(), (int64_t)g.member_off, &err);
+    if (!g.host) return pfail(p, QD_ERR_FORMAT, err);
+    g.host_skip = g.member_text;
+    g.comp_len = 0;
+    return QD_OK;
+}
+
+// text from the host's inflater until the window holds `want` bytes or the file ends
+int gz_host_fill(qd_pipe* p, Window& w, size_t want) {
+    Window::Gz& g = w.gz;
+    while (!w.eof && (size_t)w.len < want) {
+        const uint8_t* ptr = nullptr;
+        size_t len = 0;
+        std::string err;
+        const int rc = qdio::raw_next(g.host, &ptr, &len, &err);
+        if (rc < 0) return pfail(p, QD_ERR_FORMAT, err);
+        if (rc == 0) {
+            w.eof = true;
+            w.dirty = true;
+            break;
+        }
+        if (g.host_skip) {
+            const size_t drop = (size_t)std::min<uint64_t>(g.host_skip, len);
+            g.host_skip -= drop;
+            ptr += drop;
+            len -= drop;
+        }
+        for (size_t at = 0; at < len;) {
+            const size_t n = std::min<size_t>(len - at, (size_t)256 << 20);
+            const int r = window_room(p, w, n);
+            if (r != QD_OK) return r;
+            PCHK(p, hipStreamSynchronize(p->cs));
+            PCHK(p, hipMemcpy(w.buf[w.cur].p + w.len, ptr + at, n, hipMemcpyHostToDevice));
+            w.len += (uint32_t)n;
+            at += n;
+            w.dirty = true;
+            ++p->st.text_segments;
+            p->st.text_in_bytes += (int64_t)n;
+        }
+    }
+    return QD_OK;
+}
+
+// One inflate step of every gzip stream that has compressed bytes waiting: probe + tokens for all of them in one launch each, then
+// the text appended to the windows, the members' trailers checked.  `feeders`: for a stream that falls back to the host.
+int gz_steps(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chunk) {
+    std::vector<qd_gz_step> steps;
+    std::vector<int> who;
+    std::vector<uint64_t> byte0s;
+    for (int s = 0; s < p->n_streams; ++s) {
+        Window& w = p->win[s];
+        Window::Gz& g = w.gz;
+        if (!g.active || g.host || w.eof) continue;
+        if (g.need_header) {  // the next member's header (from the file: the compressed bytes live on the device)
+            if ((int64_t)g.hdr_off >= g.file_size) {
+                if (g.file_done) {
+                    w.eof = true;
+                    w.dirty = true;
+                }
+                continue;
+            }
+            uint8_t h[65536];
+            const ssize_t got = pread(g.fd, h, sizeof h, (off_t)g.hdr_off);
+            const size_t hb = got > 0 ? gz_header_bytes(h, (size_t)got) : 0;
+            if (!hb) {
+                bool zeros = got > 0;
+                for (ssize_t k = 0; k < got && zeros; ++k) zeros = h[k] == 0;
+                if (zeros && (int64_t)g.hdr_off + got >= g.file_size) {  // (padding behind the last member)
+                    g.hdr_off = (uint64_t)g.file_size;
+                    w.eof = g.file_done;
+                    w.dirty = true;
+                    continue;
+                }
+                g.member_off = g.hdr_off;
+                g.member_text = 0;
+                const int rc = gz_fallback(p, *feeders[(size_t)s], w, chunk);  // (the host's reader says what is wrong with it)
+                if (rc != QD_OK) return rc;
+                continue;
+            }
+            g.member_off = g.hdr_off;
+            g.member_text = 0;
+            g.member_crc = 0;
+            g.carried_valid = 0;
+            g.bit = 8 * (g.hdr_off + hb);
+            g.need_header = false;
+        }
+        if (g.bit >= 8 * (g.comp_off + g.comp_len)) continue;  // nothing of it on the device yet
+        if (g.stepped_end == g.comp_off + g.comp_len && g.stepped_done == g.file_done) continue;  // nothing new since the last step
+        g.stepped_end = g.comp_off + g.comp_len;
+        g.stepped_done = g.file_done;
+        qd_gz_step st{};
+        const uint64_t byte0 = ((g.bit >> 3) - g.comp_off) & ~(uint64_t)15;
+        st.comp = g.comp[g.ccur].p + byte0;
+        st.comp_bytes = g.comp_len - byte0;
+        st.bit_start = g.bit - 8 * (g.comp_off + byte0);
+        st.at_end = g.file_done ? 1 : 0;
+        st.carried = g.carried.p;
+        st.carried_valid = g.carried_valid;
+        steps.push_back(st);
+        who.push_back(s);
+        byte0s.push_back(byte0);
+    }
+    if (steps.empty()) return QD_OK;
+    const int n = (int)steps.size();
+    {
+        Tick tick(p->st.wait_sync);
+        PCHK(p, p->gz->decode(steps.data(), n, p->cs));
+    }
+    p->st.gzip_steps += n;
+    std::vector<uint8_t*> out((size_t)n, nullptr);
+    for (int i = 0; i < n; ++i) {
+        Window& w = p->win[who[(size_t)i]];
+        if (steps[(size_t)i].failed) continue;
+        if (steps[(size_t)i].text_len > 0xF0000000ull) return pfail(p, QD_ERR_UNSUPPORTED, w.path + ": more text in one step than a window's 32-bit offsets reach");
+        const int rc = window_room(p, w, (size_t)steps[(size_t)i].text_len);
+        if (rc != QD_OK) return rc;
+        out[(size_t)i] = w.buf[w.cur].p + w.len;
+    }
+    PCHK(p, p->gz->resolve(steps.data(), n, out.data(), p->cs));
+    {
+        const int rc = sync_compute(p);
+        if (rc != QD_OK) return rc;
+    }
+    PCHK(p, p->gz->finish(steps.data(), n));
+    for (int i = 0; i < n; ++i) {
+        const int s = who[(size_t)i];
+        Window& w = p->win[s];
+        Window::Gz& g = w.gz;
+        qd_gz_step& st = steps[(size_t)i];
+        if (st.failed) {
+            const int rc = gz_fallback(p, *feeders[(size_t)s], w, chunk);
+            if (rc != QD_OK) return rc;
+            continue;
+        }
+        if (st.text_len) {
+            g.member_crc = g.member_text ? qd_crc32_combine_host(g.member_crc, st.crc32, st.text_len) : st.crc32;
+            g.member_text += st.text_len;
+            w.len += (uint32_t)st.text_len;
+            w.dirty = true;
+            p->st.text_in_bytes += (int64_t)st.text_len;
+            const uint64_t used = (st.bit_next - st.bit_start + 7) / 8;
+            if (used) g.ratio = 0.5 * g.ratio + 0.5 * std::min(64.0, std::max(1.0, (double)st.text_len / (double)used));
+        }
+        g.carried_valid = st.carried_valid;
+        const bool progress = st.bit_next != st.bit_start || st.member_end;
+        g.bit = 8 * (g.comp_off + byte0s[(size_t)i]) + st.bit_next;
+        if (st.member_end) {  // the trailer: CRC-32 and ISIZE of the member's text
+            const uint64_t tr = (g.bit + 7) >> 3;
+            uint8_t t[8];
+            if (pread(g.fd, t, 8, (off_t)tr) != 8) {
+                const int rc = gz_fallback(p, *feeders[(size_t)s], w, chunk);  // (truncated: the host's reader reports it)
+                if (rc != QD_OK) return rc;
+                continue;
+            }
+            const uint32_t want_crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+            const uint32_t want_len = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+            if (want_crc != (g.member_text ? g.member_crc : 0u) || want_len != (uint32_t)g.member_text)
+                return pfail(p, QD_ERR_FORMAT, w.path + ": CRC-32 or length of a gzip member does not match its text");
+            ++p->st.gzip_members;
+            g.need_header = true;
+            g.hdr_off = tr + 8;
+            g.bit = 8 * g.hdr_off;
+        } else if (!progress && g.file_done) {
+            const int rc = gz_fallback(p, *feeders[(size_t)s], w, chunk);  // the stream ends inside a block: the host's reader reports it
+            if (rc != QD_OK) return rc;
+            continue;
+        }
+        // what lies in front of the next block header has been used: the rest moves to the front of the other buffer
+        const uint64_t keep_from = std::min<uint64_t>(((g.bit >> 3) - g.comp_off) & ~(uint64_t)15, g.comp_len);
+        if (keep_from) {
+            const uint64_t left = g.comp_len - keep_from;
+            const int nx = g.ccur ^ 1;
+            PCHK(p, g.comp[nx].need((size_t)left + 8192, 0, p->cs));
+            if (left) PCHK(p, hipMemcpyAsync(g.comp[nx].p, g.comp[g.ccur].p + keep_from, (size_t)left, hipMemcpyDeviceToDevice, p->cs));
+            g.ccur = nx;
+            g.comp_off += keep_from;
+            g.comp_len = left;
+        }
+        if (g.file_done && g.need_header && (int64_t)g.hdr_off >= g.file_size) {
+            w.eof = true;
+            w.dirty = true;
+        }
+    }
+    return QD_OK;
+}
+
 // more input for one window until it holds `want` bytes of text or its stream ends
 int top_up(qd_pipe* p, Feeder& f, Window& w, int stream_index, int chunk, size_t want) {
+    if (w.gz.active && w.gz.host) return gz_host_fill(p, w, want);
     while (!w.eof && (size_t)w.len + w.pending_text < want) {
+        if (w.gz.active) {
+            // (an estimate of the text the compressed bytes on the device stand for: gz_steps will tell)
+            const uint64_t held = 8 * (w.gz.comp_off + w.gz.comp_len) > w.gz.bit ? w.gz.comp_off + w.gz.comp_len - (w.gz.bit >> 3) : 0;
+            if (w.gz.file_done || (double)w.len + (double)held * w.gz.ratio >= (double)want) break;
+        }
         Segment s;
         {
             Tick tick(p->st.wait_input);
@@ -1076,12 +1412,21 @@ int top_up(qd_pipe* p, Feeder& f, Window& w, int stream_index, int chunk, size_t
         if (s.kind == SEG_ERROR) return pfail(p, QD_ERR_FORMAT, s.err);
         if (s.kind == SEG_END) {
             if (s.chunk != chunk) return pfail(p, QD_ERR_STATE, "feeder out of step with the driver");
+            if (w.gz.active) {  // (its text is still to be made: gz_steps says when the stream has ended)
+                w.gz.file_done = true;
+                break;
+            }
             w.eof = true;
             w.dirty = true;
             break;
         }
         if (s.chunk != chunk) {  // left over from a chunk that ended early
             PCHK(p, f.consumed(s.slot, p->cs));
+            continue;
+        }
+        if (s.kind == SEG_GZIP) {
+            const int rc = gz_append(p, f, w, s);
+            if (rc != QD_OK) return rc;
             continue;
         }
         if (s.kind == SEG_BGZF) {
@@ -1112,6 +1457,7 @@ int drain_chunk(qd_pipe* p, Feeder& f, Window& w, int chunk) {
     for (Segment& s : w.pending) PCHK(p, f.consumed(s.slot, p->cs));
     w.pending.clear();
     w.pending_text = 0;
+    if (w.gz.active && w.gz.file_done) w.eof = true;  // (the feeder has closed this chunk's file already)
     while (!w.eof) {
         Segment s = f.pop();
         if (s.kind == SEG_ERROR) continue;  // (of a stream nobody reads any more)
@@ -1590,6 +1936,7 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
         w.runs.clear();
         w.pending.clear();
         w.pending_text = 0;
+        gz_close(w);
     }
     std::vector<size_t> want(ns, 1);  // first round: one upload, to learn the stream's bytes per record
     for (;;) {
@@ -1599,7 +1946,8 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
             if (rc != QD_OK) return rc;
         }
         {
-            const int rc = flush_inflate3(p);  // (the third inflater: the blocks of every stream's uploads in one launch)
+            int rc = flush_inflate3(p);  // (the third inflater: the blocks of every stream's uploads in one launch)
+            if (rc == QD_OK) rc = gz_steps(p, feeders, chunk);  // ... and a step of every ordinary gzip stream
             if (rc != QD_OK) return rc;
         }
         // (a shared chunk: the text in front of this rank's first record goes before anything is scanned)
@@ -1707,6 +2055,9 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
             Window& w = p->win[s];
             if (w.res.n_kept >= B || w.eof) continue;
             if (w.res.n_kept > 0 && (size_t)w.len > WINDOW_MAX / 2) continue;  // a full window: a smaller batch rather than more text
+            // (... and a batch that is most of B rather than another round: a top-up is an inflate launch of its own, which takes as
+            //  long for a few hundred blocks as for ten thousand -- a lane decodes its block's symbols one after the other)
+            if (p->inflate_form == 3 && (uint64_t)w.res.n_kept * 10 >= (uint64_t)B * 8) continue;
             const double per = w.avg > 0 ? w.avg : 256.0;
             const size_t more = (size_t)((double)(B - w.res.n_kept) * per * 1.03) + 4096;
             want[s] = std::min<size_t>(std::max<size_t>((size_t)w.len + more, (size_t)w.len + 1), WINDOW_MAX * 3 / 4);
@@ -1940,6 +2291,7 @@ int qd_pipe_create(qd_ctx* ctx, qd_pipe** out) {
     p->plan = P;
     p->n_streams = 2 + L.n_streams;
     if (const char* e = getenv("QUADE_PIPE_INFLATE_FORM")) p->inflate_form = atoi(e) == 2 ? 2 : 3;  // (measurement: A/B of the inflaters inside the pipeline)
+    if (const char* e = getenv("QUADE_PIPE_DEVICE_GUNZIP")) p->device_gunzip = atoi(e) ? 1 : 0;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&p->cs, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&p->ds, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&p->is[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p->is[1], hipStreamNonBlocking) != hipSuccess ||
@@ -1963,6 +2315,7 @@ int qd_pipe_set_option(qd_pipe* p, const char* name, int64_t value) {
     else if (n == "member_slots_bytes" && value >= (1 << 20)) p->member_slots_bytes = value;
     else if (n == "inflate_streams" && (value == 1 || value == 2)) p->n_is = (int)value;
     else if (n == "inflate_form" && (value == 2 || value == 3)) p->inflate_form = (int)value;
+    else if (n == "device_gunzip" && (value == 0 || value == 1)) p->device_gunzip = (int)value;
     else return pfail(p, QD_ERR_INVALID, "unknown option " + n);
     return QD_OK;
 }
@@ -1976,6 +2329,7 @@ int qd_pipe_run(qd_pipe* p, const qd_pipe_chunk* chunks, int32_t n_chunks, qd_pi
     p->st = qd_pipe_stats_impl();  // the statistics are per call (a pipe that runs chunk after chunk: the caller adds them up)
     p->q3_jobs.clear();  // (a run that failed half way may have left blocks queued: their ring is gone)
     p->q3_parts.clear();
+    p->gz_units0 = p->gz ? p->gz->stats().units : 0;
     const int ns = p->n_streams;
     for (int c = 0; c < n_chunks; ++c) {
         if (!chunks[c].r1 || !chunks[c].r2 || !chunks[c].i1 || (ns == 4 && !chunks[c].i2) || !chunks[c].sink) return pfail(p, QD_ERR_INVALID, "chunk without files or sink");
@@ -2004,7 +2358,7 @@ int qd_pipe_run(qd_pipe* p, const qd_pipe_chunk* chunks, int32_t n_chunks, qd_pi
             f.start = chunks[c].start_offset[s] > 0 ? chunks[c].start_offset[s] : 0;
             files.push_back(std::move(f));
         }
-        feeders.emplace_back(new Feeder(p->device, std::move(files)));
+        feeders.emplace_back(new Feeder(p->device, std::move(files), p->device_gunzip != 0));
     }
     for (auto& f : feeders) PCHK(p, f->start());
     {
@@ -2062,6 +2416,10 @@ int qd_pipe_run(qd_pipe* p, const qd_pipe_chunk* chunks, int32_t n_chunks, qd_pi
         stats->download_s = p->st.download;
         stats->append_s = p->st.append;
         stats->run_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - run_t0).count();
+        stats->gzip_steps = p->st.gzip_steps;
+        stats->gzip_units = p->gz ? p->gz->stats().units - p->gz_units0 : 0;
+        stats->gzip_members = p->st.gzip_members;
+        stats->gzip_fallbacks = p->st.gzip_fallbacks;
     }
     return rc;
 }
@@ -2080,6 +2438,12 @@ int qd_pipe_destroy(qd_pipe* p) {
         for (DevBuf* b : {&w.buf[0], &w.buf[1], &w.tile_counts, &w.tile_base, &w.lines, &w.rec_tile, &w.recs, &w.status, &w.crc, &w.blk, &w.expect}) b->release();
     }
     for (DevBuf* b : {&p->jobs3, &p->status3, &p->scratch3}) b->release();
+    for (qd_pipe::Window& w : p->win) {
+        gz_close(w);
+        for (DevBuf* b : {&w.gz.comp[0], &w.gz.comp[1], &w.gz.carried}) b->release();
+    }
+    delete p->gz;
+    p->gz = nullptr;
     for (DevBuf* b : {&p->d_res, &p->matches, &p->matches_b, &p->rows_seq[0], &p->rows_seq[1], &p->rows_qual[0], &p->rows_qual[1], &p->rows_len[0], &p->rows_len[1], &p->codes, &p->mol,
                       &p->short_idx, &p->dest, &p->len1, &p->len2, &p->hist, &p->tmp, &p->perm, &p->sdest, &p->g1, &p->g2, &p->scan_tiles, &p->first, &p->g1_first,
                       &p->g2_first, &p->subs, &p->first_sub, &p->ranges, &p->crc, &p->tokens, &p->sub_out, &p->sub_bytes, &p->base1, &p->base2})

@@ -71,7 +71,8 @@ class qd_grain_info(C.Structure):
 class qd_pipe_stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("pairs", "batches", "bgzf_blocks", "host_inflated_runs", "text_segments", "pieces",
                                          "host_coded_pieces", "text_in_bytes", "text_out_bytes", "gzip_bytes", "rescans")] + \
-               [(n, C.c_double) for n in ("run_s", "wait_input_s", "wait_sync_s", "wait_out_set_s", "alloc_s", "collector_wait_s", "download_s", "append_s")]
+               [(n, C.c_double) for n in ("run_s", "wait_input_s", "wait_sync_s", "wait_out_set_s", "alloc_s", "collector_wait_s", "download_s", "append_s")] + \
+               [(n, C.c_int64) for n in ("gzip_steps", "gzip_units", "gzip_members", "gzip_fallbacks")]
 
 
 STREAM_CONTEXT = C.c_void_p(-1)  # QD_STREAM_CONTEXT: the context's own stream (None/0 = HIP's null stream)
@@ -170,6 +171,7 @@ SYMBOLS = [
     ("qd_pipe_destroy", C.c_int, [_P]),
     ("qd_dev_fastq_scan", C.c_int64, [C.c_int, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _P, C.c_int64, _P]),
     ("qd_dev_crc32", C.c_int, [C.c_int, _P, C.c_int64, C.c_int64, C.POINTER(C.c_uint32)]),
+    ("qd_dev_gunzip", C.c_int, [C.c_int, _P, C.c_int64, _P, C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
     ("qd_dev_sort_by_dest", C.c_int, [C.c_int, _P, C.c_int64, C.c_int32, _P, _P, _P]),
     ("qd_get_plan", C.c_int, [_P, C.POINTER(qd_plan)]),
     ("qd_context_device", C.c_int, [_P, C.POINTER(C.c_int32)]),
@@ -603,6 +605,23 @@ class Inflater(object):
 
     def __exit__(self, *a):
         self.close()
+
+
+def dev_gunzip(gz, out_cap, device_id=0, step_bytes=64 << 20, stretch_bytes=0, unit_text=0):
+    """A whole gzip file image (bytes: one or more members) -> its text, inflated by the device's gzip kernels (qd_dev_gunzip).
+    Returns (text bytes, stats dict).  QuadeHipError(QD_ERR_FORMAT) for input the device does not decode (not gzip, damaged, ...)."""
+    lib = load_library()
+    src = np.frombuffer(gz, dtype=np.uint8) if len(gz) else np.zeros(1, np.uint8)
+    out = np.empty(max(int(out_cap), 1), dtype=np.uint8)
+    n = C.c_int64(0)
+    st = (C.c_int64 * 6)()
+    r = lib.qd_dev_gunzip(int(device_id), _ptr(src), len(gz), _ptr(out), int(out_cap), C.byref(n), int(step_bytes), int(stretch_bytes), int(unit_text), st)
+    stats = dict(zip(("members", "steps", "stretches", "units", "chain_retries", "partial_last"), [int(x) for x in st]))
+    if r != QD_OK:
+        e = QuadeHipError(r, "qd_dev_gunzip: the device did not inflate the stream")
+        e.stats = stats
+        raise e
+    return out[:n.value].tobytes(), stats
 
 
 class Pipe(object):

@@ -102,7 +102,8 @@ static Run<C> run_unit(const std::vector<uint8_t>& comp, uint64_t bit_start, uin
                 w = 0x5A5A5A5A;
             }
         for (int t = 0; t < qd3::ROUND_TURNS && L.state <= qd3::ST_STORED; ++t) {
-            qd3::turn<C>(L, lds.data(), ring.data(), lane);
+            if (L.state == qd3::ST_STORED) qd3::turn_stored<C>(L, ring.data(), lane);
+            else qd3::turn<C>(L, lds.data(), ring.data(), lane);
             if (L.rd > 4 * landed) {
                 printf("FAIL: a turn took dword %u, landed %u chunks\n", L.rd, landed);
                 ++g_fail;

@@ -18,6 +18,9 @@ def _gz(path):
         return fh.read()
 
 
+_LAST_PIPE_STATS = {}
+
+
 def _run_cli(conf, workdir):
     from quade_amd.quade import Quade
     old = os.getcwd()
@@ -25,6 +28,7 @@ def _run_cli(conf, workdir):
     try:
         q = Quade(conf_file=conf)
         assert q() == 0
+        _LAST_PIPE_STATS["stats"] = getattr(q, "pipe_stats", None)
     finally:
         os.chdir(old)
 
@@ -64,6 +68,9 @@ def test_bundled_golden_replay_through_hip(tmp_path, bundled_dir):
     from quade_amd.sample import Sample
     assert Sample.COUNTS() == [299, 52, 0, 247, 25, 0, 27, 0]
     _compare_dirs(str(work), os.path.join(bundled_dir, "result"))
+    # the reference's fixtures are single gzip members (its real input format): inflated by the device, none handed to the host
+    st = _LAST_PIPE_STATS.get("stats")
+    assert st is not None and st["gzip_members"] == 12 and st["gzip_fallbacks"] == 0 and st["host_inflated_runs"] == 0 and st["text_segments"] == 0, st
 
 
 # ---- generated datasets ----------------------------------------------------------------------------

@@ -245,6 +245,9 @@ def test_pipeline_small_batches_with_malformed_records(tmp_path, fmt):
     assert st["pairs"] == 3 * 900 - 3 and st["batches"] >= 27
     if fmt == "bgzf":
         assert st["bgzf_blocks"] > 0 and st["text_segments"] == 0 and st["host_inflated_runs"] == 0
+    elif fmt == "gz":  # ordinary gzip members: inflated on the device too (every member's CRC-32 and ISIZE checked), never by the host
+        assert st["bgzf_blocks"] == 0 and st["text_segments"] == 0, st
+        assert st["gzip_members"] == 12 and st["gzip_steps"] >= 12 and st["gzip_units"] >= 12 and st["gzip_fallbacks"] == 0, st
     else:
         assert st["bgzf_blocks"] == 0 and st["text_segments"] > 0
 
