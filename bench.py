@@ -174,11 +174,15 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
     work = tempfile.mkdtemp(prefix="quade_bench_e2e_")
     try:
         t0 = time.perf_counter()
-        paths, bcs = synth.write_fastq_dataset(work, n_pairs)
+        # n_chunks DISTINCT chunks (a seed per chunk, one sample sheet): r04 listed one 2 M-pair dataset n_chunks times.  The files are
+        # written by this process seconds before they are read: the input is page-cache hot (the box has no cold storage to read from).
+        paths, bcs = synth.write_fastq_chunks(work, n_pairs, n_chunks)
         t_gen = time.perf_counter() - t0
         from quade_amd.quade import Quade
         from quade_amd.sample import Sample
         n = n_pairs * n_chunks
+        n_chunks_listed = n_chunks
+        n_chunks = 1  # (the lists hold every chunk once: write_conf repeats whole lists)
 
         pipe_stats = {}
 
@@ -223,22 +227,23 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
         dt_hh, cpu_hh, counts_hh, _ = run(-1, "huffhost", "device_deflate : False\n")  # ... and by the host's pool alone
         # ... at gzip level 6 on the host's pool (the driver's default was 6 until the device coded level 1; the reference's gzip.open default is 9)
         dt_6, cpu_6, counts_6, out_bytes_6 = run(6, "lvl6")
-        in_bytes = sum(os.path.getsize(p) for p in paths.values()) * n_chunks
+        in_bytes = sum(os.path.getsize(p) for v in paths.values() for p in v)
         # ... and on the reference's real input format: every input file ONE ordinary gzip member (src/Quade.py:203-206
         # opens plain .fastq.gz; its fixtures are single members) -- inflated in parallel by quade_pgz.cpp
         bgzf_paths = paths
         single_dir = os.path.join(work, "single")
         os.mkdir(single_dir)
-        paths, _ = synth.write_fastq_dataset(single_dir, n_pairs, member_bytes=0)
+        paths, _ = synth.write_fastq_chunks(single_dir, n_pairs, n_chunks_listed, member_bytes=0)
         dt_s, cpu_s1, counts_s, out_bytes_s = run(gzip_level, "single")
-        in_bytes_s = sum(os.path.getsize(p) for p in paths.values()) * n_chunks
+        single_stats = pipe_stats.get("single") or {}
+        in_bytes_s = sum(os.path.getsize(p) for v in paths.values() for p in v)
         # ... and on records whose insert-read qualities are binned as current instruments write them ('F' with short stretches of
         # ':' ',' '#'): the default dataset's uniformly random qualities are the worst case for the inflater and the coders alike
         binned_dir = os.path.join(work, "binned")
         os.mkdir(binned_dir)
-        paths, _ = synth.write_fastq_dataset(binned_dir, n_pairs, qualities="binned")
+        paths, _ = synth.write_fastq_chunks(binned_dir, n_pairs, n_chunks_listed, qualities="binned")
         dt_b, cpu_b, counts_b, out_bytes_b = run(gzip_level, "binned")
-        in_bytes_b = sum(os.path.getsize(p) for p in paths.values()) * n_chunks
+        in_bytes_b = sum(os.path.getsize(p) for v in paths.values() for p in v)
         paths = bgzf_paths
 
         def sub(dt_x, cpu_x, counts_x, level, what, **more):
@@ -256,9 +261,11 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
                                    "what": "[gpu] device_deflate : False"},
                 "what": "same input, [gpu] gzip_level : -1 (Huffman coding only; on real fastq ~25 % larger files than level 1)"}
         single = sub(dt_s, cpu_s1, counts_s, gzip_level,
-                     "same records, every input file ONE gzip member (the reference's input format), inflated by the "
-                     "parallel gunzip (speculative chunks over a marker window, proven by the chain)",
-                     input_gz_bytes=in_bytes_s, output_gz_bytes=out_bytes_s, vs_bgzf_input=(n / dt_s) / (n / dt))
+                     "same records, every input file ONE gzip member (the reference's input format: src/Quade.py:203-206), inflated ON THE "
+                     "DEVICE (block starts probed, a lane per stretch proven by the chain, marker windows resolved: quade_inflate3.hip)",
+                     input_gz_bytes=in_bytes_s, output_gz_bytes=out_bytes_s, vs_bgzf_input=(n / dt_s) / (n / dt),
+                     pipeline={k: single_stats.get(k) for k in ("gzip_steps", "gzip_units", "gzip_members", "gzip_fallbacks", "text_segments", "host_inflated_runs", "run_s",
+                                                                "wait_sync_s", "wait_input_s")})
         lvl6 = sub(dt_6, cpu_6, counts_6, 6, "same BGZF input, [gpu] gzip_level : 6 (libdeflate on the host's pool; the driver's default is 1 = the level the device codes)",
                    output_gz_bytes=out_bytes_6)
         binned = sub(dt_b, cpu_b, counts_b, gzip_level, "records of the same shape with binned insert-read qualities (BGZF input, same level): "
@@ -273,14 +280,15 @@ def e2e_rate(n_pairs, gzip_level=1, n_chunks=1):
         # dict match, min() gate, FastqWriter with gzip.open's default level -- on one core, on a bounded sample of the same workload,
         # and the device pipeline's outputs for that sample compared with it byte for byte
         cpu_ref = e2e_cpu_baseline(work, synth, Quade, n_sample=200_000)
-        large = {"value": 4 * n / dt_L, "unit": "read-pairs/s", "pairs": 4 * n, "chunks": 4 * n_chunks, "seconds": dt_L, "cpu_seconds_per_M_pairs": cpu_L / (4 * n / 1e6),
-                 "counts_equal": [4 * c for c in counts] == counts_L, "what": "the same files listed four times as often: where the run's start-up and tail no longer show"}
+        large = {"value": 4 * n / dt_L, "unit": "read-pairs/s", "pairs": 4 * n, "chunks": 4 * n_chunks_listed, "seconds": dt_L, "cpu_seconds_per_M_pairs": cpu_L / (4 * n / 1e6),
+                 "counts_equal": [4 * c for c in counts] == counts_L, "what": "the same distinct chunks listed four times over: where the run's start-up and tail no longer show"}
         return {"value": n / dt, "untimed_warmup_runs": 1, "host_pool_only": host1, "pinned_slots_path": slots, "cpu_baseline": cpu_ref, "four_times_the_chunks": large,
                 "path": "device-resident chunk pipeline (qd_pipe_run): inflate -> record scan -> rows -> match -> scatter -> format -> CRC-32 -> coder on the GPU"
                         if pipe_stats.get("lvl") else "batches over pinned slots",
                 "pipeline": pipe_stats.get("lvl"),
                 "members_made_by": "the GPU (quade_deflate.hip: LZ77 + dynamic Huffman)",
-                "huffman_only": huff, "single_member_gzip": single, "binned_qualities": binned, "host_level6": lvl6, "default_level": gzip_level, "unit": "read-pairs/s", "pairs": n, "chunks": n_chunks, "seconds": dt, "gzip_level": gzip_level,
+                "huffman_only": huff, "single_member_gzip": single, "binned_qualities": binned, "host_level6": lvl6, "default_level": gzip_level, "unit": "read-pairs/s", "pairs": n, "chunks": n_chunks_listed, "seconds": dt, "gzip_level": gzip_level,
+                "distinct_chunks": True, "input_page_cache": "hot: the chunk files were written by this process seconds before the runs (no cold storage on the box)",
                 "samples": len(bcs), "gzip_backend": io_backend(), "io_threads": io_threads(), "host_cores": host_cores(),
                 "input_gz_bytes": in_bytes, "output_gz_bytes": out_bytes, "counts_total_pass_fail_undetermined": counts,
                 "dataset_seconds": t_gen,
@@ -335,6 +343,135 @@ def e2e_cpu_baseline(work, synth, Quade, n_sample):
                       "loop, per-read objects and FastqWriter with gzip.open's default level, one thread" % (n_sample, len(bcs)),
             "outputs_equal_device_pipeline": bool(same), "counts_equal": Sample.COUNTS() == sset.counts(),
             "device_path_was_the_pipeline": getattr(q, "pipe_stats", None) is not None}
+
+
+def kernel_config_rate(cfg_name, n, steps, warm, local_rank):
+    """The hot kernel on another BASELINE config (resident rows, HIP events on the launch stream): the fractions VERDICT r04 asked to see
+    in the driver's own run, beside the headline config's."""
+    import numpy as np
+    import torch
+    from quade_amd import synth
+    from quade_amd.hip_backend import Engine
+    w = synth.generate(cfg_name, n, seed=20260000 + int(cfg_name[3:]), device="cuda", barcode_seed=20260000 + int(cfg_name[3:]))
+    torch.cuda.synchronize()
+    cfg = synth.CONFIGS[cfg_name]
+    with Engine(local_rank) as eng:
+        lay = eng.set_plan(w.plan)
+        eng.set_barcodes(w.barcode_strings())
+        kind = eng.kernel_kind(False)
+        M = lay.mol_width
+        codes = torch.empty(n, dtype=torch.int16, device="cuda")
+        mol = torch.empty((n, max(M, 1)), dtype=torch.uint8, device="cuda")
+        seq_p, qual_p = [t.data_ptr() for t in w.seq], [t.data_ptr() for t in w.qual]
+        stream = torch.cuda.Stream()
+        torch.cuda.synchronize()
+
+        def step():
+            eng.demux_device(n, seq_p, qual_p, codes.data_ptr(), mol.data_ptr() if M else None, stream=stream.cuda_stream)
+        for _ in range(warm):
+            step()
+        a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(steps):
+            step()
+        z.record(stream)
+        z.synchronize()
+        ms = float(a.elapsed_time(z)) / steps
+        got = codes.view(torch.int16).to(torch.int32) & 0xFFFF
+        same = bool(torch.equal(got, w.expected))
+        c = eng.counts().astype(np.int64)
+        ok = bool(same and c[0] == n * (steps + warm) and c[0] == c[1] + c[2] + c[3])
+    algo = synth.ALGO_BYTES[cfg_name]
+    del codes, mol, w
+    torch.cuda.empty_cache()
+    return {"pairs": n, "steps": steps, "untimed_launches": warm, "kernel": "demux_" + kind, "kernel_ms": ms, "algorithmic_bytes_per_pair": algo,
+            "achieved_GBps": n * algo / (ms * 1e-3) / 1e9, "frac": n * algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "samples": cfg["S"], "verified": ok}
+
+
+def e2e_ranks(args, rank, world, local_rank, dist, backend):
+    """The N > 1 line's demultiplexing leg (BASELINE.json metric: read-pairs/sec demultiplexed at 1/2/4/8 MI355X): chunk-sharded
+    fastq.gz -> per-sample fastq.gz through the PRODUCT's multi-rank path, in these very rank processes -- every rank generates its own
+    distinct chunks (chunk c belongs to rank c mod N), all ranks run quade_amd.quade on ONE conf in ONE output directory (the launcher's
+    RANK / WORLD_SIZE / LOCAL_RANK are what quade_amd.dist reads), counts summed by the library's RCCL communicator, part files spliced.
+    One untimed run first; the timed run is bracketed by barriers, the maximum over ranks counts.  Rehearsal on one GPU
+    (QUADE_BENCH_DEVICE): the ranks share the device and the counts travel through files (RCCL wants one rank per device)."""
+    import shutil
+    import tempfile
+    import torch
+    from quade_amd import synth
+    from quade_amd.quade import Quade
+    from quade_amd.sample import Sample
+    per_rank = max(1, args.e2e_rank_chunks)
+    n_pairs, total_chunks = args.e2e_pairs, per_rank * world
+    box = [tempfile.mkdtemp(prefix="quade_bench_ranks_") if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    work = box[0]
+    rehearsal = bool(os.environ.get("QUADE_BENCH_DEVICE"))
+    if rehearsal:
+        os.environ["QUADE_DEVICE"] = os.environ["QUADE_BENCH_DEVICE"]
+        os.environ["QUADE_DIST_TRANSPORT"] = "files"
+    try:
+        t0 = time.perf_counter()
+        mine, bcs = {}, None
+        for c in range(rank, total_chunks, world):
+            d = os.path.join(work, "c%d" % c)
+            os.makedirs(d, exist_ok=True)
+            paths, bcs = synth.write_fastq_dataset(d, n_pairs, seed=5 + 1000 * (c + 1), barcode_seed=5, first_read=c * n_pairs)
+            mine[c] = paths
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        t_gen = time.perf_counter() - t0
+        lists = {}
+        for c in range(total_chunks):
+            for k, v in every[c % world][c].items():
+                lists.setdefault(k, []).append(v)
+        conf = os.path.join(work, "conf.txt")
+        if rank == 0:
+            synth.write_conf(conf, lists, bcs, 1, gpu="[gpu]\ngzip_level : 1\n")
+        dist.barrier()
+
+        def run(tag):
+            out = os.path.join(work, "out_" + tag)
+            if rank == 0:
+                os.makedirs(out, exist_ok=True)
+            dist.barrier()
+            cwd = os.getcwd()
+            os.chdir(out)
+            try:
+                with stdout_to_stderr():
+                    dist.barrier()
+                    t0 = time.perf_counter()
+                    q = Quade(conf_file=conf)
+                    q()
+                    dt_mine = time.perf_counter() - t0
+                    dist.barrier()
+                    dt_all = time.perf_counter() - t0
+            finally:
+                os.chdir(cwd)
+            return q, dt_mine, dt_all
+        run("warm")
+        q, dt_mine, dt_all = run("timed")
+        tmax = torch.tensor([dt_all], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        st = getattr(q, "pipe_stats", None) or {}
+        mine_rec = {"rank": rank, "device": os.environ.get("QUADE_DEVICE", str(local_rank)), "chunks": sorted(mine), "seconds": dt_mine,
+                    "pairs": st.get("pairs"), "pipeline": {k: st.get(k) for k in ("pairs", "batches", "bgzf_blocks", "host_inflated_runs", "host_coded_pieces", "run_s",
+                                                                                 "wait_sync_s", "wait_input_s", "alloc_s")},
+                    "count_reduce": getattr(q, "count_reduce", None), "splice_seconds": getattr(q, "merge_seconds", None)}
+        recs = [None] * world
+        dist.all_gather_object(recs, mine_rec)
+        total = Sample.COUNTS()[0] if rank == 0 else None
+        n = n_pairs * total_chunks
+        return {"value": n / dt, "unit": "read-pairs/s", "world": world, "pairs": n, "chunks": total_chunks, "pairs_per_chunk": n_pairs, "seconds": dt,
+                "untimed_warmup_runs": 1, "distinct_chunks": True, "dataset_seconds": t_gen, "total_pairs_in_report": total, "counts_total_equal": total == n if rank == 0 else None,
+                "count_reduce": recs[0]["count_reduce"], "ranks": recs, "rehearsal_on_one_gpu": rehearsal,
+                "what": "chunk c -> rank c mod N through python -m quade_amd.quade in every rank process (the launcher's RANK / WORLD_SIZE / LOCAL_RANK), per-chunk parts "
+                        "spliced in chunk order, counts summed by qd_reduce_counts (RCCL)", "scaling": "weak (%d chunks of %d pairs per rank)" % (per_rank, n_pairs)}
+    finally:
+        dist.barrier()
+        if rank == 0:
+            shutil.rmtree(work, ignore_errors=True)
 
 
 def mapped_libraries(word):
@@ -395,6 +532,8 @@ def main():
     ap.add_argument("--e2e-chunks", type=int, default=8, help="chunks per end-to-end run (the same files listed again: 8 x 2 M pairs by "
                     "default -- a run of 2 M pairs is 0.4 s, of which the process's start-up is a quarter; 64 M pairs run 9-11 M pairs/s)")
     ap.add_argument("--strong-sample", type=int, default=32_000_000)
+    ap.add_argument("--e2e-rank-chunks", type=int, default=2, help="N > 1: chunks per rank of the chunk-sharded end-to-end leg (extra.e2e_ranks)")
+    ap.add_argument("--config-steps", type=int, default=20, help="timed steps per extra kernel config (extra.kernel_configs)")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
 
@@ -676,6 +815,17 @@ def main():
             rows = {"seq": [t[:nb].cpu().numpy() for t in w.seq], "qual": [t[:nb].cpu().numpy() for t in w.qual]}
             out["cpu_baseline"]["strong"] = strong_cpu_baseline(rows, w.plan, w.barcode_strings(),
                                                                 codes[:nb].cpu().numpy().view(np.uint16))
+    if world > 1 and not args.no_extras:
+        # the demultiplexing leg of the N > 1 line: every rank takes part (the kernel leg's engine and communicator are closed)
+        del codes, mol
+        w.seq, w.qual = [], []
+        torch.cuda.empty_cache()
+        try:
+            er = e2e_ranks(args, rank, world, local_rank, dist, backend)
+        except Exception as e:
+            er = {"error": repr(e)}
+        if rank == 0:
+            out["extra"] = {"e2e_ranks": er}
     if rank == 0 and world == 1 and not args.no_extras:
         # the other two rates of SURVEY.md 8(d); labelled, outside `value`
         extra = {}
@@ -686,6 +836,16 @@ def main():
         del codes, mol
         w.seq, w.qual = [], []
         torch.cuda.empty_cache()
+        # the kernel on the other three BASELINE configs (cfg4 / cfg5 are the 8-GPU runs' shapes)
+        kc = {}
+        for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
+            if name == args.config:
+                continue
+            try:
+                kc[name] = kernel_config_rate(name, per_gpu_default[name], max(1, args.config_steps), 30, local_rank)
+            except Exception as e:
+                kc[name] = {"error": repr(e)}
+        extra["kernel_configs"] = kc
         try:
             extra["e2e"] = e2e_rate(args.e2e_pairs, n_chunks=max(1, args.e2e_chunks))
         except Exception as e:

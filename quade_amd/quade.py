@@ -182,9 +182,11 @@ class Quade(object):
             if self.world > 1 and self.comm is None:
                 dist.barrier_through_files(self.outdir, self.token, self.rank, self.world, "closed")
             stems = [s.name + q for s in Sample.SAMPLE_LIST for q in ("_pass", "_fail")] + ["Undetermined"]
+            t_merge = time()
             with _timed("merge chunk parts"):
                 dist.merge_parts(self.outdir, self.n_parts, self.rank, self.world,
                                  names=[st + r + ".fastq.gz" for st in stems for r in ("_R1", "_R2")])
+            self.merge_seconds = time() - t_merge
             if self.world > 1:
                 dist.barrier_through_files(self.outdir, self.token, self.rank, self.world, "merged")
             if self.rank == 0:
@@ -235,7 +237,9 @@ class Quade(object):
             for eng in self.engines:
                 if id(eng) not in members:
                     self.comm.engines[0].add_counts(eng.counts())
+            t_red = time()
             counts = self.comm.reduce_counts()  # RCCL all-reduce over xGMI
+            self.count_reduce = {"backend": "rccl via qd_reduce_counts", "seconds": time() - t_red, "members": len(self.comm.engines)}
             self.comm.close()
             return counts
         counts = None  # contexts that share a device (or chunk-worker groups): summed here
@@ -244,6 +248,7 @@ class Quade(object):
             counts = c if counts is None else counts + c
         if self.world > 1:
             counts = dist.sum_counts_through_files(self.outdir, self.token, self.rank, self.world, counts)
+            self.count_reduce = {"backend": "files (rehearsal: ranks sharing one GPU)", "seconds": None, "members": self.world}
         return counts
 
     def double_index_parser(self):

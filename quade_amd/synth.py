@@ -212,7 +212,7 @@ def _gzip_members(data, path, level, member_bytes, threads=0):
 
 
 def write_fastq_dataset(workdir, n_pairs, n_samples=96, insert_len=150, seed=5, gz_level=1, member_bytes="bgzf",
-                        threads=0, plain=False, qualities="uniform"):
+                        threads=0, plain=False, qualities="uniform", barcode_seed=None, first_read=0):
     """2 x insert_len bp insert reads + dual 8 bp index reads of n_pairs pairs as four fastq(.gz) files
     under workdir (SURVEY.md 8d recipe: 90 % carry a sample's barcode pair, 10 % get an N; qualities
     phred 30..40, 15 % of the index reads with one position at phred 2..24).  Names are identical across
@@ -225,9 +225,12 @@ def write_fastq_dataset(workdir, n_pairs, n_samples=96, insert_len=150, seed=5, 
     assert qualities in ("uniform", "binned")
     rng = np.random.default_rng(seed)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    # barcode_seed: the sample sheet from a generator of its own, so that chunks drawn with different seeds share it (first_read: where
+    # this chunk's read numbering starts -- the names of distinct chunks differ as they do between the files of a real run)
+    bc_rng = rng if barcode_seed is None else np.random.default_rng(barcode_seed)
     bcs = set()
     while len(bcs) < n_samples:
-        bcs.add(("".join(rng.choice(list("ACGT"), 8)), "".join(rng.choice(list("ACGT"), 8))))
+        bcs.add(("".join(bc_rng.choice(list("ACGT"), 8)), "".join(bc_rng.choice(list("ACGT"), 8))))
     bcs = sorted(bcs)
     bc_arr = np.array([[np.frombuffer((a + b).encode(), dtype=np.uint8)] for a, b in bcs]).reshape(n_samples, 16)
     n = n_pairs
@@ -238,7 +241,7 @@ def write_fastq_dataset(workdir, n_pairs, n_samples=96, insert_len=150, seed=5, 
     lut_acgt = acgt[np.arange(256) & 3]
     lut_phred = (63 + (np.arange(256) * 11 >> 8)).astype(np.uint8)  # '?'..'I' = phred 30..40
 
-    idx = np.arange(n)
+    idx = np.arange(n) + int(first_read)
     head = np.concatenate([np.frombuffer(b"@SIM:1:FC:1:", np.uint8)[None, :].repeat(n, 0), _digits(idx % 97, 4),
                            np.full((n, 1), ord(":"), np.uint8), _digits(idx, 9), np.full((n, 1), ord(":"), np.uint8),
                            _digits((idx * 3) % 1000000007, 10)], axis=1)
@@ -294,11 +297,28 @@ def write_fastq_dataset(workdir, n_pairs, n_samples=96, insert_len=150, seed=5, 
     return paths, bcs
 
 
+def write_fastq_chunks(workdir, n_pairs, n_chunks, seed=5, **kw):
+    """n_chunks DISTINCT chunks of n_pairs pairs each (a seed per chunk, one sample sheet, read numbers running on): the files of
+    chunk c under workdir/c<c>.  Returns ({stream: [paths]}, barcode pairs) -- write_conf takes the lists as they are."""
+    import os
+    lists, bcs = {}, None
+    for c in range(n_chunks):
+        d = os.path.join(workdir, "c%d" % c)
+        os.makedirs(d, exist_ok=True)
+        paths, b = write_fastq_dataset(d, n_pairs, seed=seed + 1000 * (c + 1), barcode_seed=seed, first_read=c * n_pairs, **kw)
+        assert bcs is None or b == bcs
+        bcs = b
+        for k, v in paths.items():
+            lists.setdefault(k, []).append(v)
+    return lists, bcs
+
+
 def write_conf(path, paths, bcs, n_chunks=1, minimal_qual=25, gpu=""):
-    """A Quade configuration file for write_fastq_dataset's files (each listed n_chunks times)."""
+    """A Quade configuration file for write_fastq_dataset's files (each listed n_chunks times) or write_fastq_chunks' lists (the
+    whole list n_chunks times)."""
     with open(path, "w") as fh:
         fh.write("[quality]\nminimal_qual : %d\n[fastq]\n" % minimal_qual +
-                 "".join("%s : %s\n" % (k, "  ".join([v] * n_chunks)) for k, v in paths.items()) +
+                 "".join("%s : %s\n" % (k, "  ".join((v if isinstance(v, list) else [v]) * n_chunks)) for k, v in paths.items()) +
                  "[index]\nindex2 : True\nmolecular1 : False\nmolecular2 : False\nindex1_start : 1\nindex1_end : 8\n"
                  "index2_start : 1\nindex2_end : 8\n[output]\nwrite_pass : True\nwrite_fail : True\nwrite_undetermined : True\n" +
                  gpu + "".join("[sample%d]\nname : S%d\nindex1_seq : %s\nindex2_seq : %s\n" % (i + 1, i + 1, a, b)

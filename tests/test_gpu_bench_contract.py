@@ -21,7 +21,7 @@ def _run(args, env=None, launcher=None):
 
 def test_single_gpu_line():
     j = _run(["--steps", "3", "--warmup", "1", "--pairs", "3000000", "--cpu-sample", "20000", "--e2e-pairs", "30000", "--e2e-chunks", "1",
-              "--strong-sample", "1000000"])
+              "--strong-sample", "1000000", "--config-steps", "3"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k
@@ -62,6 +62,15 @@ def test_single_gpu_line():
     # hygiene: what ran as warm-up, the step-based fraction beside the event-based one
     assert j["warmup_ran"] == j["untimed_launches"] and 0 < r["frac_by_step"] <= r["frac"] * 1.001
     assert "traffic_age_commit" in r
+    # the single-member files went through the device's gzip kernels, none was handed to the host; the chunks were distinct
+    assert e["distinct_chunks"] is True and "hot" in e["input_page_cache"]
+    assert sm1["pipeline"]["gzip_members"] == 4 and sm1["pipeline"]["gzip_fallbacks"] == 0 and sm1["pipeline"]["text_segments"] == 0, sm1["pipeline"]
+    # the kernel on the other BASELINE configs, verified, in the same line
+    kc = j["extra"]["kernel_configs"]
+    assert sorted(kc) == ["cfg2", "cfg4", "cfg5"]
+    for name, k in kc.items():
+        assert k["verified"] is True and k["kernel_ms"] > 0 and 0 < k["frac"] < 1, (name, k)
+        assert abs(k["frac"] - k["pairs"] * k["algorithmic_bytes_per_pair"] / (k["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9
 
 
 def test_two_ranks_self_spawned():
@@ -84,10 +93,18 @@ def test_two_rank_rehearsal_line():
     env = dict(os.environ, QUADE_BENCH_DEVICE="0", QUADE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                 "--master-addr", "127.0.0.1", "--master-port", "29577"]
-    j = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "2000000"], env=env, launcher=launcher)
+    j = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "2000000", "--e2e-pairs", "40000", "--e2e-rank-chunks", "2"], env=env, launcher=launcher)
     assert j["n_gpus"] == 2 and j["verified"] is True and "cpu_baseline" not in j
     assert j["launched_by"] == "external launcher" and j["world"] == 2
     assert abs(j["value"] - 2 * 2000000 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
+    # the demultiplexing leg of the N > 1 line: chunk-sharded fastq.gz -> fastq.gz through the product's multi-rank path
+    er = j["extra"]["e2e_ranks"]
+    assert "error" not in er, er
+    assert er["world"] == 2 and er["chunks"] == 4 and er["pairs"] == 160000 and er["value"] > 0 and er["distinct_chunks"] is True
+    assert er["counts_total_equal"] is True and er["total_pairs_in_report"] == 160000
+    assert [r["rank"] for r in er["ranks"]] == [0, 1] and [r["chunks"] for r in er["ranks"]] == [[0, 2], [1, 3]]
+    assert all(r["pairs"] == 80000 and r["pipeline"]["host_inflated_runs"] == 0 for r in er["ranks"]), er["ranks"]
+    assert er["rehearsal_on_one_gpu"] is True and "files" in er["count_reduce"]["backend"]  # (the driver's runs: "rccl via qd_reduce_counts")
 
 
 def test_single_rank_rccl_path():
