@@ -84,6 +84,10 @@ struct Unit {
     uint64_t tok_off;      // the unit's slot region in the token buffer: [tok_off, tok_off + tok_cap), tok_off % 4 == 0
     uint32_t tok_cap;      // % 4 == 0
     uint32_t wend;         // at least 80 dwords behind bit_end (a lane's ring holds the 256 bytes behind its position)
+    // A unit whose decode passes bit_stop without a block starting there (the candidate was not a block start) goes on until a block
+    // header lies on one of these positions -- the stream's other candidates, ascending -- or its input ends: no second launch.
+    const uint64_t* cands;
+    uint32_t n_cands, pad;
 };
 struct Result {
     uint32_t status;     // 0, or QD_INFLATE_*
@@ -111,6 +115,8 @@ struct Lane {
     uint32_t clast;    // the last chunk that may be loaded (requests beyond are clamped to it: garbage, never a fault)
     uint64_t buf;
     uint64_t bit_stop, bit_end;
+    const uint64_t* cands;
+    uint32_t n_cands;
     uint32_t* lens;  // LENS_DW dwords of scratch (global memory)
     uint32_t lim_l[C::NL], bas_l[C::NL], lim_d[C::ND], bas_d[C::ND];
     uint16_t* tok;              // the launch's token buffer (wave-uniform): a lane's slots are tok[on0 .. on_end)
@@ -334,7 +340,18 @@ QD3_HD void header(Lane<C>& L, uint16_t* tab, uint32_t* ring, uint32_t lane) {
         L.state = ST_DONE;
         return;
     }
-    if (at > L.bit_stop) return fail(L, QD_INFLATE_CHAIN);
+    if (at > L.bit_stop) {  // the position this unit was to stop at is no block boundary: on to the next candidate that is one
+        uint32_t lo = 0, hi = L.n_cands;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (L.cands[mid] < at) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < L.n_cands && L.cands[lo] == at) {
+            L.state = ST_DONE;
+            return;
+        }
+    }
     if (at + 3 > L.bit_end) return fail(L, QD_INFLATE_TRUNCATED);
     refill(L, ring, lane);
     L.final_seen = (uint32_t)L.buf & 1u;
@@ -538,6 +555,8 @@ QD3_HD void lane_init(Lane<C>& L, const Unit& u, uint16_t* tokens, uint32_t* len
     L.clast = u.wend >= 4 ? (u.wend - 4) >> 2 : 0;
     L.bit_stop = u.bit_stop;
     L.bit_end = u.bit_end;
+    L.cands = u.cands;
+    L.n_cands = u.n_cands;
     L.lens = lens;
     L.tok = tokens;
     L.on0 = L.on = (uint32_t)u.tok_off;  // (slot indices are 32 bit: a launch's token buffer holds less than 2^32 slots)

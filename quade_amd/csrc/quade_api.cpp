@@ -1673,7 +1673,7 @@ extern "C" int qd_dev_gunzip(int device_id, const uint8_t* gz, int64_t gz_len, u
                 rc = QD_ERR_FORMAT;
                 break;
             }
-            if (s.bit_next == s.bit_start && !s.member_end) {  // a block longer than the step: more input, if there is any
+            if (s.bit_next == s.bit_start && !s.member_end && !s.starved) {  // a block longer than the step: more input, if there is any
                 if (s.at_end) {
                     rc = QD_ERR_FORMAT;
                     break;

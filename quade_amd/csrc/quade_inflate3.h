@@ -35,7 +35,8 @@ struct qd_gz_step {
     uint64_t comp_bytes;
     uint64_t bit_start;      // a deflate block header starts here (bits from comp)
     int32_t at_end;          // no more input exists behind comp_bytes
-    int32_t pad0;
+    int32_t starved;         // out of decode(): not all of this step's stretches went into the launch (its token slots are indexed with
+                             // 32 bits: the streams behind take their turn in the next step) -- "no progress" then says nothing about the stream
     uint8_t* carried;        // device, 32 KiB: the text in front of bit_start's block (in), in front of the next step's (out of qd_gz::resolve)
     uint32_t carried_valid;  // how much of it exists (0 at a member's start); updated by resolve
     uint32_t pad1;
@@ -60,15 +61,18 @@ class qd_gz {
     qd_gz(const qd_gz&) = delete;
     qd_gz& operator=(const qd_gz&) = delete;
     // probe + tokens + chain check; synchronises `st` twice.  Fills text_len / bit_next / member_end / failed of every step.
-    hipError_t decode(qd_gz_step* steps, int n, hipStream_t st);
+    hipError_t decode(qd_gz_step* steps, int n, hipStream_t st, int slots_per_byte = 4);
     // the decoded steps' text -> out[i][0 .. text_len) (device); asynchronous on `st`; carried windows updated on the device
     hipError_t resolve(qd_gz_step* steps, int n, uint8_t* const* out, hipStream_t st);
     // after `st` has run resolve(): the steps' CRC-32s, and failed != 0 for a stream whose tokens did not resolve (a damaged stream)
     hipError_t finish(qd_gz_step* steps, int n);
     qd_gz_stats stats() const;
+    // device buffers for steps of about this size in one go (comp_bytes, text_bytes: summed over the streams of a step): growing them
+    // step by step drains the device every time
+    hipError_t reserve(uint64_t comp_bytes, uint64_t text_bytes);
     // knobs (tests: small values make many stretches and units out of small inputs)
     uint64_t stretch_bytes = 32u << 10;  // compressed bytes per stretch: a lane decodes one
-    uint64_t unit_text = 1u << 20;       // text per resolve unit, about
+    uint64_t unit_text = 2u << 20;       // text per resolve unit, about (the windows kernel walks a stream's units one after the other)
 
   private:
     qd_gz_impl* p_;

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64) void inflate3_tokens(const qd3::Unit* units, co
     uint16_t* const tab = reinterpret_cast<uint16_t*>(lds3 + qd3::RING_DW + lane * (uint32_t)C::LANE_DW);
     qd3::Lane<C> L;
     {
-        qd3::Unit un{nullptr, 0, ~0ull, 0, 0, 0, 0};
+        qd3::Unit un{nullptr, 0, ~0ull, 0, 0, 0, 0, nullptr, 0, 0};
         if (u < n_units) {
             if (jobs) {
                 const qd_inflate3_job j = jobs[u];
@@ -407,23 +407,90 @@ __device__ bool gz_header_holds(const uint32_t* base, uint64_t bit, uint64_t bit
     return true;
 }
 
-// found[i] = the first position in [bit_from, bit_to) of stretch i at which a dynamic block's header holds, or ~0
+// The three tests of gz_header_holds as stages of their own, so that a wave runs the dear ones on full sets of survivors:
+//   1. three header bits + the two counts in range: every offset (one in nine passes);
+//   2. the code-length code complete (Kraft sum 128): the survivors, 64 at a time (one in ~200 passes);
+//   3. the run-length coded lengths decode and both codes are complete: their survivors, 16 or more at a time.
+// (With all three inside one function a wave paid the second on every iteration and the third on one in 25 -- some lane always
+//  needs them: 18 ms per launch, as long as the token kernel.  profiles/r05_gz_first_form.txt)
+__device__ __forceinline__ bool gz_stage1(const uint32_t* base, uint64_t bit, uint64_t bit_end) {
+    if (bit + 17 + 12 > bit_end) return false;
+    const uint64_t w = bit >> 5;
+    const uint32_t sh = (uint32_t)bit & 31u;
+    const uint64_t two = (uint64_t)base[w] | ((uint64_t)base[w + 1] << 32);
+    const uint32_t x = (uint32_t)(two >> sh);
+    return (x & 7u) == 4u && ((x >> 3) & 31u) <= 29u && ((x >> 8) & 31u) <= 29u;
+}
+__device__ __forceinline__ bool gz_stage2(const uint32_t* base, uint64_t bit) {
+    const uint32_t ncl = ((uint32_t)(gz_bits(base, bit) >> 13) & 15u) + 4u;
+    const uint64_t x = gz_bits(base, bit + 17);
+    uint32_t kraft = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 19; ++k) {
+        const uint32_t l = (uint32_t)(x >> (3u * k)) & 7u;
+        kraft += (k < ncl && l) ? 128u >> l : 0u;
+    }
+    return kraft == 128u;
+}
+
+// found[i] = the first position in [bit_from, bit_to) of stretch i at which a dynamic block's header holds, or ~0.  One wave per stretch.
+constexpr uint32_t GZ_Q2_RUN = 16;  // survivors of stage 2 that wait for a stage-3 pass at most (a true block start waits with them)
 __global__ __launch_bounds__(64) void gz_probe(const GzStretch* stretches, uint32_t n, uint64_t* found) {
     extern __shared__ __attribute__((aligned(16))) uint8_t probe_lds[];
     const uint32_t i = blockIdx.x, lane = threadIdx.x;
     if (i >= n) return;
     const GzStretch st = stretches[i];
     uint8_t* clt = probe_lds + 128u * lane;
+    typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
+    lds_vu32* q1 = (lds_vu32*)(probe_lds + 64 * 128);  // offsets (from bit_from) that passed stage 1: up to 128
+    lds_vu32* q2 = q1 + 128;                            // ... stage 2: up to 64 + 64
+    uint32_t n1 = 0, n2 = 0;                                            // (wave-uniform)
     uint64_t hit = ~0ull;
-#pragma unroll 1
-    for (uint64_t at = st.bit_from; at < st.bit_to; at += 64) {
-        const uint64_t bit = at + lane;
-        const bool ok = bit < st.bit_to && gz_header_holds(st.base, bit, st.bit_end, clt);
-        const uint64_t m = __ballot(ok);
-        if (m) {
-            hit = at + (uint64_t)__builtin_ctzll(m);
-            break;
+    const uint64_t span = st.bit_to > st.bit_from ? st.bit_to - st.bit_from : 0;
+    auto stage3 = [&]() {  // every queued survivor of stage 2 (at most 128, ascending): the first that holds, if any
+        for (uint32_t b = 0; b < n2 && hit == ~0ull; b += 64) {
+            const bool have = b + lane < n2;
+            const uint64_t bit = st.bit_from + (have ? q2[b + lane] : 0u);
+            const bool ok = have && gz_header_holds(st.base, bit, st.bit_end, clt);
+            const uint64_t m = __ballot(ok);
+            if (m) hit = st.bit_from + q2[b + (uint32_t)__builtin_ctzll(m)];
         }
+        n2 = 0;
+    };
+    auto stage2 = [&](uint32_t count) {  // the first `count` queued survivors of stage 1 (<= 64)
+        const bool have = lane < count;
+        const uint32_t off = have ? q1[lane] : 0u;
+        const bool ok = have && gz_stage2(st.base, st.bit_from + off);
+        const uint64_t m = __ballot(ok);
+        if (ok) q2[n2 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = off;
+        n2 += (uint32_t)__popcll(m);
+        // the rest of the queue moves up
+        const uint32_t rest = n1 - count;
+        const uint32_t a = lane < rest ? q1[count + lane] : 0u, b2 = 64 + lane < rest ? q1[count + 64 + lane] : 0u;
+        if (lane < rest) q1[lane] = a;
+        if (64 + lane < rest) q1[64 + lane] = b2;
+        n1 = rest;
+    };
+#pragma unroll 1
+    for (uint64_t at = 0; at < span && hit == ~0ull; at += 64) {
+        const uint64_t off = at + lane;
+        const bool ok = off < span && gz_stage1(st.base, st.bit_from + off, st.bit_end);
+        const uint64_t m = __ballot(ok);
+        if (ok) q1[n1 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)off;
+        n1 += (uint32_t)__popcll(m);
+        if (n1 >= 64) {
+            stage2(64);
+            if (n2 >= GZ_Q2_RUN) stage3();
+        }
+    }
+    if (hit == ~0ull) {  // what is still queued (ascending: anything here lies behind every offset checked so far)
+        if (n1) stage2(n1 > 64 ? 64 : n1);
+        stage3();
+        if (n1 && hit == ~0ull) stage2(n1);
+        if (hit == ~0ull) stage3();
+    } else {
+        // a hit: queued survivors of stage 1 / 2 in FRONT of it were all checked (the queues are worked off in order, and stage 3 takes
+        // the first of its batch) -- except those of stage 1 still waiting, which lie behind every entry of q2: none can be smaller
     }
     if (lane == 0) found[i] = hit;
 }
@@ -833,7 +900,29 @@ qd_gz::qd_gz() : p_(new qd_gz_impl()) {}
 qd_gz::~qd_gz() { delete p_; }
 qd_gz_stats qd_gz::stats() const { return p_->st_; }
 
-hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st) {
+hipError_t qd_gz::reserve(uint64_t comp_bytes, uint64_t text_bytes) {
+    qd_gz_impl& G = *p_;
+    const uint64_t stretch = std::max<uint64_t>(stretch_bytes, 256), n_st = comp_bytes / stretch + 64, n_units = text_bytes / std::max<uint64_t>(unit_text, 1024) + n_st / 8 + 64;
+    GZCHK(G.d_tokens.need((size_t)std::min<uint64_t>(comp_bytes * 16 + n_st * 8192, 0xFFFF0000ull * 2)));
+    GZCHK(G.d_sym.need((size_t)text_bytes * 2 + 4096));
+    GZCHK(G.d_stretch.need((size_t)n_st * sizeof(GzStretch)));
+    GZCHK(G.d_found.need((size_t)n_st * 8));
+    GZCHK(G.d_units.need((size_t)n_st * sizeof(qd3::Unit)));
+    GZCHK(G.d_res.need((size_t)n_st * sizeof(qd3::Result)));
+    GZCHK(G.d_lens.need((size_t)n_st * qd3::LENS_DW * 4));
+    GZCHK(G.d_use.need((size_t)n_st * 4));
+    GZCHK(G.d_wout.need((size_t)n_units * GZ_WIN * 2));
+    GZCHK(G.d_winin.need((size_t)n_units * GZ_WIN));
+    GZCHK(G.d_tiles.need((size_t)(text_bytes / GZ_FIX_TILE + n_units + 64) * sizeof(GzFixTile)));
+    GZCHK(G.d_ranges.need((size_t)(text_bytes / 65536 + n_units + 64) * sizeof(qd_crc_range) + (n_units + 1) * 4 + 512));
+    GZCHK(G.d_crc.need((size_t)(text_bytes / 65536 + 2 * n_units + 64) * 4));
+    GZCHK(G.h_found.need((size_t)n_st * sizeof(GzStretch)));
+    GZCHK(G.h_res.need((size_t)n_st * sizeof(qd3::Unit)));
+    GZCHK(G.h_up.need((size_t)n_st * (sizeof(qd3::Unit) + 4) + (size_t)n_units * 64 + (size_t)(text_bytes / GZ_FIX_TILE + text_bytes / 65536) * 16 + 65536));
+    return hipSuccess;
+}
+
+hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st, int slots_per_byte) {
     qd_gz_impl& G = *p_;
     const uint64_t STRETCH = std::max<uint64_t>(stretch_bytes, 256);
     G.acc_.assign((size_t)n, qd_gz_impl::Acc());
@@ -847,6 +936,7 @@ hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st) {
         s.bit_next = s.bit_start;
         s.member_end = 0;
         s.failed = 0;
+        s.starved = 0;
         s.crc32 = 0;
         if (((uintptr_t)s.comp & 15u) || s.bit_start >= 8 * s.comp_bytes) {
             if ((uintptr_t)s.comp & 15u) s.failed = QD_INFLATE_TRUNCATED;
@@ -872,7 +962,7 @@ hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st) {
         GZCHK(G.h_found.need(probe.size() * std::max(sizeof(GzStretch), (size_t)8)));
         memcpy(G.h_found.p, probe.data(), probe.size() * sizeof(GzStretch));
         GZCHK(hipMemcpyAsync(G.d_stretch.p, G.h_found.p, probe.size() * sizeof(GzStretch), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(gz_probe, dim3((uint32_t)probe.size()), dim3(64), 64 * 128, st, G.d_stretch.as<GzStretch>(), (uint32_t)probe.size(), G.d_found.as<uint64_t>());
+        hipLaunchKernelGGL(gz_probe, dim3((uint32_t)probe.size()), dim3(64), 64 * 128 + 256 * 4, st, G.d_stretch.as<GzStretch>(), (uint32_t)probe.size(), G.d_found.as<uint64_t>());
         GZCHK(hipGetLastError());
         GZCHK(hipStreamSynchronize(st));  // (the table above has been read: the staging buffer takes the answer)
         GZCHK(hipMemcpyAsync(G.h_found.p, G.d_found.p, probe.size() * 8, hipMemcpyDeviceToHost, st));
@@ -890,7 +980,24 @@ hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st) {
         if (n_st[(size_t)i]) starts[(size_t)i].push_back(steps[i].bit_start);
     for (size_t q = 0; q < probe.size(); ++q)
         if (found[q] != ~0ull) starts[(size_t)probe_of[q].first].push_back(found[q]);
-    auto make_unit = [&](const qd_gz_step& s, uint64_t start, uint64_t stop, uint64_t tok_off, uint32_t cap) {
+    // the streams' candidates on the device: a unit that runs past a false one stops at the next that is a block boundary
+    std::vector<uint64_t> cand_all;
+    std::vector<size_t> cand_at((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        std::vector<uint64_t>& v = starts[(size_t)i];
+        std::sort(v.begin(), v.end());
+        cand_at[(size_t)i] = cand_all.size();
+        cand_all.insert(cand_all.end(), v.begin(), v.end());
+    }
+    cand_at[(size_t)n] = cand_all.size();
+    GZCHK(G.d_found.need(std::max<size_t>(cand_all.size(), probe.size()) * 8 + 64));
+    GZCHK(G.h_found.need(std::max<size_t>(cand_all.size() * 8, probe.size() * std::max(sizeof(GzStretch), (size_t)8)) + 64));
+    if (!cand_all.empty()) {
+        memcpy(G.h_found.p, cand_all.data(), cand_all.size() * 8);
+        GZCHK(hipMemcpyAsync(G.d_found.p, G.h_found.p, cand_all.size() * 8, hipMemcpyHostToDevice, st));
+    }
+    auto make_unit = [&](int i, uint64_t start, uint64_t stop, uint64_t tok_off, uint32_t cap) {
+        const qd_gz_step& s = steps[i];
         qd3::Unit u;
         u.base = reinterpret_cast<const uint32_t*>(s.comp);
         u.bit_start = start;
@@ -899,26 +1006,34 @@ hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st) {
         u.tok_off = tok_off;
         u.tok_cap = cap;
         u.wend = (uint32_t)std::min<uint64_t>((s.comp_bytes + 3) / 4 + 80, 0xFFFFFFF0u);
+        u.cands = G.d_found.as<uint64_t>() + cand_at[(size_t)i];
+        u.n_cands = (uint32_t)(cand_at[(size_t)i + 1] - cand_at[(size_t)i]);
+        u.pad = 0;
         return u;
     };
+    // Four slots per byte of the stretch: fastq makes at most two, so a unit may run on through a neighbour whose start was a false
+    // candidate.  (A code has at least one bit and a token at most two slots: eight always hold -- the second try for text that
+    // compresses beyond that, one symbol repeated under a Huffman-only coder.  A launch's slots are indexed with 32 bits: at four a
+    // byte it takes a gigabyte of compressed bytes.)
+    const uint64_t per_byte = slots_per_byte >= 8 ? 8 : 4;
     auto cap_for = [&](const qd_gz_step& s, uint64_t start, uint64_t stop) {
         const uint64_t bytes = ((stop == ~0ull ? 8 * s.comp_bytes : stop) - start + 7) / 8;
-        return (uint32_t)std::min<uint64_t>((4 * bytes + 4096 + 3) & ~(uint64_t)3, 1u << 28);
+        return (uint32_t)std::min<uint64_t>((per_byte * bytes + 4096 + 3) & ~(uint64_t)3, 1u << 29);
     };
     G.units_.clear();
     std::vector<std::pair<int, uint32_t>> unit_of;  // unit -> (step, index among the step's starts)
     uint64_t tok_total = 0;
     for (int i = 0; i < n; ++i) {
         std::vector<uint64_t>& v = starts[(size_t)i];
-        std::sort(v.begin(), v.end());
         for (size_t k = 0; k < v.size(); ++k) {
             const uint64_t stop = k + 1 < v.size() ? v[k + 1] : ~0ull;
             const uint32_t cap = cap_for(steps[i], v[k], stop);
             if (tok_total + cap >= 0xFFFF0000ull) {  // a launch's slots are indexed with 32 bits: what does not fit waits for the next step
                 v.resize(k);
+                steps[i].starved = 1;
                 break;
             }
-            G.units_.push_back(make_unit(steps[i], v[k], stop, tok_total, cap));
+            G.units_.push_back(make_unit(i, v[k], stop, tok_total, cap));
             unit_of.push_back({i, (uint32_t)k});
             tok_total += cap;
         }
@@ -927,77 +1042,24 @@ hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st) {
     }
     if (G.units_.empty()) return hipSuccess;
     const size_t nu0 = G.units_.size();
-    // 3. tokens; a unit that ran past its stop position (no block starts there: the candidate was not one) runs again to the next
+    // 3. tokens: one launch
     std::vector<qd3::Result> res(nu0);
-    std::vector<uint8_t> dropped(nu0, 0);  // units whose start was not proven
-    auto run_units = [&](const std::vector<uint32_t>& which) -> hipError_t {
-        const size_t m = which.size();
-        std::vector<qd3::Unit> batch(m);
-        for (size_t q = 0; q < m; ++q) batch[q] = G.units_[which[q]];
-        GZCHK(G.d_units.need(m * sizeof(qd3::Unit)));
-        GZCHK(G.d_res.need(m * sizeof(qd3::Result)));
-        GZCHK(G.d_lens.need(m * qd3::LENS_DW * 4));
-        GZCHK(G.d_tokens.need((size_t)tok_total * 2 + 64));
-        GZCHK(G.h_res.need(m * std::max(sizeof(qd3::Unit), sizeof(qd3::Result))));
-        memcpy(G.h_res.p, batch.data(), m * sizeof(qd3::Unit));
-        GZCHK(hipMemcpyAsync(G.d_units.p, G.h_res.p, m * sizeof(qd3::Unit), hipMemcpyHostToDevice, st));
-        GZCHK(launch_tokens<CfgA>(G.d_units.as<qd3::Unit>(), nullptr, (uint32_t)m, G.d_tokens.as<uint16_t>(), G.d_lens.as<uint32_t>(), G.d_res.as<qd3::Result>(), st));
-        GZCHK(hipStreamSynchronize(st));
-        GZCHK(hipMemcpyAsync(G.h_res.p, G.d_res.p, m * sizeof(qd3::Result), hipMemcpyDeviceToHost, st));
-        GZCHK(hipStreamSynchronize(st));
-        for (size_t q = 0; q < m; ++q) res[which[q]] = G.h_res.as<qd3::Result>()[q];
-        return hipSuccess;
-    };
+    std::vector<uint8_t> dropped(nu0, 0);  // units whose start turned out to be no block boundary (their predecessor ran through them)
     {
-        std::vector<uint32_t> all(nu0);
-        for (size_t q = 0; q < nu0; ++q) all[q] = (uint32_t)q;
-        GZCHK(run_units(all));
+        GZCHK(G.d_units.need(nu0 * sizeof(qd3::Unit)));
+        GZCHK(G.d_res.need(nu0 * sizeof(qd3::Result)));
+        GZCHK(G.d_lens.need(nu0 * qd3::LENS_DW * 4));
+        GZCHK(G.d_tokens.need((size_t)tok_total * 2 + 64));
+        GZCHK(G.h_res.need(nu0 * std::max(sizeof(qd3::Unit), sizeof(qd3::Result))));
+        memcpy(G.h_res.p, G.units_.data(), nu0 * sizeof(qd3::Unit));
+        GZCHK(hipMemcpyAsync(G.d_units.p, G.h_res.p, nu0 * sizeof(qd3::Unit), hipMemcpyHostToDevice, st));
+        GZCHK(launch_tokens<CfgA>(G.d_units.as<qd3::Unit>(), nullptr, (uint32_t)nu0, G.d_tokens.as<uint16_t>(), G.d_lens.as<uint32_t>(), G.d_res.as<qd3::Result>(), st));
+        GZCHK(hipStreamSynchronize(st));
+        GZCHK(hipMemcpyAsync(G.h_res.p, G.d_res.p, nu0 * sizeof(qd3::Result), hipMemcpyDeviceToHost, st));
+        GZCHK(hipStreamSynchronize(st));
+        memcpy(res.data(), G.h_res.p, nu0 * sizeof(qd3::Result));
     }
     G.st_.units += (int64_t)nu0;
-    for (int iter = 0; iter < 6; ++iter) {
-        std::vector<uint32_t> redo;
-        for (size_t q = 0; q < nu0; ++q) {
-            if (!dropped[q] && res[q].status == QD_INFLATE_TOKEN_SPACE && G.units_[q].tok_cap < 8 * ((cap_for(steps[unit_of[q].first], G.units_[q].bit_start, G.units_[q].bit_stop) - 4096) / 4)) {
-                // text that compresses beyond four tokens a byte (one symbol repeated under a Huffman-only coder): a code has at least
-                // one bit and a token at most two slots -- eight slots a byte always hold
-                qd3::Unit& u = G.units_[q];
-                const uint64_t cap8 = 2ull * (cap_for(steps[unit_of[q].first], u.bit_start, u.bit_stop) - 4096) + 4096;
-                if (cap8 < (1u << 30) && tok_total + cap8 < 0xFFFF0000ull) {
-                    u.tok_off = tok_total;
-                    u.tok_cap = (uint32_t)cap8;
-                    tok_total += cap8;
-                    redo.push_back((uint32_t)q);
-                }
-                continue;
-            }
-            if (dropped[q] || res[q].status != QD_INFLATE_CHAIN) continue;
-            // the next unit of the same step that is still alive was started from a false candidate: this one takes its stretch over
-            size_t nx = q + 1;
-            while (nx < nu0 && unit_of[nx].first == unit_of[q].first && dropped[nx]) ++nx;
-            if (nx >= nu0 || unit_of[nx].first != unit_of[q].first) break;  // (cannot happen: the last unit has no stop position)
-            dropped[nx] = 1;
-            qd3::Unit& u = G.units_[q];
-            u.bit_stop = G.units_[nx].bit_stop;
-            const uint32_t cap = cap_for(steps[unit_of[q].first], u.bit_start, u.bit_stop);
-            if (tok_total + cap >= 0xFFFF0000ull) {
-                steps[unit_of[q].first].failed = QD_INFLATE_TOKEN_SPACE;
-                continue;
-            }
-            u.tok_off = tok_total;
-            u.tok_cap = cap;
-            tok_total += cap;
-            redo.push_back((uint32_t)q);
-        }
-        if (redo.empty()) break;
-        G.st_.chain_retries += (int64_t)redo.size();
-        // (the token buffer may have to grow: the earlier units' tokens must survive -- a rare path: everything is decoded again)
-        if ((size_t)tok_total * 2 + 64 > G.d_tokens.cap) {
-            redo.clear();
-            for (size_t q = 0; q < nu0; ++q)
-                if (!dropped[q]) redo.push_back((uint32_t)q);
-        }
-        GZCHK(run_units(redo));
-    }
     static const bool debug = getenv("QUADE_GZ_DEBUG") != nullptr;
     if (debug) {
         size_t n_found = 0;
@@ -1010,7 +1072,7 @@ hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st) {
                         res[q].status, res[q].final_seen, res[q].n_slots, res[q].text_len, (unsigned long long)res[q].bit_next, (unsigned long long)res[q].blk_bit, res[q].blk_slots,
                         res[q].blk_text);
     }
-    // 4. the chain from every stream's true start
+    // 4. the chain from every stream's true start: a unit counts when it began exactly where its predecessor stopped
     for (int i = 0; i < n; ++i) {
         qd_gz_step& s = steps[i];
         if (s.failed || !n_st[(size_t)i]) continue;
@@ -1018,14 +1080,20 @@ hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st) {
         uint64_t at = s.bit_start;
         bool stop_here = false;
         for (size_t q = 0; q < nu0 && !stop_here; ++q) {
-            if (unit_of[q].first != i || dropped[q]) continue;
+            if (unit_of[q].first != i) continue;
             const qd3::Unit& u = G.units_[q];
             const qd3::Result& r = res[q];
-            if (u.bit_start != at) {  // (cannot happen: every unit stops where the next live one starts)
+            if (u.bit_start < at) {  // its predecessor ran through this start: no block began there
+                dropped[q] = 1;
+                ++G.st_.chain_retries;
+                continue;
+            }
+            if (u.bit_start != at) {  // (cannot happen: a unit stops on one of the stream's candidates, and all of them are units)
                 s.failed = QD_INFLATE_CHAIN;
                 break;
             }
-            if (r.status == 0 && (r.final_seen || r.bit_next == u.bit_stop)) {
+            const bool last = u.bit_stop == ~0ull;
+            if (r.status == 0 && (r.final_seen || (!last && r.bit_next >= u.bit_stop && r.bit_next <= u.bit_end))) {
                 A.stretch.push_back((uint32_t)q);
                 A.use_slots.push_back(r.n_slots);
                 A.text.push_back(r.text_len);
@@ -1037,23 +1105,22 @@ hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st) {
                 }
                 continue;
             }
-            if (u.bit_stop == ~0ull) {  // the step's last unit ran out of input (or of room) inside a block: up to the last block boundary it passed
-                if (r.blk_bit > u.bit_start) {
-                    A.stretch.push_back((uint32_t)q);
-                    A.use_slots.push_back(r.blk_slots);
-                    A.text.push_back(r.blk_text);
-                    s.text_len += r.blk_text;
-                    at = r.blk_bit;
-                    ++G.st_.partial_last;
-                } else if (at == s.bit_start && (s.at_end || r.status == QD_INFLATE_TABLE_SPACE || r.status == QD_INFLATE_TOKEN_SPACE)) {
-                    s.failed = (int32_t)(r.status ? r.status : QD_INFLATE_TRUNCATED);  // nothing decoded, and more input will not help
-                }
-                stop_here = true;
-                continue;
+            // it ran out of input (or of room) inside a block -- the step's last unit, or one that ran through every later candidate:
+            // up to the last block boundary it passed
+            const bool ran_out = r.status == QD_INFLATE_TRUNCATED || r.status == QD_INFLATE_TOKEN_SPACE || last;
+            if (ran_out && r.blk_bit > u.bit_start) {
+                A.stretch.push_back((uint32_t)q);
+                A.use_slots.push_back(r.blk_slots);
+                A.text.push_back(r.blk_text);
+                s.text_len += r.blk_text;
+                at = r.blk_bit;
+                ++G.st_.partial_last;
+            } else if (at == s.bit_start && (s.at_end || !ran_out || r.status == QD_INFLATE_TABLE_SPACE || r.status == QD_INFLATE_TOKEN_SPACE)) {
+                s.failed = (int32_t)(r.status ? r.status : QD_INFLATE_TRUNCATED);  // nothing decoded, and more input will not help
             }
-            // a unit in the middle, from a proven start, that does not decode: the stream is damaged there (or beyond what a lane's tables hold)
-            if (at == s.bit_start) s.failed = (int32_t)r.status;
-            stop_here = true;  // (else: what was proven so far counts, the next step fails at the damage and says so)
+            // (a unit from a proven start that does not decode: what was proven so far counts; the next step starts at the damage, makes
+            //  no progress there and gives the stream up)
+            stop_here = true;
         }
         s.bit_next = at;
         if (debug)
@@ -1065,6 +1132,11 @@ hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st) {
             s.member_end = 0;
             A = qd_gz_impl::Acc();
         }
+    }
+    if (per_byte < 8) {
+        bool again = false;
+        for (int i = 0; i < n; ++i) again = again || steps[i].failed == QD_INFLATE_TOKEN_SPACE;
+        if (again) return decode(steps, n, st, 8);  // (everything once more: rare -- text that compresses beyond four tokens a byte)
     }
     return hipSuccess;
 }

@@ -50,7 +50,7 @@ namespace {
 
 constexpr size_t SEG_BYTES = 16u << 20;  // bytes per upload (compressed blocks or text)
 constexpr size_t SEG_TEXT_MAX = 128u << 20;  // text one BGZF upload inflates to at most (a buffer of blocks that hold more goes out in several)
-constexpr int RING_SLOTS = 48;           // device ring per stream: how far a feeder runs ahead of the kernels
+constexpr int RING_SLOTS = 64;           // device ring per stream: how far a feeder runs ahead of the kernels (a 2 M-pair batch of 2 x 150 bp takes ~24 uploads)
 constexpr int PIN_SLOTS = 3;             // page-locked upload buffers per stream
 constexpr uint32_t PIECE_BYTES = 1u << 20;       // text per gzip member at most (piece_bytes_for)
 constexpr size_t WINDOW_MAX = (size_t)1 << 30;   // text per stream and batch (offsets are 32 bit)
@@ -992,7 +992,7 @@ int window_room(qd_pipe* p, Window& w, size_t extra) {
 }
 
 constexpr uint32_t LAUNCH_BLOCKS3 = 32768;  // blocks per launch of the third inflater at most (sizes its token scratch: 131 KB a block)
-constexpr size_t FLUSH_SEGMENTS3 = RING_SLOTS / 2;  // uploads one window may queue before a launch frees their ring slots
+constexpr size_t FLUSH_SEGMENTS3 = RING_SLOTS * 3 / 4;  // uploads one window may queue before a launch frees their ring slots
 
 // the third inflater: everything queued goes down in one launch (more when it exceeds LAUNCH_BLOCKS3), every window's blocks are checked
 int flush_inflate3(qd_pipe* p) {
@@ -1296,9 +1296,8 @@ int gz_steps(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chun
             g.need_header = false;
         }
         if (g.bit >= 8 * (g.comp_off + g.comp_len)) continue;  // nothing of it on the device yet
-        if (g.stepped_end == g.comp_off + g.comp_len && g.stepped_done == g.file_done) continue;  // nothing new since the last step
-        g.stepped_end = g.comp_off + g.comp_len;
-        g.stepped_done = g.file_done;
+        // (a step that made no progress -- the bytes on the device end inside a block -- is not tried again until more have arrived)
+        if (g.stepped_end == g.comp_off + g.comp_len && g.stepped_done == g.file_done) continue;
         qd_gz_step st{};
         const uint64_t byte0 = ((g.bit >> 3) - g.comp_off) & ~(uint64_t)15;
         st.comp = g.comp[g.ccur].p + byte0;
@@ -1354,6 +1353,10 @@ int gz_steps(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chun
         }
         g.carried_valid = st.carried_valid;
         const bool progress = st.bit_next != st.bit_start || st.member_end;
+        if (!progress && !st.starved) {
+            g.stepped_end = g.comp_off + g.comp_len;
+            g.stepped_done = g.file_done;
+        }
         g.bit = 8 * (g.comp_off + byte0s[(size_t)i]) + st.bit_next;
         if (st.member_end) {  // the trailer: CRC-32 and ISIZE of the member's text
             const uint64_t tr = (g.bit + 7) >> 3;
@@ -1371,7 +1374,7 @@ int gz_steps(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chun
             g.need_header = true;
             g.hdr_off = tr + 8;
             g.bit = 8 * g.hdr_off;
-        } else if (!progress && g.file_done) {
+        } else if (!progress && g.file_done && !st.starved) {
             const int rc = gz_fallback(p, *feeders[(size_t)s], w, chunk);  // the stream ends inside a block: the host's reader reports it
             if (rc != QD_OK) return rc;
             continue;
@@ -1402,7 +1405,8 @@ int top_up(qd_pipe* p, Feeder& f, Window& w, int stream_index, int chunk, size_t
         if (w.gz.active) {
             // (an estimate of the text the compressed bytes on the device stand for: gz_steps will tell)
             const uint64_t held = 8 * (w.gz.comp_off + w.gz.comp_len) > w.gz.bit ? w.gz.comp_off + w.gz.comp_len - (w.gz.bit >> 3) : 0;
-            if (w.gz.file_done || (double)w.len + (double)held * w.gz.ratio >= (double)want) break;
+            const bool stuck = w.gz.stepped_end == w.gz.comp_off + w.gz.comp_len;  // (the last step could use none of what is held: more must come)
+            if (w.gz.file_done || (!stuck && (double)w.len + (double)held * w.gz.ratio >= (double)want)) break;
         }
         Segment s;
         {
@@ -1621,6 +1625,19 @@ int reserve_buffers(qd_pipe* p, uint32_t B, uint32_t n_dest) {
         PCHK(p, w.expect.need(blocks * 4, 0, p->cs));
         PCHK(p, w.status.need(blocks * 4, 0, p->cs));
         PCHK(p, w.crc.need(blocks * 4, 0, p->cs));
+    }
+    {  // ordinary gzip streams: the gzip kernels' buffers for a batch's steps, and the streams' compressed bytes
+        uint64_t comp = 0, text = 0;
+        for (int s = 0; s < p->n_streams; ++s) {
+            Window& w = p->win[s];
+            if (!w.gz.active) continue;
+            const double avg = w.avg > 0 ? w.avg : (s < 2 ? 400.0 : 64.0);
+            const uint64_t t = (uint64_t)((double)B * avg * 1.15) + (64u << 20), c = (uint64_t)((double)t / std::max(1.5, w.gz.ratio)) + 2 * SEG_BYTES;
+            comp += c;
+            text += t;
+            for (int k = 0; k < 2; ++k) PCHK(p, w.gz.comp[k].need((size_t)c + SEG_BYTES, k == w.gz.ccur ? (size_t)w.gz.comp_len : 0, p->cs));
+        }
+        if (comp && p->gz) PCHK(p, p->gz->reserve(comp, text));
     }
     if (p->inflate_form == 3) {  // a batch's blocks of all streams go down together: ~a block per 64 KiB of text
         size_t blocks3 = 0;
@@ -1939,7 +1956,20 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
         gz_close(w);
     }
     std::vector<size_t> want(ns, 1);  // first round: one upload, to learn the stream's bytes per record
-    for (;;) {
+    static const bool trace = getenv("QUADE_PIPE_TRACE") != nullptr;  // (debugging: one line per turn of the loop)
+    for (uint64_t turn = 0;; ++turn) {
+        if (trace && (turn < 60 || turn % 1000000 == 0)) {
+            fprintf(stderr, "[pipe] chunk %d turn %llu:", chunk, (unsigned long long)turn);
+            for (int s = 0; s < ns; ++s) {
+                const Window& w = p->win[s];
+                fprintf(stderr, " [%d len %u want %zu kept %u eof %d%s", s, w.len, want[s], w.res.n_kept, (int)w.eof, w.gz.active ? " gz" : "");
+                if (w.gz.active)
+                    fprintf(stderr, " comp %llu+%llu bit %llu hdr %d done %d host %d", (unsigned long long)w.gz.comp_off, (unsigned long long)w.gz.comp_len,
+                            (unsigned long long)w.gz.bit, (int)w.gz.need_header, (int)w.gz.file_done, w.gz.host ? 1 : 0);
+                fprintf(stderr, "]");
+            }
+            fprintf(stderr, "\n");
+        }
         // 1. text
         for (int s = 0; s < ns; ++s) {
             const int rc = top_up(p, *feeders[s], p->win[s], s, chunk, want[s]);

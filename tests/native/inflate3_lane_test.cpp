@@ -61,14 +61,15 @@ struct Run {
 };
 
 template <class C>
-static Run<C> run_unit(const std::vector<uint8_t>& comp, uint64_t bit_start, uint64_t bit_stop, uint32_t tok_cap) {
+static Run<C> run_unit(const std::vector<uint8_t>& comp, uint64_t bit_start, uint64_t bit_stop, uint32_t tok_cap, const std::vector<uint64_t>* cands = nullptr) {
     std::vector<uint32_t> words((comp.size() + 3) / 4 + 80, 0);  // (a lane's ring holds the 256 bytes behind its position)
     memcpy(words.data(), comp.data(), comp.size());
     std::vector<uint16_t> lds(2 * C::LANE_DW);
     std::vector<uint32_t> ring(qd3::RING_DW, 0xABABABAB), lens(qd3::LENS_DW, 0xDEADBEEF);
     Run<C> r;
     r.tok.assign(tok_cap + 8, 0xEEEE);
-    qd3::Unit u{words.data(), bit_start, bit_stop, (uint64_t)comp.size() * 8, 0, tok_cap, (uint32_t)((comp.size() + 3) / 4 + 80)};
+    qd3::Unit u{words.data(), bit_start, bit_stop, (uint64_t)comp.size() * 8, 0, tok_cap, (uint32_t)((comp.size() + 3) / 4 + 80), cands ? cands->data() : nullptr,
+                cands ? (uint32_t)cands->size() : 0u, 0};
     qd3::Lane<C> L;
     const uint32_t lane = 0;
     qd3::lane_init(L, u, r.tok.data(), lens.data());
@@ -155,9 +156,13 @@ static void check_stream(const char* what, const std::vector<uint8_t>& text, int
         std::vector<uint8_t> got2;
         CHECK(expand(all, (uint32_t)all.size(), got2));
         CHECK(got2 == text);
-        // a stop position that is no block boundary: the chain breaks, and is reported
-        Run<C> bad = run_unit<C>(comp, r.headers[0], r.headers[1] + 1, cap);
-        CHECK(bad.res.status == QD_INFLATE_CHAIN || bad.res.status == QD_INFLATE_TOKEN_SPACE);
+        // a stop position that is no block boundary: the unit goes on to the next candidate that is one (here: the third block's
+        // start, among candidates that are none), or to the stream's end without any
+        const std::vector<uint64_t> cands = {r.headers[1] + 1, r.headers[1] + 5, r.headers[2], r.headers[2] + 3};
+        Run<C> on = run_unit<C>(comp, r.headers[0], r.headers[1] + 1, cap, &cands);
+        CHECK(on.res.status == 0 && on.res.bit_next == r.headers[2] && !on.res.final_seen);
+        Run<C> through = run_unit<C>(comp, r.headers[0], r.headers[1] + 1, cap);
+        CHECK(through.res.status == 0 && through.res.final_seen && through.res.text_len == text.size());
     }
 }
 

@@ -40,3 +40,13 @@ def test_io_seams_of_the_pipeline_under_tsan(tmp_path):
     d.mkdir()
     r = subprocess.run([exe, str(d)], capture_output=True, text=True, timeout=900, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_inflate3_lane_decoder_against_zlib(tmp_path):
+    """tests/native/inflate3_lane_test.cpp: the third inflater's per-lane DEFLATE decoder (quade_amd/csrc/inflate3_lane.h compiles for the
+    host too) against zlib -- every block type, levels and strategies, the input ring's "only landed bytes are taken" rule, units cut at
+    block boundaries, a stop position that is no block boundary, damaged and truncated streams."""
+    exe = str(tmp_path / "inflate3_lane_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unknown-pragmas", "-o", exe, os.path.join(ROOT, "tests", "native", "inflate3_lane_test.cpp"), "-lz"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-2000:]
