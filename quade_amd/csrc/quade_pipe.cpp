@@ -1312,12 +1312,22 @@ int gz_steps(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chun
     }
     if (steps.empty()) return QD_OK;
     const int n = (int)steps.size();
+    static double t_decode = 0, t_room = 0, t_resolve = 0, t_sync = 0, t_post = 0;  // (QUADE_PIPE_TRACE: where a gzip step's wall time goes)
+    static const bool trace = getenv("QUADE_PIPE_TRACE") != nullptr;
+    struct Report {
+        ~Report() {
+            if (trace) fprintf(stderr, "[pipe] gzip steps so far: decode %.3f s, window room %.3f s, resolve (host side) %.3f s, sync + finish %.3f s, bookkeeping %.3f s\n",
+                               t_decode, t_room, t_resolve, t_sync, t_post);
+        }
+    } report;
     {
         Tick tick(p->st.wait_sync);
+        Tick t2(t_decode);
         PCHK(p, p->gz->decode(steps.data(), n, p->cs));
     }
     p->st.gzip_steps += n;
     std::vector<uint8_t*> out((size_t)n, nullptr);
+    std::unique_ptr<Tick> tk(new Tick(t_room));
     for (int i = 0; i < n; ++i) {
         Window& w = p->win[who[(size_t)i]];
         if (steps[(size_t)i].failed) continue;
@@ -1326,12 +1336,15 @@ int gz_steps(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chun
         if (rc != QD_OK) return rc;
         out[(size_t)i] = w.buf[w.cur].p + w.len;
     }
+    tk.reset(new Tick(t_resolve));
     PCHK(p, p->gz->resolve(steps.data(), n, out.data(), p->cs));
+    tk.reset(new Tick(t_sync));
     {
         const int rc = sync_compute(p);
         if (rc != QD_OK) return rc;
     }
     PCHK(p, p->gz->finish(steps.data(), n));
+    tk.reset(new Tick(t_post));
     for (int i = 0; i < n; ++i) {
         const int s = who[(size_t)i];
         Window& w = p->win[s];
@@ -1955,7 +1968,10 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
         w.pending_text = 0;
         gz_close(w);
     }
-    std::vector<size_t> want(ns, 1);  // first round: one upload, to learn the stream's bytes per record
+    std::vector<size_t> want(ns, 1);  // first round: one upload, to learn the stream's bytes per record ...
+    if (p->reserved)                  // ... unless the chunks before have told (a small first top-up is an inflate launch of its own)
+        for (int s = 0; s < ns; ++s)
+            if (p->win[s].avg > 0) want[s] = std::min<size_t>((size_t)((double)B * p->win[s].avg * 1.03) + 4096, WINDOW_MAX * 3 / 4);
     static const bool trace = getenv("QUADE_PIPE_TRACE") != nullptr;  // (debugging: one line per turn of the loop)
     for (uint64_t turn = 0;; ++turn) {
         if (trace && (turn < 60 || turn % 1000000 == 0)) {
