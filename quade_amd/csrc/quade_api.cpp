@@ -77,6 +77,7 @@ struct qd_ctx {
     int opt_wg_per_cu = 0;    // 0 = occupancy query
     int opt_force_generic = 0;
     int opt_block = 0;        // 0 = automatic
+    int opt_slot_factor = 0;  // 0 = automatic: QD_SLOT_FACTOR slots per barcode, half that for sample sheets whose image then fits a CU three times
     int opt_mol_strips = 1;   // LDS-staged molecular stores in the fast kernel
     int opt_kernel = 0;       // 0 = automatic, K_FAST / K_GENERIC
     QdKernelCache kcache;     // per-context launch memo (attribute set, occupancy)
@@ -172,12 +173,12 @@ void canon(const uint8_t* b, int len, u64 w[QD_KEY_WORDS]) {
 // worst-case probe sequence.  Returns slots (size mask+1).
 std::vector<uint32_t> build_slots(const std::vector<int>& ids, const std::vector<u64>& keys32,
                                   const std::vector<uint8_t>& blen, uint32_t& mask, uint32_t& seed,
-                                  const std::vector<u64>* packed16 = nullptr, uint32_t K = 0) {
+                                  const std::vector<u64>* packed16 = nullptr, uint32_t K = 0, uint32_t slot_factor = QD_SLOT_FACTOR) {
     // >= 4 slots per barcode (half that many cost +8 % on S = 1536 and +13 % on S = 96, twice as many nothing:
     // profiles/r02_slot_table_load.txt), and never fewer than 256: a dozen barcodes in 64 slots have every lane of
     // a wave probing the same few LDS words (S = 12: -7 % with 256 slots)
     uint32_t m = 256;
-    while (m < (uint32_t)QD_SLOT_FACTOR * (uint32_t)ids.size()) m <<= 1;
+    while (m < slot_factor * (uint32_t)ids.size()) m <<= 1;
     mask = m - 1;
     std::vector<uint32_t> best;
     uint32_t best_worst = ~0u;
@@ -285,8 +286,9 @@ int rebuild(qd_ctx* c) {
     }
     if (K > 16 && !wide) ids_fast.clear();
     c->wide = wide;
-    std::vector<uint32_t> sf = wide ? build_slots(ids_fast, k32, blen, c->mask_fast, c->seed_fast, &k16, (uint32_t)K)
-                                    : build_slots(ids_fast, k32, blen, c->mask_fast, c->seed_fast);
+    const uint32_t slot_factor = c->opt_slot_factor > 0 ? (uint32_t)c->opt_slot_factor : (uint32_t)QD_SLOT_FACTOR;
+    std::vector<uint32_t> sf = wide ? build_slots(ids_fast, k32, blen, c->mask_fast, c->seed_fast, &k16, (uint32_t)K, slot_factor)
+                                    : build_slots(ids_fast, k32, blen, c->mask_fast, c->seed_fast, nullptr, 0, slot_factor);
     std::vector<uint32_t> sg = build_slots(ids_gen, k32, blen, c->mask_gen, c->seed_gen);
 
     HIPCHK(c, hipMalloc(&c->d_slots_fast, sf.size() * 4));
@@ -634,6 +636,11 @@ int qd_set_option(qd_ctx* c, const char* name, int64_t value) {
             return fail(c, QD_ERR_INVALID, "fast_block must be 0, 256, 512 or 1024");
         c->opt_block = (int)value;
         return QD_OK;
+    }
+    if (!strcmp(name, "slot_factor")) {  // open-addressing slots per barcode of the fast kernel's table (before rounding up to a power of two)
+        if (value < 0 || value > 16) return fail(c, QD_ERR_INVALID, "slot_factor must be 0 (automatic) .. 16");
+        c->opt_slot_factor = (int)value;
+        return c->have_table ? rebuild(c) : QD_OK;
     }
     if (!strcmp(name, "mol_strips")) {
         c->opt_mol_strips = value != 0;

@@ -59,8 +59,11 @@ with torch.cuda.stream(st):
                             if xv:
                                 continue  # this build does not know the option: only its default arm runs
                     wq = wq * 10 + xv if xname else wq  # (shown in the wq column as <wq><value>)
-                    if wq or len(wqs) > 1:  # (older builds given through TUNE_LIBS do not know the option)
-                        e.set_option("work_queue", wq)
+                    if not xname and (wq or len(wqs) > 1):  # (the work-queue launch form was removed in r04: only builds given through TUNE_LIBS know it)
+                        try:
+                            e.set_option("work_queue", wq)
+                        except Exception:
+                            continue
                     for i in range(reps + 1):
                         a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         a.record(st)
