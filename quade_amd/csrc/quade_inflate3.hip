@@ -896,7 +896,11 @@ class qd_gz_impl {
     qd_gz_stats st_{};
 };
 
-qd_gz::qd_gz() : p_(new qd_gz_impl()) {}
+qd_gz::qd_gz() : p_(new qd_gz_impl()) {
+    const int st = env_int("QUADE_GZ_STRETCH_KB", 0), ut = env_int("QUADE_GZ_UNIT_KB", 0);  // (measurement knobs)
+    if (st > 0) stretch_bytes = (uint64_t)st << 10;
+    if (ut > 0) unit_text = (uint64_t)ut << 10;
+}
 qd_gz::~qd_gz() { delete p_; }
 qd_gz_stats qd_gz::stats() const { return p_->st_; }
 
