@@ -119,8 +119,7 @@ struct Lane {
     uint32_t n_cands;
     uint32_t* lens;  // LENS_DW dwords of scratch (global memory)
     uint32_t lim_l[C::NL], bas_l[C::NL], lim_d[C::ND], bas_d[C::ND];
-    uint16_t* tok;              // the launch's token buffer (wave-uniform): a lane's slots are tok[on0 .. on_end)
-    uint32_t on, on0, on_end;   // next slot, first slot, end of the region
+    uint32_t on, on0, on_end;   // next slot, first slot, end of the region in the launch's token buffer (a wave-uniform base: turn()'s `tok`)
     uint32_t text_len, pend, stored_left;
     uint32_t state, status, final_seen;
     uint64_t blk_bit;
@@ -476,7 +475,7 @@ QD3_HD void header(Lane<C>& L, uint16_t* tab, uint32_t* ring, uint32_t lane) {
 // profiles/r05_inflate3_first_form.txt).  The one branch left: a code longer than the first level.  Tokens leave as they are made
 // (a 2-byte store per literal, two per match, at the lane's own place: nothing is gathered in registers first).
 template <class C>
-QD3_HD void turn(Lane<C>& L, const uint16_t* tab, const uint32_t* ring, uint32_t lane) {
+QD3_HD void turn(Lane<C>& L, const uint16_t* tab, const uint32_t* ring, uint32_t lane, uint16_t* tok) {
     const uint32_t next_word = ring[ring_at(L.rd, lane)];
     const uint32_t lo32 = (uint32_t)L.buf;
     const bool dist = L.state == ST_DIST;
@@ -508,10 +507,10 @@ QD3_HD void turn(Lane<C>& L, const uint16_t* tab, const uint32_t* ring, uint32_t
     // the token: a literal is one slot; a match leaves when its distance is known, two slots
     const uint32_t ns = dist ? 2u : (is_lit ? 1u : 0u);
     const bool room = L.on + ns <= L.on_end;
-    if (is_lit && room) L.tok[L.on] = (uint16_t)val;
+    if (is_lit && room) tok[L.on] = (uint16_t)val;
     if (dist && room) {
-        L.tok[L.on] = (uint16_t)(TOK_MATCH | (L.pend - 3u));
-        L.tok[L.on + 1u] = (uint16_t)(value - 1u);
+        tok[L.on] = (uint16_t)(TOK_MATCH | (L.pend - 3u));
+        tok[L.on + 1u] = (uint16_t)(value - 1u);
     }
     L.on += room ? ns : 0u;
     L.text_len += dist ? L.pend : (is_lit ? 1u : 0u);
@@ -531,10 +530,10 @@ QD3_HD void turn(Lane<C>& L, const uint16_t* tab, const uint32_t* ring, uint32_t
 // A turn of a lane inside a stored block: a byte of it leaves as a literal (rare in fastq: a loop of its own, so that the turns
 // above do not carry it).
 template <class C>
-QD3_HD void turn_stored(Lane<C>& L, const uint32_t* ring, uint32_t lane) {
+QD3_HD void turn_stored(Lane<C>& L, const uint32_t* ring, uint32_t lane, uint16_t* tok) {
     const uint32_t next_word = ring[ring_at(L.rd, lane)];
     if (L.on < L.on_end) {
-        L.tok[L.on++] = (uint16_t)((uint32_t)L.buf & 255u);
+        tok[L.on++] = (uint16_t)((uint32_t)L.buf & 255u);
     } else {
         if (!L.status) L.status = QD_INFLATE_TOKEN_SPACE;
         L.state = ST_DONE;
@@ -550,7 +549,7 @@ QD3_HD void turn_stored(Lane<C>& L, const uint32_t* ring, uint32_t lane) {
 }
 
 template <class C>
-QD3_HD void lane_init(Lane<C>& L, const Unit& u, uint16_t* tokens, uint32_t* lens) {
+QD3_HD void lane_init(Lane<C>& L, const Unit& u, uint32_t* lens) {
     L.comp = u.base;
     L.clast = u.wend >= 4 ? (u.wend - 4) >> 2 : 0;
     L.bit_stop = u.bit_stop;
@@ -558,7 +557,6 @@ QD3_HD void lane_init(Lane<C>& L, const Unit& u, uint16_t* tokens, uint32_t* len
     L.cands = u.cands;
     L.n_cands = u.n_cands;
     L.lens = lens;
-    L.tok = tokens;
     L.on0 = L.on = (uint32_t)u.tok_off;  // (slot indices are 32 bit: a launch's token buffer holds less than 2^32 slots)
     L.on_end = L.on0 + u.tok_cap;
     L.text_len = L.pend = L.stored_left = 0;

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(64) void inflate3_tokens(const qd3::Unit* units, co
                 un = units[u];
             }
         }
-        qd3::lane_init(L, un, tokens, lens_scratch + (size_t)(u < n_units ? u : 0) * qd3::LENS_DW);
+        qd3::lane_init(L, un, lens_scratch + (size_t)(u < n_units ? u : 0) * qd3::LENS_DW);
         if (u >= n_units) {
             L.state = qd3::ST_DONE;
             L.status = 0;
@@ -91,13 +91,13 @@ __global__ __launch_bounds__(64) void inflate3_tokens(const qd3::Unit* units, co
         if (__ballot(L.state == qd3::ST_STORED)) {  // (stored blocks: byte soup, not fastq)
 #pragma unroll 1
             for (int t = 0; t < qd3::ROUND_TURNS; ++t) {
-                if (L.state == qd3::ST_STORED) qd3::turn_stored<C>(L, ring, lane);
-                else if (L.state <= qd3::ST_DIST) qd3::turn<C>(L, tab, ring, lane);
+                if (L.state == qd3::ST_STORED) qd3::turn_stored<C>(L, ring, lane, tokens);
+                else if (L.state <= qd3::ST_DIST) qd3::turn<C>(L, tab, ring, lane, tokens);
             }
         } else {
 #pragma unroll 1
             for (int t = 0; t < qd3::ROUND_TURNS; ++t)
-                if (L.state <= qd3::ST_DIST) qd3::turn<C>(L, tab, ring, lane);
+                if (L.state <= qd3::ST_DIST) qd3::turn<C>(L, tab, ring, lane, tokens);
         }
         if (mh) ++waited;
     }

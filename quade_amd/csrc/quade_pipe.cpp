@@ -658,6 +658,7 @@ struct qd_pipe {
     };
     // Option "device_gunzip" (default 1): ordinary gzip files are inflated on the device as well (qd_gz, quade_inflate3.hip)
     int device_gunzip = 1;
+    int inflate_overlap = 1;  // the third inflater's launches (and the gzip steps) on a stream of their own
     qd_gz* gz = nullptr;
     int64_t gz_units0 = 0;
     std::vector<qd_inflate3_job> q3_jobs;   // (out: the offset inside the window's text until the launch -- the buffer may still grow)
@@ -998,23 +999,36 @@ constexpr size_t FLUSH_SEGMENTS3 = RING_SLOTS * 3 / 4;  // uploads one window ma
 int flush_inflate3(qd_pipe* p) {
     if (p->q3_jobs.empty()) return QD_OK;
     const size_t n = p->q3_jobs.size();
+    // Option "inflate_overlap" (default 1): the launches go down a stream of their own, so that the token kernel of batch k + 1 -- a
+    // latency, two waves per CU -- shares the device with what batch k still has queued on the compute stream (format, coder); the
+    // windows' scans wait for the event (join_inflate).  It reads the upload ring and writes the windows' text behind what the carry
+    // copies (compute stream) move to their front: no overlap with anything queued there.
+    const hipStream_t xs = p->inflate_overlap ? p->is[0] : p->cs;
     for (const qd_pipe::Queued3& q : p->q3_parts) {
         Window& w = p->win[q.stream];
         for (uint32_t i = q.first; i < q.first + q.n; ++i) p->q3_jobs[i].out = w.buf[w.cur].p + reinterpret_cast<uintptr_t>(p->q3_jobs[i].out);
-        for (int slot : q.slots) PCHK(p, hipStreamWaitEvent(p->cs, q.feeder->ready(slot), 0));
+        for (int slot : q.slots) PCHK(p, hipStreamWaitEvent(xs, q.feeder->ready(slot), 0));
     }
     PCHK(p, p->jobs3.need(n * sizeof(qd_inflate3_job), 0, p->cs));
     PCHK(p, p->status3.need(n * 4, 0, p->cs));
     PCHK(p, p->scratch3.need(qd_inflate3_scratch_bytes((uint32_t)std::min<size_t>(n, LAUNCH_BLOCKS3)), 0, p->cs));
-    PCHK(p, p->stage.upload(p->jobs3.p, p->q3_jobs.data(), n * sizeof(qd_inflate3_job), p->cs));
+    PCHK(p, p->stage.upload(p->jobs3.p, p->q3_jobs.data(), n * sizeof(qd_inflate3_job), xs));
     for (size_t at = 0; at < n; at += LAUNCH_BLOCKS3) {
         const uint32_t m = (uint32_t)std::min<size_t>(LAUNCH_BLOCKS3, n - at);
-        PCHK(p, qd_launch_inflate3_jobs(p->jobs3.as<qd_inflate3_job>() + at, m, p->status3.as<int32_t>() + at, p->scratch3.p, p->cs));
+        PCHK(p, qd_launch_inflate3_jobs(p->jobs3.as<qd_inflate3_job>() + at, m, p->status3.as<int32_t>() + at, p->scratch3.p, xs));
     }
     for (const qd_pipe::Queued3& q : p->q3_parts) {
-        for (int slot : q.slots) PCHK(p, q.feeder->consumed(slot, p->cs));
+        for (int slot : q.slots) PCHK(p, q.feeder->consumed(slot, xs));
         const uint32_t* st = p->status3.as<uint32_t>() + q.first;  // (a block's CRC-32 is checked by its resolve kernel: the statuses say it all)
-        PCHK(p, qd_text_check_blocks(p->status3.as<int32_t>() + q.first, st, st, q.n, q.block_base, &p->d_res.as<qd_scan_result>()[q.stream].first_bad, p->cs));
+        PCHK(p, qd_text_check_blocks(p->status3.as<int32_t>() + q.first, st, st, q.n, q.block_base, &p->d_res.as<qd_scan_result>()[q.stream].first_bad, xs));
+    }
+    if (xs != p->cs) {
+        for (const qd_pipe::Queued3& q : p->q3_parts) {
+            Window& w = p->win[q.stream];
+            if (!w.inflated[0]) PCHK(p, hipEventCreateWithFlags(&w.inflated[0], hipEventDisableTiming));
+            PCHK(p, hipEventRecord(w.inflated[0], xs));
+            w.in_flight[0] = true;
+        }
     }
     p->q3_jobs.clear();
     p->q3_parts.clear();
@@ -1186,10 +1200,11 @@ int gz_append(qd_pipe* p, Feeder& f, Window& w, Segment& s) {
         }
     }
     if ((uint64_t)s.file_off != g.comp_off + g.comp_len) return pfail(p, QD_ERR_STATE, w.path + ": uploads out of order");
-    PCHK(p, g.comp[g.ccur].need((size_t)g.comp_len + s.bytes + 8192, (size_t)g.comp_len, p->cs));
-    PCHK(p, hipStreamWaitEvent(p->cs, f.ready(s.slot), 0));
-    PCHK(p, hipMemcpyAsync(g.comp[g.ccur].p + g.comp_len, f.ring() + (size_t)s.slot * SEG_BYTES, s.bytes, hipMemcpyDeviceToDevice, p->cs));
-    PCHK(p, f.consumed(s.slot, p->cs));
+    const hipStream_t gs = p->inflate_overlap ? p->is[1] : p->cs;  // (the gzip steps' stream: gz_steps)
+    PCHK(p, g.comp[g.ccur].need((size_t)g.comp_len + s.bytes + 8192, (size_t)g.comp_len, gs));
+    PCHK(p, hipStreamWaitEvent(gs, f.ready(s.slot), 0));
+    PCHK(p, hipMemcpyAsync(g.comp[g.ccur].p + g.comp_len, f.ring() + (size_t)s.slot * SEG_BYTES, s.bytes, hipMemcpyDeviceToDevice, gs));
+    PCHK(p, f.consumed(s.slot, gs));
     g.comp_len += s.bytes;
     return QD_OK;
 }
@@ -1312,6 +1327,10 @@ int gz_steps(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chun
     }
     if (steps.empty()) return QD_OK;
     const int n = (int)steps.size();
+    // A stream of their own ("inflate_overlap"): a step ends with the host waiting for its results, and on the compute stream that wait
+    // would include everything batch k still has queued there (format, coder).  What a step writes -- the windows' text behind what
+    // the carry copies move to their front -- nothing queued on the compute stream touches.
+    const hipStream_t gs = p->inflate_overlap ? p->is[1] : p->cs;
     static double t_decode = 0, t_room = 0, t_resolve = 0, t_sync = 0, t_post = 0;  // (QUADE_PIPE_TRACE: where a gzip step's wall time goes)
     static const bool trace = getenv("QUADE_PIPE_TRACE") != nullptr;
     struct Report {
@@ -1323,7 +1342,7 @@ int gz_steps(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chun
     {
         Tick tick(p->st.wait_sync);
         Tick t2(t_decode);
-        PCHK(p, p->gz->decode(steps.data(), n, p->cs));
+        PCHK(p, p->gz->decode(steps.data(), n, gs));
     }
     p->st.gzip_steps += n;
     std::vector<uint8_t*> out((size_t)n, nullptr);
@@ -1337,11 +1356,14 @@ int gz_steps(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chun
         out[(size_t)i] = w.buf[w.cur].p + w.len;
     }
     tk.reset(new Tick(t_resolve));
-    PCHK(p, p->gz->resolve(steps.data(), n, out.data(), p->cs));
+    PCHK(p, p->gz->resolve(steps.data(), n, out.data(), gs));
     tk.reset(new Tick(t_sync));
-    {
+    if (gs == p->cs) {
         const int rc = sync_compute(p);
         if (rc != QD_OK) return rc;
+    } else {
+        Tick tick(p->st.wait_sync);
+        PCHK(p, hipStreamSynchronize(gs));
     }
     PCHK(p, p->gz->finish(steps.data(), n));
     tk.reset(new Tick(t_post));
@@ -1397,8 +1419,8 @@ int gz_steps(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chun
         if (keep_from) {
             const uint64_t left = g.comp_len - keep_from;
             const int nx = g.ccur ^ 1;
-            PCHK(p, g.comp[nx].need((size_t)left + 8192, 0, p->cs));
-            if (left) PCHK(p, hipMemcpyAsync(g.comp[nx].p, g.comp[g.ccur].p + keep_from, (size_t)left, hipMemcpyDeviceToDevice, p->cs));
+            PCHK(p, g.comp[nx].need((size_t)left + 8192, 0, gs));
+            if (left) PCHK(p, hipMemcpyAsync(g.comp[nx].p, g.comp[g.ccur].p + keep_from, (size_t)left, hipMemcpyDeviceToDevice, gs));
             g.ccur = nx;
             g.comp_off += keep_from;
             g.comp_len = left;
@@ -2338,6 +2360,7 @@ int qd_pipe_create(qd_ctx* ctx, qd_pipe** out) {
     p->n_streams = 2 + L.n_streams;
     if (const char* e = getenv("QUADE_PIPE_INFLATE_FORM")) p->inflate_form = atoi(e) == 2 ? 2 : 3;  // (measurement: A/B of the inflaters inside the pipeline)
     if (const char* e = getenv("QUADE_PIPE_DEVICE_GUNZIP")) p->device_gunzip = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("QUADE_PIPE_INFLATE_OVERLAP")) p->inflate_overlap = atoi(e) ? 1 : 0;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&p->cs, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&p->ds, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&p->is[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p->is[1], hipStreamNonBlocking) != hipSuccess ||
@@ -2362,6 +2385,7 @@ int qd_pipe_set_option(qd_pipe* p, const char* name, int64_t value) {
     else if (n == "inflate_streams" && (value == 1 || value == 2)) p->n_is = (int)value;
     else if (n == "inflate_form" && (value == 2 || value == 3)) p->inflate_form = (int)value;
     else if (n == "device_gunzip" && (value == 0 || value == 1)) p->device_gunzip = (int)value;
+    else if (n == "inflate_overlap" && (value == 0 || value == 1)) p->inflate_overlap = (int)value;
     else return pfail(p, QD_ERR_INVALID, "unknown option " + n);
     return QD_OK;
 }

@@ -72,7 +72,7 @@ static Run<C> run_unit(const std::vector<uint8_t>& comp, uint64_t bit_start, uin
                 cands ? (uint32_t)cands->size() : 0u, 0};
     qd3::Lane<C> L;
     const uint32_t lane = 0;
-    qd3::lane_init(L, u, r.tok.data(), lens.data());
+    qd3::lane_init(L, u, lens.data());
     qd3::topup(L, ring.data(), lane, true);
     qd3::ring_wait();
     qd3::landed_all(L);
@@ -103,8 +103,8 @@ static Run<C> run_unit(const std::vector<uint8_t>& comp, uint64_t bit_start, uin
                 w = 0x5A5A5A5A;
             }
         for (int t = 0; t < qd3::ROUND_TURNS && L.state <= qd3::ST_STORED; ++t) {
-            if (L.state == qd3::ST_STORED) qd3::turn_stored<C>(L, ring.data(), lane);
-            else qd3::turn<C>(L, lds.data(), ring.data(), lane);
+            if (L.state == qd3::ST_STORED) qd3::turn_stored<C>(L, ring.data(), lane, r.tok.data());
+            else qd3::turn<C>(L, lds.data(), ring.data(), lane, r.tok.data());
             if (L.rd > 4 * landed) {
                 printf("FAIL: a turn took dword %u, landed %u chunks\n", L.rd, landed);
                 ++g_fail;
