@@ -445,6 +445,14 @@ int qd_sink_device_members(qd_sink* sink, int64_t* device_members); /* of qd_sin
 int qd_dev_gunzip(int device_id, const uint8_t* gz, int64_t gz_len, uint8_t* out, int64_t out_cap, int64_t* out_len, int64_t step_bytes,
                   int64_t stretch_bytes, int64_t unit_text, int64_t* stats);
 
+/* ---- device buffers kept across pipelines (ABI v6) -------------------------------------------------------------------
+ * No counterpart in the reference (its buffers are Python objects).  The large device buffers of a pipeline -- windows, token slots,
+ * upload rings -- go to a per-device free list of the process when the pipeline is destroyed, and the next pipeline is served from
+ * it: hipMalloc of ~25 GB takes between 50 ms and over a second on this pool's boxes, which a process that runs several jobs pays
+ * once.  The list holds at most QUADE_POOL_GB gigabytes (environment; default 64, 0 = no list).  qd_pool_trim gives everything on
+ * the list back to the driver (memory in use by live objects is not touched); always QD_OK. */
+int qd_pool_trim(void);
+
 /* ---- device-resident chunk pipeline (ABI v5) ---------------------------------------------------------------------
  * Replaces, for whole chunks, the per-pair loop of Quade.double_index_parser / simple_index_parser and everything it
  * calls (src/Quade.py:195-254: four FastqReader.next(), slice + fuse, Sample.FINDER; src/FastqWriter.py:48-90: name tag,

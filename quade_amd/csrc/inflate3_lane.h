@@ -50,14 +50,26 @@ namespace qd3 {
 enum : uint32_t { ST_LIT = 0, ST_DIST = 1, ST_STORED = 2, ST_HEADER = 3, ST_DONE = 4 };
 enum : uint32_t { TOK_MATCH = 0x8000u };  // slot: literal byte | TOK_MATCH + (length - 3), followed by a slot distance - 1 (< 0x8000)
 
-template <int LB_, int DB_, int NLONG_>
+// LB / DB: bits of the two first-level tables; NLONG: symbols with longer codes (both codes together); DBYTE: the distance table's
+// entries are bytes (bits | symbol << 3) instead of 16-bit ones; CHUNKS: 16-byte chunks of its stream a lane keeps in the wave's
+// ring; TURNS: turns between two top-ups of the ring.
+template <int LB_, int DB_, int NLONG_, bool DBYTE_ = false, int CHUNKS_ = 16, int TURNS_ = 24>
 struct Cfg {
     static constexpr int LB = LB_, DB = DB_, NLONG = NLONG_;
+    static constexpr bool DBYTE = DBYTE_;
     static constexpr int LIT_N = 1 << LB, DST_N = 1 << DB;
-    static constexpr int LANE_DW = ((LIT_N + DST_N + NLONG + 1) / 2) | 1;  // dwords of LDS per lane (odd)
-    static constexpr int NL = 15 - LB, ND = 15 - DB;                        // code lengths behind the first level
-    static_assert(DB >= 6, "the code-length code's 128-byte table borrows the distance table's space");
+    static constexpr int DST_HW = DBYTE ? DST_N / 2 : DST_N;                  // 16-bit units the distance table takes
+    static constexpr int LANE_DW = ((LIT_N + DST_HW + NLONG + 1) / 2) | 1;    // dwords of LDS per lane (odd)
+    static constexpr int NL = 15 - LB, ND = 15 - DB;                          // code lengths behind the first level
+    static constexpr int RING_CHUNKS = CHUNKS_;
+    static constexpr int RING_DW = RING_CHUNKS * 256;  // dwords of a wave's ring: slot j = [256 j, 256 (j + 1)), lane l's chunk at + 4 l (what one LDS-DMA writes)
+    // A turn moves at most one dword into buf and looks at the one behind it: when a round starts, at least 4 CHUNKS - 3 - TURNS
+    // dwords in front of the lane have landed (everything the top-up before the last round asked for), and it takes TURNS + 1.
+    static constexpr int ROUND_TURNS = TURNS_;
+    static_assert((CHUNKS_ & (CHUNKS_ - 1)) == 0 && 2 * TURNS_ + 4 <= 4 * CHUNKS_, "ring size against the turns of a round");
+    static_assert(DB >= 6 && (DST_HW + NLONG) * 2 >= 128, "the code-length code's 128-byte table borrows the space of the distance table (and of the long symbols behind it)");
     static_assert(LB >= DB && LB <= 11, "first-level widths");
+    static_assert(!DBYTE || DB <= 7, "a byte entry holds three bits of code length");
 };
 constexpr int LENS_DW = 40;  // a lane's scratch of code lengths, a nibble each: literal/length [0, 288), distance [288, 320)
 
@@ -127,11 +139,10 @@ struct Lane {
 };
 
 // ---- the stream ------------------------------------------------------------------------------------------------------------------
-constexpr int RING_CHUNKS = 16;          // 16-byte chunks of its stream a lane keeps in LDS
-constexpr int RING_DW = RING_CHUNKS * 256;  // dwords of a wave's ring: slot j = [256 j, 256 (j + 1)), lane l's chunk at + 4 l (what one LDS-DMA writes)
-constexpr int ROUND_TURNS = 24;          // turns between two top-ups: a turn moves at most one dword into buf, so a round takes at most 24 of
-                                         // the >= 37 dwords that have landed when it starts (16 chunks - 6 freed last round and on their way - 3 dwords)
-QD3_HD uint32_t ring_at(uint32_t w, uint32_t lane) { return (((w >> 2) & (uint32_t)(RING_CHUNKS - 1)) << 8) + (lane << 2) + (w & 3u); }
+template <class C>
+QD3_HD uint32_t ring_at(uint32_t w, uint32_t lane) {
+    return (((w >> 2) & (uint32_t)(C::RING_CHUNKS - 1)) << 8) + (lane << 2) + (w & 3u);
+}
 
 // chunk `src` of the stream -> slot `slot` of the ring, for the lanes that `want` it; lands some time later (ring_wait)
 QD3_HD void ring_dma(const uint32_t* comp, uint32_t src, uint32_t* ring, uint32_t slot, uint32_t lane, bool want) {
@@ -152,16 +163,16 @@ QD3_HD void ring_wait() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
-// requests the chunks behind the lane's position whose slots are free: afterwards the ring holds (or awaits) chunks [rd / 4, rd / 4 + 16)
+// requests the chunks behind the lane's position whose slots are free: afterwards the ring holds (or awaits) chunks [rd / 4, rd / 4 + CHUNKS)
 template <class C>
 QD3_HD void topup(Lane<C>& L, uint32_t* ring, uint32_t lane, bool active) {
     const uint32_t rc = L.rd >> 2;
 #pragma unroll 1
-    for (uint32_t j = 0; j < (uint32_t)RING_CHUNKS; ++j) {  // (the slot is wave-uniform: one LDS-DMA instruction serves the lanes that need this slot)
-        const uint32_t c = rc + ((j - rc) & (uint32_t)(RING_CHUNKS - 1));
+    for (uint32_t j = 0; j < (uint32_t)C::RING_CHUNKS; ++j) {  // (the slot is wave-uniform: one LDS-DMA instruction serves the lanes that need this slot)
+        const uint32_t c = rc + ((j - rc) & (uint32_t)(C::RING_CHUNKS - 1));
         ring_dma(L.comp, c < L.clast ? c : L.clast, ring, j, lane, active && c >= L.fetched);
     }
-    if (active) L.fetched = rc + (uint32_t)RING_CHUNKS;
+    if (active) L.fetched = rc + (uint32_t)C::RING_CHUNKS;
 }
 // (after ring_wait)
 template <class C>
@@ -178,7 +189,7 @@ QD3_HD void rd_init(Lane<C>& L, uint64_t bit) {  // position only: prime() once 
 template <class C>
 QD3_HD void prime(Lane<C>& L, const uint32_t* ring, uint32_t lane) {
     const uint32_t sh = L.have;
-    const uint64_t lo = ring[ring_at(L.rd, lane)], hi = ring[ring_at(L.rd + 1, lane)];
+    const uint64_t lo = ring[ring_at<C>(L.rd, lane)], hi = ring[ring_at<C>(L.rd + 1, lane)];
     L.buf = (lo | (hi << 32)) >> sh;
     L.have = 64 - sh;
     L.rd += 2;
@@ -193,7 +204,7 @@ QD3_HD void refill(Lane<C>& L, uint32_t* ring, uint32_t lane) {
             ring_wait();
             landed_all(L);
         }
-        L.buf |= (uint64_t)ring[ring_at(L.rd, lane)] << L.have;
+        L.buf |= (uint64_t)ring[ring_at<C>(L.rd, lane)] << L.have;
         L.have += 32;
         ++L.rd;
     }
@@ -278,7 +289,13 @@ QD3_HD uint32_t build(const uint32_t* lens, uint32_t n, uint16_t* t, uint16_t* l
             pk_add(first, l, code);
         }
     }
-    for (uint32_t i = 0; i < N / 2; ++i) reinterpret_cast<uint32_t*>(t)[i] = E_NONE | (E_NONE << 16);
+    constexpr bool BYTES = DIST && C::DBYTE;  // (a byte entry: bits | symbol << 3; 0: a longer code, or none)
+    uint8_t* const t8 = reinterpret_cast<uint8_t*>(t);
+    if (BYTES) {
+        for (uint32_t i = 0; i < N / 4; ++i) reinterpret_cast<uint32_t*>(t)[i] = 0;
+    } else {
+        for (uint32_t i = 0; i < N / 2; ++i) reinterpret_cast<uint32_t*>(t)[i] = E_NONE | (E_NONE << 16);
+    }
 #pragma unroll
     for (int k = 0; k < NX; ++k) lim[k] = bas[k] = 0;
     if (total == 0) return 0;                                // no codes at all: every look-up fails (zlib: as long as none is used)
@@ -304,7 +321,12 @@ QD3_HD uint32_t build(const uint32_t* lens, uint32_t n, uint16_t* t, uint16_t* l
             const uint32_t e = DIST ? dist_entry(s, l) : lit_entry(s, l);
             if (l <= (uint32_t)XB) {  // the stream carries a code MSB first inside an LSB-first bit order: indexed by the reversed code
                 const uint32_t rev = brev32(c) >> (32u - l);
-                for (uint32_t k = rev; k < N; k += 1u << l) t[k] = (uint16_t)e;
+                if (BYTES) {
+                    const uint32_t e8 = s >= 30 ? 0u : l | (s << 3);
+                    for (uint32_t k = rev; k < N; k += 1u << l) t8[k] = (uint8_t)e8;
+                } else {
+                    for (uint32_t k = rev; k < N; k += 1u << l) t[k] = (uint16_t)e;
+                }
             } else {
                 uint32_t at = 0;
 #pragma unroll
@@ -328,7 +350,7 @@ template <class C>
 QD3_HD void header(Lane<C>& L, uint16_t* tab, uint32_t* ring, uint32_t lane) {
     uint16_t* const lit = tab;
     uint16_t* const dst = tab + C::LIT_N;
-    uint16_t* const lng = tab + C::LIT_N + C::DST_N;
+    uint16_t* const lng = tab + C::LIT_N + C::DST_HW;
     const uint64_t at = bitpos(L);
     if (at <= L.bit_end) {  // (a block that "ended" behind the input's end was decoded from bytes that are not the stream's)
         L.blk_bit = at;
@@ -388,7 +410,7 @@ QD3_HD void header(Lane<C>& L, uint16_t* tab, uint32_t* ring, uint32_t lane) {
             cl |= (uint64_t)((uint32_t)L.buf & 7u) << (3u * sym);
             drop(L, 3);
         }
-        // its table: 128 bytes where the distance table will be (symbol | bits << 5); the code must be complete
+        // its table: 128 bytes where the distance table (and, behind a byte-wide one, the long symbols) will be: symbol | bits << 5; the code must be complete
         uint8_t* const clt = reinterpret_cast<uint8_t*>(dst);
         uint64_t cc = 0;  // count per length, eight bits each
         for (uint32_t s = 0; s < 19; ++s) {
@@ -476,10 +498,18 @@ QD3_HD void header(Lane<C>& L, uint16_t* tab, uint32_t* ring, uint32_t lane) {
 // (a 2-byte store per literal, two per match, at the lane's own place: nothing is gathered in registers first).
 template <class C>
 QD3_HD void turn(Lane<C>& L, const uint16_t* tab, const uint32_t* ring, uint32_t lane, uint16_t* tok) {
-    const uint32_t next_word = ring[ring_at(L.rd, lane)];
+    const uint32_t next_word = ring[ring_at<C>(L.rd, lane)];
     const uint32_t lo32 = (uint32_t)L.buf;
     const bool dist = L.state == ST_DIST;
-    uint32_t e = tab[(dist ? (uint32_t)C::LIT_N : 0u) + (lo32 & (dist ? (uint32_t)C::DST_N - 1u : (uint32_t)C::LIT_N - 1u))];
+    uint32_t e;
+    if (C::DBYTE) {  // the distance table's entries are bytes: the 16-bit word around one is read, and the entry put into the common form
+        const uint32_t ix = lo32 & (dist ? (uint32_t)C::DST_N - 1u : (uint32_t)C::LIT_N - 1u);
+        const uint32_t w = tab[dist ? (uint32_t)C::LIT_N + (ix >> 1) : ix];
+        const uint32_t b = (w >> (8u * (ix & 1u))) & 255u;
+        e = dist ? ((b & 7u) ? (b & 7u) | (1u << 4) | ((b >> 3) << 6) : E_NONE) : w;
+    } else {
+        e = tab[(dist ? (uint32_t)C::LIT_N : 0u) + (lo32 & (dist ? (uint32_t)C::DST_N - 1u : (uint32_t)C::LIT_N - 1u))];
+    }
     if ((e & 0x3Fu) == E_NONE) {  // a code longer than the first level, or none: the next 15 bits MSB first against the lengths' limits
         const uint32_t x = brev32(lo32) >> 17;
         uint32_t at = 0xFFFFFFFFu;
@@ -492,7 +522,7 @@ QD3_HD void turn(Lane<C>& L, const uint16_t* tab, const uint32_t* ring, uint32_t
             for (int k = C::NL - 1; k >= 0; --k)
                 if (x < L.lim_l[k]) at = (L.bas_l[k] + (x >> (14 - C::LB - k))) & 0xFFFFu;
         }
-        e = at < (uint32_t)C::NLONG ? tab[C::LIT_N + C::DST_N + at] : E_NONE;
+        e = at < (uint32_t)C::NLONG ? tab[C::LIT_N + C::DST_HW + at] : E_NONE;
     }
     const uint32_t nb = e & 15u, kind = (e >> 4) & 3u, val = e >> 6;
     const bool is_lit = kind == 0u, is_len = !dist && kind == 1u, is_eob = kind == 2u;  // (the distance table holds kind 1 only)
@@ -531,7 +561,7 @@ QD3_HD void turn(Lane<C>& L, const uint16_t* tab, const uint32_t* ring, uint32_t
 // above do not carry it).
 template <class C>
 QD3_HD void turn_stored(Lane<C>& L, const uint32_t* ring, uint32_t lane, uint16_t* tok) {
-    const uint32_t next_word = ring[ring_at(L.rd, lane)];
+    const uint32_t next_word = ring[ring_at<C>(L.rd, lane)];
     if (L.on < L.on_end) {
         tok[L.on++] = (uint16_t)((uint32_t)L.buf & 255u);
     } else {

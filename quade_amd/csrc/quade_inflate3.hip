@@ -21,24 +21,46 @@
 #include "quade_inflate.h"
 #include "inflate3_lane.h"
 #include "quade_inflate3.h"
+#include "quade_pool.h"
 
 namespace {
 
-using CfgA = qd3::Cfg<8, 7, 112>;   // 996 B of tables per lane (112 long symbols: what the fixed code has behind 8 bits) + the wave's 16 KB input ring = 78 KB: two waves per CU
-static_assert((CfgA::LANE_DW * 64 + qd3::RING_DW) * 4 * 2 <= 160 * 1024, "two workgroups per CU");
+// Two sizes of the lane decoder.  A wave's LDS -- 64 lanes' tables and its input ring -- decides how many waves a CU holds, and a CU
+// has four SIMDs: a token launch is a latency-bound kernel whose throughput is the number of waves in flight.
+//   CfgS  (what a launch runs)  7-bit literal/length table, 6-bit distance table of BYTE entries, 88 symbols with longer codes,
+//         a ring of 8 chunks: 500 B + 128 B a lane, 39.25 KB a wave -> FOUR waves per CU, one per SIMD.  fastq's deflate blocks
+//         have ~45 literal/length symbols behind 7 bits and <= 18 distance symbols behind 6 (tools/deflate_stats.py).
+//   CfgA  (the redo)  8 / 7 bits, 112 long symbols -- what the fixed code has behind 8 bits -- and a ring of 16 chunks: 78 KB a wave,
+//         two per CU.  A unit that CfgS gave up with "table space" (a fixed block; a block of byte soup) is decoded again by a
+//         second launch of this size, in which every other lane retires at once.
+using CfgS = qd3::Cfg<7, 6, 88, true, 8, 12>;
+using CfgA = qd3::Cfg<8, 7, 112>;
+static_assert((CfgS::LANE_DW * 64 + CfgS::RING_DW) * 4 * 4 <= 160 * 1024 - 2048, "four workgroups per CU");
+static_assert((CfgA::LANE_DW * 64 + CfgA::RING_DW) * 4 * 2 <= 160 * 1024, "two workgroups per CU");
 
 // units[] (stretches of a gzip member) or jobs[] (BGZF: unit i = block i, its slot region i * QD_INFLATE3_TOK_STRIDE)
+// redo: only the units whose result says "table space" (the launch before this one, of a smaller configuration, gave them up) --
+// by a small grid whose waves walk all groups of 64 units (a launch as wide as the first would spend a millisecond placing
+// workgroups of 78 KB that find nothing to do).
 template <class C>
 __global__ __launch_bounds__(64) void inflate3_tokens(const qd3::Unit* units, const qd_inflate3_job* jobs, uint32_t n_units, uint16_t* tokens, uint32_t* lens_scratch,
-                                                      qd3::Result* res, uint32_t wait_rounds) {
+                                                      qd3::Result* res, uint32_t wait_rounds, uint32_t redo) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds3[];
-    const uint32_t lane = threadIdx.x, u = blockIdx.x * 64u + lane;
+    const uint32_t lane = threadIdx.x;
     uint32_t* const ring = lds3;  // the wave's input ring first (16-byte aligned slots), the lanes' tables behind it
-    uint16_t* const tab = reinterpret_cast<uint16_t*>(lds3 + qd3::RING_DW + lane * (uint32_t)C::LANE_DW);
+    uint16_t* const tab = reinterpret_cast<uint16_t*>(lds3 + C::RING_DW + lane * (uint32_t)C::LANE_DW);
+#pragma unroll 1
+  for (uint32_t group = blockIdx.x; 64u * group < n_units; group += gridDim.x) {
+    const uint32_t u = 64u * group + lane;
+    bool mine = u < n_units;
+    if (redo) {
+        mine = mine && res[u].status == (uint32_t)QD_INFLATE_TABLE_SPACE;
+        if (!__ballot(mine)) continue;
+    }
     qd3::Lane<C> L;
     {
         qd3::Unit un{nullptr, 0, ~0ull, 0, 0, 0, 0, nullptr, 0, 0};
-        if (u < n_units) {
+        if (mine) {
             if (jobs) {
                 const qd_inflate3_job j = jobs[u];
                 const uintptr_t a = reinterpret_cast<uintptr_t>(j.payload);
@@ -52,13 +74,13 @@ __global__ __launch_bounds__(64) void inflate3_tokens(const qd3::Unit* units, co
                 un = units[u];
             }
         }
-        qd3::lane_init(L, un, lens_scratch + (size_t)(u < n_units ? u : 0) * qd3::LENS_DW);
-        if (u >= n_units) {
+        qd3::lane_init(L, un, lens_scratch + (size_t)(mine ? u : 0) * qd3::LENS_DW);
+        if (!mine) {
             L.state = qd3::ST_DONE;
             L.status = 0;
         }
     }
-    qd3::topup(L, ring, lane, u < n_units);
+    qd3::topup(L, ring, lane, mine);
     qd3::ring_wait();
     qd3::landed_all(L);
     qd3::prime(L, ring, lane);
@@ -90,18 +112,19 @@ __global__ __launch_bounds__(64) void inflate3_tokens(const qd3::Unit* units, co
         qd3::topup(L, ring, lane, dec);  // ... what it used up is requested again, and lands while this round runs
         if (__ballot(L.state == qd3::ST_STORED)) {  // (stored blocks: byte soup, not fastq)
 #pragma unroll 1
-            for (int t = 0; t < qd3::ROUND_TURNS; ++t) {
+            for (int t = 0; t < C::ROUND_TURNS; ++t) {
                 if (L.state == qd3::ST_STORED) qd3::turn_stored<C>(L, ring, lane, tokens);
                 else if (L.state <= qd3::ST_DIST) qd3::turn<C>(L, tab, ring, lane, tokens);
             }
         } else {
 #pragma unroll 1
-            for (int t = 0; t < qd3::ROUND_TURNS; ++t)
+            for (int t = 0; t < C::ROUND_TURNS; ++t)
                 if (L.state <= qd3::ST_DIST) qd3::turn<C>(L, tab, ring, lane, tokens);
         }
         if (mh) ++waited;
     }
-    if (u < n_units) qd3::lane_finish(L, res + u);
+    if (mine) qd3::lane_finish(L, res + u);
+  }
 }
 
 // ---- BGZF: tokens -> text, one workgroup per block ------------------------------------------------------------------------------------
@@ -751,15 +774,27 @@ __global__ void inflate3_jobs_from_blocks(const uint8_t* comp, uint8_t* out, con
 }
 
 template <class C>
-hipError_t launch_tokens(const qd3::Unit* units, const qd_inflate3_job* jobs, uint32_t n_units, uint16_t* tokens, uint32_t* lens, qd3::Result* res, hipStream_t st) {
+hipError_t launch_tokens_of(const qd3::Unit* units, const qd_inflate3_job* jobs, uint32_t n_units, uint16_t* tokens, uint32_t* lens, qd3::Result* res, uint32_t redo, hipStream_t st) {
     static const int wait_turns = env_int("QUADE_INFLATE3_WAIT", 256);
-    const size_t lds = ((size_t)C::LANE_DW * 64 + qd3::RING_DW) * 4;
+    const size_t lds = ((size_t)C::LANE_DW * 64 + C::RING_DW) * 4;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(inflate3_tokens<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(inflate3_tokens<C>, dim3((n_units + 63) / 64), dim3(64), lds, st, units, jobs, n_units, tokens, lens, res,
-                       (uint32_t)((wait_turns + qd3::ROUND_TURNS - 1) / qd3::ROUND_TURNS));
+    const uint32_t groups = (n_units + 63) / 64;
+    hipLaunchKernelGGL(inflate3_tokens<C>, dim3(redo ? std::min<uint32_t>(groups, 128u) : groups), dim3(64), lds, st, units, jobs, n_units, tokens, lens, res,
+                       (uint32_t)((wait_turns + C::ROUND_TURNS - 1) / C::ROUND_TURNS), redo);
     return hipGetLastError();
+}
+// every unit's tokens: the small configuration (four waves per CU), then the large one for the units it had no table space for
+// (QUADE_INFLATE3_CFG=a: the large one alone, as the round's first form ran -- for A/B runs)
+hipError_t launch_tokens(const qd3::Unit* units, const qd_inflate3_job* jobs, uint32_t n_units, uint16_t* tokens, uint32_t* lens, qd3::Result* res, hipStream_t st) {
+    static const bool large_only = [] {
+        const char* v = getenv("QUADE_INFLATE3_CFG");
+        return v && (*v == 'a' || *v == 'A');
+    }();
+    if (large_only) return launch_tokens_of<CfgA>(units, jobs, n_units, tokens, lens, res, 0, st);
+    const hipError_t e = launch_tokens_of<CfgS>(units, jobs, n_units, tokens, lens, res, 0, st);
+    return e != hipSuccess ? e : launch_tokens_of<CfgA>(units, jobs, n_units, tokens, lens, res, 1, st);
 }
 
 template <int NT, int Q>
@@ -802,7 +837,7 @@ hipError_t qd_launch_inflate3_jobs(const qd_inflate3_job* d_jobs, uint32_t n_blo
     if ((uintptr_t)scratch & 255u) return hipErrorInvalidValue;
     const Scratch3 c = carve(scratch, n_blocks);
     static const int shape = env_int("QUADE_INFLATE3_RESOLVE", 0);  // 0: 512 lanes, windows of 4 Ki (two workgroups per CU); 1: 1 024 lanes, 16 Ki; 2: 1 024 lanes, 4 Ki
-    hipError_t e = launch_tokens<CfgA>(nullptr, d_jobs, n_blocks, c.tokens, c.lens, c.res, st);
+    hipError_t e = launch_tokens(nullptr, d_jobs, n_blocks, c.tokens, c.lens, c.res, st);
     if (e != hipSuccess) return e;
     if (shape == 1) return launch_resolve<1024, 16384>(d_jobs, n_blocks, c.tokens, c.res, status, st);
     if (shape == 2) return launch_resolve<1024, 4096>(d_jobs, n_blocks, c.tokens, c.res, status, st);
@@ -834,19 +869,14 @@ struct GBuf {  // grow-only device allocation
     size_t cap = 0;
     hipError_t need(size_t n) {
         if (n <= cap) return hipSuccess;
-        if (p) {
-            (void)hipDeviceSynchronize();
-            (void)hipFree(p);
-        }
+        if (p) qd_pool_put(p, cap);  // (drains the device first)
         p = nullptr;
         cap = 0;
         const size_t want = n + n / 4 + 65536;
-        const hipError_t e = hipMalloc((void**)&p, want);
-        if (e == hipSuccess) cap = want;
-        return e;
+        return qd_pool_get(want, (void**)&p, &cap);  // (quade_pool.h: from what an earlier pipeline of this process released)
     }
     ~GBuf() {
-        if (p) (void)hipFree(p);
+        if (p) qd_pool_put(p, cap);
     }
     template <class T>
     T* as() const { return reinterpret_cast<T*>(p); }
@@ -1057,7 +1087,7 @@ hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st, int slots_per
         GZCHK(G.h_res.need(nu0 * std::max(sizeof(qd3::Unit), sizeof(qd3::Result))));
         memcpy(G.h_res.p, G.units_.data(), nu0 * sizeof(qd3::Unit));
         GZCHK(hipMemcpyAsync(G.d_units.p, G.h_res.p, nu0 * sizeof(qd3::Unit), hipMemcpyHostToDevice, st));
-        GZCHK(launch_tokens<CfgA>(G.d_units.as<qd3::Unit>(), nullptr, (uint32_t)nu0, G.d_tokens.as<uint16_t>(), G.d_lens.as<uint32_t>(), G.d_res.as<qd3::Result>(), st));
+        GZCHK(launch_tokens(G.d_units.as<qd3::Unit>(), nullptr, (uint32_t)nu0, G.d_tokens.as<uint16_t>(), G.d_lens.as<uint32_t>(), G.d_res.as<qd3::Result>(), st));
         GZCHK(hipStreamSynchronize(st));
         GZCHK(hipMemcpyAsync(G.h_res.p, G.d_res.p, nu0 * sizeof(qd3::Result), hipMemcpyDeviceToHost, st));
         GZCHK(hipStreamSynchronize(st));
@@ -1069,6 +1099,14 @@ hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st, int slots_per
         size_t n_found = 0;
         for (uint64_t f : found) n_found += f != ~0ull;
         fprintf(stderr, "[qd_gz] decode: %d steps, %zu stretches probed, %zu block starts found, %zu units\n", n, probe.size(), n_found, nu0);
+        uint64_t sl_sum = 0, sl_max = 0, bits_sum = 0, bits_max = 0;  // (a launch lasts as long as its longest lane)
+        for (size_t q = 0; q < nu0; ++q) {
+            const uint64_t bits = res[q].bit_next > G.units_[q].bit_start ? res[q].bit_next - G.units_[q].bit_start : 0;
+            sl_sum += res[q].n_slots, sl_max = std::max<uint64_t>(sl_max, res[q].n_slots);
+            bits_sum += bits, bits_max = std::max(bits_max, bits);
+        }
+        if (nu0) fprintf(stderr, "[qd_gz]   per unit: slots mean %llu max %llu, compressed bytes mean %llu max %llu\n", (unsigned long long)(sl_sum / nu0), (unsigned long long)sl_max,
+                         (unsigned long long)(bits_sum / nu0 / 8), (unsigned long long)(bits_max / 8));
         for (size_t q = 0; q < nu0; ++q)
             if (res[q].status || dropped[q] || q < 3 || q + 2 >= nu0)
                 fprintf(stderr, "[qd_gz]   unit %zu step %d%s: bits [%llu, stop %llu) end %llu -> status %u final %u slots %u text %u next %llu blk %llu/%u/%u\n", q, unit_of[q].first,

@@ -42,6 +42,7 @@
 #include "quade_inflate.h"
 #include "quade_inflate3.h"
 #include "quade_io_internal.h"
+#include "quade_pool.h"
 #include "quade_text.h"
 
 uint32_t qd_crc32_combine_host(uint32_t crc1, uint32_t crc2, uint64_t len2);  // quade_io.cpp (zlib's)
@@ -90,7 +91,8 @@ struct DevBuf {  // grow-only device allocation
         Tick tick(g_alloc_seconds);
         const size_t want = n + n / 4 + (1u << 16);
         uint8_t* q = nullptr;
-        hipError_t e = hipMalloc((void**)&q, want);
+        size_t got = want;
+        hipError_t e = qd_pool_get(want, (void**)&q, &got);  // (quade_pool.h: from what an earlier pipeline of this process released)
         if (e != hipSuccess) return e;
         // nothing queued anywhere may still use the old allocation (the inflate launches run on streams of their own)
         if (p) (void)hipDeviceSynchronize();
@@ -99,13 +101,13 @@ struct DevBuf {  // grow-only device allocation
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) return e;
         }
-        if (p) (void)hipFree(p);
+        if (p) qd_pool_put(p, cap);
         p = q;
-        cap = want;
+        cap = got;
         return hipSuccess;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) qd_pool_put(p, cap);
         p = nullptr;
         cap = 0;
     }
@@ -208,7 +210,7 @@ class Feeder {
         hipError_t e = hipSetDevice(device_);
         if (e != hipSuccess) return e;
         if ((e = hipStreamCreateWithFlags(&up_, hipStreamNonBlocking)) != hipSuccess) return e;
-        if ((e = hipMalloc((void**)&ring_, (size_t)RING_SLOTS * SEG_BYTES + 4096)) != hipSuccess) return e;  // (the third inflater's lanes read up to 512 bytes ahead of a payload)
+        if ((e = qd_pool_get((size_t)RING_SLOTS * SEG_BYTES + 4096, (void**)&ring_, &ring_cap_)) != hipSuccess) return e;  // (the third inflater's lanes read up to 512 bytes ahead of a payload)
         for (int i = 0; i < RING_SLOTS; ++i) {
             if ((e = hipEventCreateWithFlags(&ready_[i], hipEventDisableTiming)) != hipSuccess) return e;
             if ((e = hipEventCreateWithFlags(&consumed_[i], hipEventDisableTiming)) != hipSuccess) return e;
@@ -237,7 +239,7 @@ class Feeder {
             if (pin_[i]) (void)hipHostFree(pin_[i]);
             pin_[i] = nullptr;
         }
-        if (ring_) (void)hipFree(ring_);
+        if (ring_) qd_pool_put(ring_, ring_cap_);
         ring_ = nullptr;
     }
     // the next segment of the stream (blocks); SEG_END closes a chunk
@@ -574,6 +576,7 @@ class Feeder {
     bool device_gunzip_ = false;
     hipStream_t up_ = nullptr;
     uint8_t* ring_ = nullptr;
+    size_t ring_cap_ = 0;
     hipEvent_t ready_[RING_SLOTS] = {nullptr}, consumed_[RING_SLOTS] = {nullptr};
     int state_[RING_SLOTS] = {0};  // 0 free, 1 with the driver, 2 its last reader is queued (consumed_ tells when it has run)
     uint8_t* pin_[PIN_SLOTS] = {nullptr};
@@ -1200,7 +1203,7 @@ int gz_append(qd_pipe* p, Feeder& f, Window& w, Segment& s) {
         }
     }
     if ((uint64_t)s.file_off != g.comp_off + g.comp_len) return pfail(p, QD_ERR_STATE, w.path + ": uploads out of order");
-    const hipStream_t gs = p->inflate_overlap ? p->is[1] : p->cs;  // (the gzip steps' stream: gz_steps)
+    const hipStream_t gs = p->inflate_overlap ? p->is[0] : p->cs;  // (the gzip steps' stream: gz_steps)
     PCHK(p, g.comp[g.ccur].need((size_t)g.comp_len + s.bytes + 8192, (size_t)g.comp_len, gs));
     PCHK(p, hipStreamWaitEvent(gs, f.ready(s.slot), 0));
     PCHK(p, hipMemcpyAsync(g.comp[g.ccur].p + g.comp_len, f.ring() + (size_t)s.slot * SEG_BYTES, s.bytes, hipMemcpyDeviceToDevice, gs));
@@ -1330,7 +1333,9 @@ int gz_steps(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chun
     // A stream of their own ("inflate_overlap"): a step ends with the host waiting for its results, and on the compute stream that wait
     // would include everything batch k still has queued there (format, coder).  What a step writes -- the windows' text behind what
     // the carry copies move to their front -- nothing queued on the compute stream touches.
-    const hipStream_t gs = p->inflate_overlap ? p->is[1] : p->cs;
+    // (is[0], the BGZF launches' stream too: the runtime spreads streams over four hardware queues, and is[1] landed on the compute
+    //  stream's -- its kernels ran strictly one after the other with the coder's, profiles/r05_e2e_gz_timeline_before.txt)
+    const hipStream_t gs = p->inflate_overlap ? p->is[0] : p->cs;
     static double t_decode = 0, t_room = 0, t_resolve = 0, t_sync = 0, t_post = 0;  // (QUADE_PIPE_TRACE: where a gzip step's wall time goes)
     static const bool trace = getenv("QUADE_PIPE_TRACE") != nullptr;
     struct Report {
@@ -2008,16 +2013,26 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
             }
             fprintf(stderr, "\n");
         }
+        // (QUADE_PIPE_TRACE: where the host is, in ms since the first mark)
+        auto mark = [&](const char* what) {
+            if (!trace) return;
+            static const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[pipe] %9.3f ms  chunk %d turn %llu: %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), chunk,
+                    (unsigned long long)turn, what);
+        };
         // 1. text
+        mark("top-up");
         for (int s = 0; s < ns; ++s) {
             const int rc = top_up(p, *feeders[s], p->win[s], s, chunk, want[s]);
             if (rc != QD_OK) return rc;
         }
+        mark("inflate launches");
         {
             int rc = flush_inflate3(p);  // (the third inflater: the blocks of every stream's uploads in one launch)
             if (rc == QD_OK) rc = gz_steps(p, feeders, chunk);  // ... and a step of every ordinary gzip stream
             if (rc != QD_OK) return rc;
         }
+        mark("inflate launched / gzip step done");
         // (a shared chunk: the text in front of this rank's first record goes before anything is scanned)
         {
             bool more = false;
@@ -2045,8 +2060,10 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
             scanned = true;
         }
         if (scanned) {
+            mark("scans queued");
             int rc = sync_compute(p);
             if (rc != QD_OK) return rc;
+            mark("scans done");
             bool again = false;
             for (int s = 0; s < ns; ++s) {
                 Window& w = p->win[s];
@@ -2137,8 +2154,10 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
         uint32_t n = (uint32_t)std::min<uint64_t>(B, pairs_left);
         for (int s = 0; s < ns; ++s) n = std::min(n, p->win[s].res.n_kept);
         if (n) {
+            mark("batch");
             const int rc = process_batch(p, n, sink, *batch_index);
             if (rc != QD_OK) return rc;
+            mark("batch queued");
             ++*batch_index;
             pairs_left -= n;
         }

@@ -171,6 +171,7 @@ SYMBOLS = [
     ("qd_pipe_destroy", C.c_int, [_P]),
     ("qd_dev_fastq_scan", C.c_int64, [C.c_int, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _P, C.c_int64, _P]),
     ("qd_dev_crc32", C.c_int, [C.c_int, _P, C.c_int64, C.c_int64, C.POINTER(C.c_uint32)]),
+    ("qd_pool_trim", C.c_int, []),
     ("qd_dev_gunzip", C.c_int, [C.c_int, _P, C.c_int64, _P, C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
     ("qd_dev_sort_by_dest", C.c_int, [C.c_int, _P, C.c_int64, C.c_int32, _P, _P, _P]),
     ("qd_get_plan", C.c_int, [_P, C.POINTER(qd_plan)]),

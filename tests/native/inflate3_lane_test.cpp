@@ -12,7 +12,7 @@
 
 #include "../../quade_amd/csrc/inflate3_lane.h"
 
-static int g_fail = 0;
+static int g_fail = 0, g_redone = 0;
 #define CHECK(x)                                                     \
     do {                                                             \
         if (!(x)) {                                                  \
@@ -65,7 +65,7 @@ static Run<C> run_unit(const std::vector<uint8_t>& comp, uint64_t bit_start, uin
     std::vector<uint32_t> words((comp.size() + 3) / 4 + 80, 0);  // (a lane's ring holds the 256 bytes behind its position)
     memcpy(words.data(), comp.data(), comp.size());
     std::vector<uint16_t> lds(2 * C::LANE_DW);
-    std::vector<uint32_t> ring(qd3::RING_DW, 0xABABABAB), lens(qd3::LENS_DW, 0xDEADBEEF);
+    std::vector<uint32_t> ring(C::RING_DW, 0xABABABAB), lens(qd3::LENS_DW, 0xDEADBEEF);
     Run<C> r;
     r.tok.assign(tok_cap + 8, 0xEEEE);
     qd3::Unit u{words.data(), bit_start, bit_stop, (uint64_t)comp.size() * 8, 0, tok_cap, (uint32_t)((comp.size() + 3) / 4 + 80), cands ? cands->data() : nullptr,
@@ -98,11 +98,11 @@ static Run<C> run_unit(const std::vector<uint8_t>& comp, uint64_t bit_start, uin
         int n_saved = 0;
         for (uint32_t c = landed; c < L.fetched; ++c)
             for (int k = 0; k < 4; ++k) {
-                uint32_t& w = ring[qd3::ring_at(4 * c + k, lane)];
+                uint32_t& w = ring[qd3::ring_at<C>(4 * c + k, lane)];
                 saved[n_saved++] = w;
                 w = 0x5A5A5A5A;
             }
-        for (int t = 0; t < qd3::ROUND_TURNS && L.state <= qd3::ST_STORED; ++t) {
+        for (int t = 0; t < C::ROUND_TURNS && L.state <= qd3::ST_STORED; ++t) {
             if (L.state == qd3::ST_STORED) qd3::turn_stored<C>(L, ring.data(), lane, r.tok.data());
             else qd3::turn<C>(L, lds.data(), ring.data(), lane, r.tok.data());
             if (L.rd > 4 * landed) {
@@ -112,7 +112,7 @@ static Run<C> run_unit(const std::vector<uint8_t>& comp, uint64_t bit_start, uin
         }
         n_saved = 0;
         for (uint32_t c = landed; c < L.fetched; ++c)
-            for (int k = 0; k < 4; ++k) ring[qd3::ring_at(4 * c + k, lane)] = saved[n_saved++];
+            for (int k = 0; k < 4; ++k) ring[qd3::ring_at<C>(4 * c + k, lane)] = saved[n_saved++];
     }
     qd3::lane_finish(L, &r.res);
     return r;
@@ -124,6 +124,18 @@ static void check_stream(const char* what, const std::vector<uint8_t>& text, int
     const uint32_t cap = (uint32_t)((text.size() + 16 + 3) & ~3u) + 8;
     Run<C> r = run_unit<C>(comp, 0, ~0ull, cap);
     if (allow_space && r.res.status == QD_INFLATE_TABLE_SPACE) return;
+    // a configuration too small for the fixed code (264 symbols behind 7 bits, 112 behind 8) says "table space" at a fixed block: the
+    // launch decodes such a unit again with the large configuration (quade_inflate3.hip: launch_tokens) -- so does the test
+    constexpr bool fixed_fits = C::LB >= 9 || (C::LB == 8 && C::NLONG >= 112);
+    if (!fixed_fits && r.res.status == QD_INFLATE_TABLE_SPACE) {
+        ++g_redone;
+        Run<qd3::Cfg<8, 7, 112>> again = run_unit<qd3::Cfg<8, 7, 112>>(comp, 0, ~0ull, cap);
+        CHECK(again.res.status == 0 && again.res.final_seen && again.res.text_len == text.size());
+        std::vector<uint8_t> got;
+        CHECK(expand(again.tok, again.res.n_slots, got));
+        CHECK(got == text);
+        return;
+    }
     if (r.res.status != 0 || !r.res.final_seen || r.res.text_len != text.size()) {
         printf("FAIL %s level %d strategy %d: status %u final %u text %u of %zu\n", what, level, strategy, r.res.status, r.res.final_seen, r.res.text_len, text.size());
         ++g_fail;
@@ -240,13 +252,16 @@ static void suite(const char* name) {
         Run<C> r = run_unit<C>(comp, 0, ~0ull, 1024);
         CHECK(r.res.status == QD_INFLATE_TOKEN_SPACE);
     }
-    printf("%s: done\n", name);
+    printf("%s: done (%d streams decoded again by the large configuration)\n", name, g_redone);
+    g_redone = 0;
 }
 
 int main() {
     suite<qd3::Cfg<8, 7, 112>>("LB 8 / DB 7 / 112 long");
     suite<qd3::Cfg<9, 6, 56>>("LB 9 / DB 6 / 56 long");
     suite<qd3::Cfg<10, 7, 96>>("LB 10 / DB 7 / 96 long");
+    suite<qd3::Cfg<7, 6, 88, true, 8, 12>>("LB 7 / DB 6 in bytes / 88 long / ring of 8 chunks, 12 turns a round");
+    suite<qd3::Cfg<8, 7, 64, true, 4, 6>>("LB 8 / DB 7 in bytes / 64 long / ring of 4 chunks, 6 turns a round");
     if (g_fail) {
         printf("%d checks failed\n", g_fail);
         return 1;
