@@ -439,8 +439,9 @@ int qd_sink_device_members(qd_sink* sink, int64_t* device_members); /* of qd_sin
  * files through these kernels; this entry point inflates a whole file image for tests and measurements: gz[0 .. gz_len) = one or more
  * gzip members -> out (at most out_cap bytes), *out_len = the text's size.  Every member's CRC-32 and ISIZE are checked.  step_bytes:
  * compressed bytes per step (what the pipeline takes per batch and stream); stretch_bytes / unit_text: 0 = the defaults (32 KiB of
- * compressed bytes per decoding lane, 1 MiB of text per resolving workgroup).  stats (may be NULL): int64[6] = members, steps,
- * stretches probed, units decoded, units decoded again (a false block start in front of them), steps that ended inside a block.
+ * compressed bytes per decoding lane, 1 MiB of text per resolving workgroup).  stats (may be NULL): int64[8] = members, steps,
+ * stretches probed, units decoded, units dropped (a false block start: their predecessor ran through them), steps that ended inside
+ * a block, decodes done again without the probe's text filter (the stream is not text), 0.
  * QD_ERR_FORMAT: not gzip, damaged, or beyond what the device decodes (the pipeline then hands the file to the host's inflater). */
 int qd_dev_gunzip(int device_id, const uint8_t* gz, int64_t gz_len, uint8_t* out, int64_t out_cap, int64_t* out_len, int64_t step_bytes,
                   int64_t stretch_bytes, int64_t unit_text, int64_t* stats);

@@ -1643,6 +1643,8 @@ extern "C" int qd_dev_gunzip(int device_id, const uint8_t* gz, int64_t gz_len, u
             stats[3] = s.units;
             stats[4] = s.chain_retries;
             stats[5] = s.partial_last;
+            stats[6] = s.plain_probes;
+            stats[7] = 0;
         }
         return code;
     };

@@ -51,6 +51,7 @@ struct qd_gz_step {
 };
 struct qd_gz_stats {
     int64_t stretches, probed_bits_est, units, chain_retries, partial_last;
+    int64_t plain_probes;  // decodes done again without the probe's text filter (a stream that is not text)
 };
 class qd_gz_impl;
 // Several streams advance together (one token launch for all of them: its throughput is the number of stretches in flight).
@@ -61,7 +62,7 @@ class qd_gz {
     qd_gz(const qd_gz&) = delete;
     qd_gz& operator=(const qd_gz&) = delete;
     // probe + tokens + chain check; synchronises `st` twice.  Fills text_len / bit_next / member_end / failed of every step.
-    hipError_t decode(qd_gz_step* steps, int n, hipStream_t st, int slots_per_byte = 4);
+    hipError_t decode(qd_gz_step* steps, int n, hipStream_t st, int slots_per_byte = 4, bool text_filter = true);
     // the decoded steps' text -> out[i][0 .. text_len) (device); asynchronous on `st`; carried windows updated on the device
     hipError_t resolve(qd_gz_step* steps, int n, uint8_t* const* out, hipStream_t st);
     // after `st` has run resolve(): the steps' CRC-32s, and failed != 0 for a stream whose tokens did not resolve (a damaged stream)

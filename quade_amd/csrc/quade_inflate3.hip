@@ -350,7 +350,27 @@ __device__ __forceinline__ uint64_t gz_bits(const uint32_t* base, uint64_t bit) 
 }
 
 // does a dynamic block's header hold at `bit`?  clt: 128 bytes of the lane's own LDS
-__device__ bool gz_header_holds(const uint32_t* base, uint64_t bit, uint64_t bit_end, uint8_t* clt) {
+// text_only: ... and no byte that text does not hold (anything but tab, newline, carriage return and 32 .. 126) has a code.  A header
+// that "holds" at a position where no block starts -- one in ~3 of what the first form reported from fastq at 16 KiB stretches -- has
+// code lengths drawn from noise, spread over all 256 literals; a real block of fastq has none for ~160 of them.  (pugz asks the
+// same of the decoded text; here the lengths say it before anything is decoded.)  Streams that are not text: qd_gz::decode's
+// second try, without this.
+__device__ __forceinline__ bool gz_text_lengths_only(uint32_t a, uint32_t b) {  // no non-text byte among the literals [a, b)
+    b = min(b, 256u);
+    if (a >= b) return true;
+    const uint64_t non_text[4] = {0x00000000FFFFD9FFull, 0x8000000000000000ull, ~0ull, ~0ull};
+    bool hit = false;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) {
+        const uint32_t lo = max(a, 64u * w), hi = min(b, 64u * w + 64u);
+        if (lo < hi) {
+            const uint64_t bits = (hi - lo == 64u ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << (lo - 64u * w);
+            hit = hit || (non_text[w] & bits) != 0;
+        }
+    }
+    return !hit;
+}
+__device__ bool gz_header_holds(const uint32_t* base, uint64_t bit, uint64_t bit_end, uint8_t* clt, bool text_only) {
     if (bit + 17 + 12 > bit_end) return false;
     uint64_t x = gz_bits(base, bit);
     if ((x & 7u) != 4u) return false;  // not the last block, dynamic codes
@@ -420,6 +440,7 @@ __device__ bool gz_header_holds(const uint32_t* base, uint64_t bit, uint64_t bit
             if (in_d) max_d = max(max_d, v);
             if (idx <= 256u && idx + rep > 256u) eob = v;
             if (sum_l > 32768u || sum_d > 32768u) return false;  // over-subscribed
+            if (text_only && in_l && !gz_text_lengths_only(idx, idx + in_l)) return false;
         }
         idx += rep;
         prev = v;
@@ -458,7 +479,7 @@ __device__ __forceinline__ bool gz_stage2(const uint32_t* base, uint64_t bit) {
 
 // found[i] = the first position in [bit_from, bit_to) of stretch i at which a dynamic block's header holds, or ~0.  One wave per stretch.
 constexpr uint32_t GZ_Q2_RUN = 16;  // survivors of stage 2 that wait for a stage-3 pass at most (a true block start waits with them)
-__global__ __launch_bounds__(64) void gz_probe(const GzStretch* stretches, uint32_t n, uint64_t* found) {
+__global__ __launch_bounds__(64) void gz_probe(const GzStretch* stretches, uint32_t n, uint64_t* found, uint32_t text_only) {
     extern __shared__ __attribute__((aligned(16))) uint8_t probe_lds[];
     const uint32_t i = blockIdx.x, lane = threadIdx.x;
     if (i >= n) return;
@@ -474,7 +495,7 @@ __global__ __launch_bounds__(64) void gz_probe(const GzStretch* stretches, uint3
         for (uint32_t b = 0; b < n2 && hit == ~0ull; b += 64) {
             const bool have = b + lane < n2;
             const uint64_t bit = st.bit_from + (have ? q2[b + lane] : 0u);
-            const bool ok = have && gz_header_holds(st.base, bit, st.bit_end, clt);
+            const bool ok = have && gz_header_holds(st.base, bit, st.bit_end, clt, text_only != 0);
             const uint64_t m = __ballot(ok);
             if (m) hit = st.bit_from + q2[b + (uint32_t)__builtin_ctzll(m)];
         }
@@ -956,7 +977,7 @@ hipError_t qd_gz::reserve(uint64_t comp_bytes, uint64_t text_bytes) {
     return hipSuccess;
 }
 
-hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st, int slots_per_byte) {
+hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st, int slots_per_byte, bool text_filter) {
     qd_gz_impl& G = *p_;
     const uint64_t STRETCH = std::max<uint64_t>(stretch_bytes, 256);
     G.acc_.assign((size_t)n, qd_gz_impl::Acc());
@@ -996,7 +1017,8 @@ hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st, int slots_per
         GZCHK(G.h_found.need(probe.size() * std::max(sizeof(GzStretch), (size_t)8)));
         memcpy(G.h_found.p, probe.data(), probe.size() * sizeof(GzStretch));
         GZCHK(hipMemcpyAsync(G.d_stretch.p, G.h_found.p, probe.size() * sizeof(GzStretch), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(gz_probe, dim3((uint32_t)probe.size()), dim3(64), 64 * 128 + 256 * 4, st, G.d_stretch.as<GzStretch>(), (uint32_t)probe.size(), G.d_found.as<uint64_t>());
+        hipLaunchKernelGGL(gz_probe, dim3((uint32_t)probe.size()), dim3(64), 64 * 128 + 256 * 4, st, G.d_stretch.as<GzStretch>(), (uint32_t)probe.size(), G.d_found.as<uint64_t>(),
+                           text_filter ? 1u : 0u);
         GZCHK(hipGetLastError());
         GZCHK(hipStreamSynchronize(st));  // (the table above has been read: the staging buffer takes the answer)
         GZCHK(hipMemcpyAsync(G.h_found.p, G.d_found.p, probe.size() * 8, hipMemcpyDeviceToHost, st));
@@ -1175,10 +1197,24 @@ hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st, int slots_per
             A = qd_gz_impl::Acc();
         }
     }
+    if (text_filter) {
+        // A stream with many stretches of which the probe found (next to) no block start: not text -- its real block headers were
+        // refused with the false ones, and one lane would have to decode it all.  Everything once more with the plain probe.
+        bool again = false;
+        for (int i = 0; i < n; ++i) {
+            if (n_st[(size_t)i] < 8) continue;
+            const size_t cands = cand_at[(size_t)i + 1] - cand_at[(size_t)i];
+            again = again || 16 * cands < n_st[(size_t)i];
+        }
+        if (again) {
+            ++G.st_.plain_probes;
+            return decode(steps, n, st, slots_per_byte, false);
+        }
+    }
     if (per_byte < 8) {
         bool again = false;
         for (int i = 0; i < n; ++i) again = again || steps[i].failed == QD_INFLATE_TOKEN_SPACE;
-        if (again) return decode(steps, n, st, 8);  // (everything once more: rare -- text that compresses beyond four tokens a byte)
+        if (again) return decode(steps, n, st, 8, text_filter);  // (everything once more: rare -- text that compresses beyond four tokens a byte)
     }
     return hipSuccess;
 }

@@ -615,9 +615,9 @@ def dev_gunzip(gz, out_cap, device_id=0, step_bytes=64 << 20, stretch_bytes=0, u
     src = np.frombuffer(gz, dtype=np.uint8) if len(gz) else np.zeros(1, np.uint8)
     out = np.empty(max(int(out_cap), 1), dtype=np.uint8)
     n = C.c_int64(0)
-    st = (C.c_int64 * 6)()
+    st = (C.c_int64 * 8)()
     r = lib.qd_dev_gunzip(int(device_id), _ptr(src), len(gz), _ptr(out), int(out_cap), C.byref(n), int(step_bytes), int(stretch_bytes), int(unit_text), st)
-    stats = dict(zip(("members", "steps", "stretches", "units", "chain_retries", "partial_last"), [int(x) for x in st]))
+    stats = dict(zip(("members", "steps", "stretches", "units", "chain_retries", "partial_last", "plain_probes"), [int(x) for x in st]))
     if r != QD_OK:
         e = QuadeHipError(r, "qd_dev_gunzip: the device did not inflate the stream")
         e.stats = stats

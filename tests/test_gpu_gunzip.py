@@ -60,6 +60,22 @@ def test_device_gunzip_many_stretches_are_decoded_in_parallel_and_proven_by_the_
     got, st = hb.dev_gunzip(gz, len(text), step_bytes=8 << 20)
     assert got == text
     assert st["steps"] >= 2 and st["units"] > 0.8 * (len(gz) / 32768), st
+    # the probe's text filter: (next to) no header "held" where no block starts, and the stream was not taken for binary
+    assert st["plain_probes"] == 0 and st["chain_retries"] <= 0.02 * st["units"], st
+
+
+def test_device_gunzip_bytes_that_are_not_text_take_the_plain_probe():
+    """Dynamic-Huffman blocks whose literals are not text: the probe's text filter refuses their headers, the decode notices
+    (stretches without block starts) and runs again without it -- same bytes out, counted."""
+    from quade_amd import hip_backend as hb
+    rng = np.random.default_rng(11)
+    v = np.minimum(rng.geometric(0.08, 6_000_000), 120).astype(np.uint8) + 128  # many byte values >= 128, geometrically rarer
+    text = bytes(v)
+    gz = _gz(text, 6)
+    assert len(gz) > 16 * 32768
+    got, st = hb.dev_gunzip(gz, len(text), step_bytes=2 << 20)
+    assert got == text
+    assert st["plain_probes"] >= 1, st
 
 
 def test_device_gunzip_several_members_and_a_member_inside_a_step():
