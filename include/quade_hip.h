@@ -438,8 +438,8 @@ int qd_sink_device_members(qd_sink* sink, int64_t* device_members); /* of qd_sin
  * plain .fastq.gz files, and its fixtures test/dataset/[*].fastq.gz are single gzip members.  The pipeline (qd_pipe_run) feeds such
  * files through these kernels; this entry point inflates a whole file image for tests and measurements: gz[0 .. gz_len) = one or more
  * gzip members -> out (at most out_cap bytes), *out_len = the text's size.  Every member's CRC-32 and ISIZE are checked.  step_bytes:
- * compressed bytes per step (what the pipeline takes per batch and stream); stretch_bytes / unit_text: 0 = the defaults (32 KiB of
- * compressed bytes per decoding lane, 1 MiB of text per resolving workgroup).  stats (may be NULL): int64[8] = members, steps,
+ * compressed bytes per step (what the pipeline takes per batch and stream); stretch_bytes / unit_text: 0 = the defaults (16 KiB of
+ * compressed bytes per probed stretch, at most 2 MiB of text per resolving workgroup).  stats (may be NULL): int64[8] = members, steps,
  * stretches probed, units decoded, units dropped (a false block start: their predecessor ran through them), steps that ended inside
  * a block, decodes done again without the probe's text filter (the stream is not text), 0.
  * QD_ERR_FORMAT: not gzip, damaged, or beyond what the device decodes (the pipeline then hands the file to the host's inflater). */

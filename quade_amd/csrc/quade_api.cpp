@@ -1627,7 +1627,7 @@ extern "C" int qd_dev_gunzip(int device_id, const uint8_t* gz, int64_t gz_len, u
     int rc = QD_OK;
     qd_gz G;
     if (stretch_bytes > 0) G.stretch_bytes = (uint64_t)stretch_bytes;
-    if (unit_text > 0) G.unit_text = (uint64_t)unit_text;
+    if (unit_text > 0) G.unit_text = (uint64_t)unit_text, G.unit_text_given = true;
     int64_t members = 0, steps_run = 0;
     auto done = [&](int code) {
         if (st) (void)hipStreamSynchronize(st);

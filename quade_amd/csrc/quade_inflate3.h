@@ -72,7 +72,8 @@ class qd_gz {
     // step by step drains the device every time
     hipError_t reserve(uint64_t comp_bytes, uint64_t text_bytes);
     // knobs (tests: small values make many stretches and units out of small inputs)
-    uint64_t stretch_bytes = 32u << 10;  // compressed bytes per stretch: a lane decodes one
+    uint64_t stretch_bytes = 16u << 10;  // compressed bytes per stretch: a lane decodes one
+    bool unit_text_given = false;        // unit_text is an order (tests, A/B runs), not an upper bound
     uint64_t unit_text = 2u << 20;       // text per resolve unit, about (the windows kernel walks a stream's units one after the other)
 
   private:

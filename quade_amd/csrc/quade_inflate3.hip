@@ -683,7 +683,15 @@ __global__ __launch_bounds__(NT) void gz_resolve(const GzUnit* units, uint32_t n
                         continue;
                     }
                     const uint32_t a = max(d0, wlo), z = min(d0 + len, whi);
-                    for (uint32_t p = a; p < z; ++p) par[p - wlo] = (uint16_t)rix(p - dist);  // (p - dist may be "negative": rix adds the window)
+                    // (the source's place in the ring, from the window's: p - dist lies between 32 Ki in front of the window and its
+                    //  end -- one wrap either way instead of a division per byte)
+                    int32_t src = (int32_t)rb + (int32_t)(a - wlo) - (int32_t)dist;
+                    src += src < 0 ? (int32_t)RN : 0;
+                    for (uint32_t p = a; p < z; ++p) {
+                        par[p - wlo] = (uint16_t)src;
+                        ++src;
+                        src -= src >= (int32_t)RN ? (int32_t)RN : 0;
+                    }
                 }
             }
             base_pos += total;
@@ -950,15 +958,15 @@ class qd_gz_impl {
 qd_gz::qd_gz() : p_(new qd_gz_impl()) {
     const int st = env_int("QUADE_GZ_STRETCH_KB", 0), ut = env_int("QUADE_GZ_UNIT_KB", 0);  // (measurement knobs)
     if (st > 0) stretch_bytes = (uint64_t)st << 10;
-    if (ut > 0) unit_text = (uint64_t)ut << 10;
+    if (ut > 0) unit_text = (uint64_t)ut << 10, unit_text_given = true;
 }
 qd_gz::~qd_gz() { delete p_; }
 qd_gz_stats qd_gz::stats() const { return p_->st_; }
 
 hipError_t qd_gz::reserve(uint64_t comp_bytes, uint64_t text_bytes) {
     qd_gz_impl& G = *p_;
-    const uint64_t stretch = std::max<uint64_t>(stretch_bytes, 256), n_st = comp_bytes / stretch + 64, n_units = text_bytes / std::max<uint64_t>(unit_text, 1024) + n_st / 8 + 64;
-    GZCHK(G.d_tokens.need((size_t)std::min<uint64_t>(comp_bytes * 16 + n_st * 8192, 0xFFFF0000ull * 2)));
+    const uint64_t stretch = std::max<uint64_t>(stretch_bytes, 256), n_st = comp_bytes / stretch + 64, n_units = text_bytes / std::min<uint64_t>(std::max<uint64_t>(unit_text, 1024), 256u << 10) + n_st / 8 + 64;
+    GZCHK(G.d_tokens.need((size_t)std::min<uint64_t>(comp_bytes * 8 + n_st * 8192, 0xFFFF0000ull * 2)));  // (four slots a byte: a second try at eight grows it)
     GZCHK(G.d_sym.need((size_t)text_bytes * 2 + 4096));
     GZCHK(G.d_stretch.need((size_t)n_st * sizeof(GzStretch)));
     GZCHK(G.d_found.need((size_t)n_st * 8));
@@ -1221,7 +1229,17 @@ hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st, int slots_per
 
 hipError_t qd_gz::resolve(qd_gz_step* steps, int n, uint8_t* const* out, hipStream_t st) {
     qd_gz_impl& G = *p_;
-    const uint64_t UNIT_TEXT = std::max<uint64_t>(unit_text, 1024);
+    // Text per unit (one resolving workgroup, two of them per CU: 512 in flight).  Given (a test, a measurement): as given.  Else the
+    // launch's text in whole rounds of 508 units of at most unit_text each -- 750 units of 2 MB took two rounds of which the second was
+    // half empty (profiles/r05_e2e_gz_timeline_before.txt: 16.5 ms) -- and at least 256 KB: every unit costs a window of its own.
+    uint64_t UNIT_TEXT = std::max<uint64_t>(unit_text, 1024);
+    if (!unit_text_given) {
+        uint64_t total = 0;
+        for (int i = 0; i < n; ++i)
+            if (!steps[i].failed) total += steps[i].text_len;
+        const uint64_t rounds = std::max<uint64_t>(1, (total + UNIT_TEXT * 508 - 1) / (UNIT_TEXT * 508));
+        UNIT_TEXT = std::max<uint64_t>(256u << 10, total / (rounds * 508) + 1);
+    }
     // units of ~1 MB of text: runs of accepted stretches; chains: a stream's units in order
     G.gzunits_.clear();
     G.unit_step_.clear();

@@ -623,10 +623,16 @@ __global__ __launch_bounds__(256) void format_records(PlanParams p, qd_format_ar
 constexpr uint32_t CRC_SLICE = 256;  // bytes per lane: 256 lanes cover a 64 KiB range
 
 // the workgroup's CRC-32 of text[off .. off + len), len <= 64 KiB; the result is valid in thread 0
+// The range comes into LDS first, by loads that neighbouring lanes make from neighbouring dwords; every lane then takes its 256-byte
+// slice from there (rows of 64 dwords padded to 65: lane L's k-th dword lies in bank L + k).  The first form had every lane read its
+// slice from global memory a dword at a time: one load instruction touched 64 cache lines for 256 useful bytes, the lines were
+// gone from the CU's cache before their other 31 dwords were asked for, and the kernel moved ~30 bytes from HBM per byte of text
+// (profiles/r05_e2e_gz_timeline_before.txt: 6.1 ms for 1.5 GB).
 __device__ __forceinline__ uint32_t crc32_range(const uint8_t* text, uint64_t off, uint32_t len_in) {
     __shared__ uint32_t T[4][256];
     __shared__ uint32_t X8[32];
     __shared__ uint32_t part[4];
+    __shared__ uint32_t D[256 * 65 + 8];
     const uint32_t tid = threadIdx.x;
     {
         uint32_t c = tid;
@@ -634,6 +640,13 @@ __device__ __forceinline__ uint32_t crc32_range(const uint8_t* text, uint64_t of
         T[0][tid] = c;
     }
     if (tid == 0) qd_crc_pow_table(X8);
+    const uint32_t len = len_in > 256u * CRC_SLICE ? 256u * CRC_SLICE : len_in;
+    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(text + off) & 3u);  // the range starts `sh` bytes into its first dword
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(text + off - sh);
+        const uint32_t nd = len ? (sh + len + 3u) >> 2 : 0u;
+        for (uint32_t d = tid; d < nd; d += 256u) D[d + (d >> 6)] = src[d];
+    }
     __syncthreads();
     {
         uint32_t c = T[0][tid];
@@ -643,19 +656,22 @@ __device__ __forceinline__ uint32_t crc32_range(const uint8_t* text, uint64_t of
         }
     }
     __syncthreads();
-    const uint32_t len = len_in > 256u * CRC_SLICE ? 256u * CRC_SLICE : len_in;
     const uint32_t beg = min(tid * CRC_SLICE, len), end = min(beg + CRC_SLICE, len);
     uint32_t term = 0;
     if (end > beg) {
-        const uint8_t* p = text + off + beg;
-        const uint8_t* e = text + off + end;
+        auto byte_at = [&](uint32_t j) {
+            const uint32_t b = sh + j, d = b >> 2;
+            return (D[d + (d >> 6)] >> (8u * (b & 3u))) & 0xFFu;
+        };
+        uint32_t j = beg;
         uint32_t c = 0xFFFFFFFFu;
-        while (p < e && ((uintptr_t)p & 3u)) c = (c >> 8) ^ T[0][(c ^ *p++) & 0xFFu];
-        for (; p + 4 <= e; p += 4) {
-            c ^= *reinterpret_cast<const uint32_t*>(p);
+        while (j < end && ((sh + j) & 3u)) c = (c >> 8) ^ T[0][(c ^ byte_at(j++)) & 0xFFu];
+        for (; j + 4 <= end; j += 4) {
+            const uint32_t d = (sh + j) >> 2;
+            c ^= D[d + (d >> 6)];
             c = T[3][c & 0xFFu] ^ T[2][(c >> 8) & 0xFFu] ^ T[1][(c >> 16) & 0xFFu] ^ T[0][c >> 24];
         }
-        while (p < e) c = (c >> 8) ^ T[0][(c ^ *p++) & 0xFFu];
+        while (j < end) c = (c >> 8) ^ T[0][(c ^ byte_at(j++)) & 0xFFu];
         // crc(A || B) = crc(A) * x^(8 |B|) + crc(B) mod P: this lane's share of the range's CRC
         term = qd_crc_mulmod(~c, qd_crc_xpow8(X8, len - end));
     }
