@@ -457,14 +457,6 @@ __device__ bool gz_header_holds(const uint32_t* base, uint64_t bit, uint64_t bit
 //   3. the run-length coded lengths decode and both codes are complete: their survivors, 16 or more at a time.
 // (With all three inside one function a wave paid the second on every iteration and the third on one in 25 -- some lane always
 //  needs them: 18 ms per launch, as long as the token kernel.  profiles/r05_gz_first_form.txt)
-__device__ __forceinline__ bool gz_stage1(const uint32_t* base, uint64_t bit, uint64_t bit_end) {
-    if (bit + 17 + 12 > bit_end) return false;
-    const uint64_t w = bit >> 5;
-    const uint32_t sh = (uint32_t)bit & 31u;
-    const uint64_t two = (uint64_t)base[w] | ((uint64_t)base[w + 1] << 32);
-    const uint32_t x = (uint32_t)(two >> sh);
-    return (x & 7u) == 4u && ((x >> 3) & 31u) <= 29u && ((x >> 8) & 31u) <= 29u;
-}
 __device__ __forceinline__ bool gz_stage2(const uint32_t* base, uint64_t bit) {
     const uint32_t ncl = ((uint32_t)(gz_bits(base, bit) >> 13) & 15u) + 4u;
     const uint64_t x = gz_bits(base, bit + 17);
@@ -478,7 +470,13 @@ __device__ __forceinline__ bool gz_stage2(const uint32_t* base, uint64_t bit) {
 }
 
 // found[i] = the first position in [bit_from, bit_to) of stretch i at which a dynamic block's header holds, or ~0.  One wave per stretch.
+// Stage 1 takes 2 048 positions a step: a lane holds 64 bits of the stream and tests its 32 positions at once with shifts and ands of
+// the whole word (bits b .. b+2 = 0 0 1; the upper four bits of both counts not all set: a count of 30 or 31) -- ~60 instructions for
+// what the first form spent 32 iterations of ~40 on.  Its survivors (one position in nine) are written to a queue in ascending
+// order and go through stage 2 sixty-four at a time; what survives that waits for stage 3 as before.
 constexpr uint32_t GZ_Q2_RUN = 16;  // survivors of stage 2 that wait for a stage-3 pass at most (a true block start waits with them)
+constexpr uint32_t GZ_Q1_CAP = 704;  // (bits 0 0 1 cannot start at two of three neighbouring positions: at most 683 of 2 048 pass)
+constexpr uint32_t GZ_PROBE_LDS = 64 * 128 + (GZ_Q1_CAP + 128) * 4;
 __global__ __launch_bounds__(64) void gz_probe(const GzStretch* stretches, uint32_t n, uint64_t* found, uint32_t text_only) {
     extern __shared__ __attribute__((aligned(16))) uint8_t probe_lds[];
     const uint32_t i = blockIdx.x, lane = threadIdx.x;
@@ -486,12 +484,11 @@ __global__ __launch_bounds__(64) void gz_probe(const GzStretch* stretches, uint3
     const GzStretch st = stretches[i];
     uint8_t* clt = probe_lds + 128u * lane;
     typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
-    lds_vu32* q1 = (lds_vu32*)(probe_lds + 64 * 128);  // offsets (from bit_from) that passed stage 1: up to 128
-    lds_vu32* q2 = q1 + 128;                            // ... stage 2: up to 64 + 64
-    uint32_t n1 = 0, n2 = 0;                                            // (wave-uniform)
+    lds_vu32* q1 = (lds_vu32*)(probe_lds + 64 * 128);  // positions (bits from the step's first) that passed stage 1
+    lds_vu32* q2 = q1 + GZ_Q1_CAP;                      // offsets from bit_from that passed stage 2: up to 16 + 64 wait
+    uint32_t n2 = 0;                                    // (wave-uniform)
     uint64_t hit = ~0ull;
-    const uint64_t span = st.bit_to > st.bit_from ? st.bit_to - st.bit_from : 0;
-    auto stage3 = [&]() {  // every queued survivor of stage 2 (at most 128, ascending): the first that holds, if any
+    auto stage3 = [&]() {  // every queued survivor of stage 2 (ascending): the first that holds, if any
         for (uint32_t b = 0; b < n2 && hit == ~0ull; b += 64) {
             const bool have = b + lane < n2;
             const uint64_t bit = st.bit_from + (have ? q2[b + lane] : 0u);
@@ -501,41 +498,49 @@ __global__ __launch_bounds__(64) void gz_probe(const GzStretch* stretches, uint3
         }
         n2 = 0;
     };
-    auto stage2 = [&](uint32_t count) {  // the first `count` queued survivors of stage 1 (<= 64)
-        const bool have = lane < count;
-        const uint32_t off = have ? q1[lane] : 0u;
-        const bool ok = have && gz_stage2(st.base, st.bit_from + off);
-        const uint64_t m = __ballot(ok);
-        if (ok) q2[n2 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = off;
-        n2 += (uint32_t)__popcll(m);
-        // the rest of the queue moves up
-        const uint32_t rest = n1 - count;
-        const uint32_t a = lane < rest ? q1[count + lane] : 0u, b2 = 64 + lane < rest ? q1[count + 64 + lane] : 0u;
-        if (lane < rest) q1[lane] = a;
-        if (64 + lane < rest) q1[64 + lane] = b2;
-        n1 = rest;
-    };
+    // a position needs 29 bits of input behind it (the three header bits, the counts, four lengths of the code-length code), and lies in [bit_from, bit_to)
+    const uint64_t p_end = min(st.bit_to, st.bit_end >= 29 ? st.bit_end - 28 : 0ull);
 #pragma unroll 1
-    for (uint64_t at = 0; at < span && hit == ~0ull; at += 64) {
-        const uint64_t off = at + lane;
-        const bool ok = off < span && gz_stage1(st.base, st.bit_from + off, st.bit_end);
-        const uint64_t m = __ballot(ok);
-        if (ok) q1[n1 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)off;
-        n1 += (uint32_t)__popcll(m);
-        if (n1 >= 64) {
-            stage2(64);
-            if (n2 >= GZ_Q2_RUN) stage3();
+    for (uint64_t p0 = st.bit_from & ~31ull; p0 < p_end && hit == ~0ull; p0 += 2048) {
+        const uint64_t mine = p0 + 32u * lane;  // this lane's positions: mine + [0, 32)
+        uint32_t mask = 0;
+        if (mine < p_end && mine + 32 > st.bit_from) {
+            const uint64_t w = mine >> 5;
+            const uint64_t two = (uint64_t)st.base[w] | ((uint64_t)st.base[w + 1] << 32);
+            const uint64_t a = ~two & ~(two >> 1) & (two >> 2);                                  // not the last block, dynamic codes
+            const uint64_t hl = (two >> 4) & (two >> 5) & (two >> 6) & (two >> 7);               // 30 or 31 literal/length codes + 257
+            const uint64_t hd = (two >> 9) & (two >> 10) & (two >> 11) & (two >> 12);            // 30 or 31 distance codes + 1
+            mask = (uint32_t)(a & ~hl & ~hd);
+            if (mine < st.bit_from) mask &= ~0u << (uint32_t)(st.bit_from - mine);
+            if (mine + 32 > p_end) mask &= ~0u >> (uint32_t)(mine + 32 - p_end);
+        }
+        // ascending into q1: this lane's survivors behind those of the lanes below it
+        uint32_t cnt = (uint32_t)__popc(mask), incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(incl, d, 64);
+            if (lane >= (uint32_t)d) incl += y;
+        }
+        const uint32_t n1 = __shfl(incl, 63, 64);
+        {
+            uint32_t at = incl - cnt;
+            for (uint32_t m = mask; m; m &= m - 1u) q1[at++] = 32u * lane + (uint32_t)__builtin_ctz(m);
+        }
+        // stage 2, sixty-four at a time
+        for (uint32_t b = 0; b < n1; b += 64) {
+            const bool have = b + lane < n1;
+            const uint64_t pos = p0 + (have ? q1[b + lane] : 0u);
+            const bool ok = have && gz_stage2(st.base, pos);
+            const uint64_t m = __ballot(ok);
+            if (ok) q2[n2 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(pos - st.bit_from);
+            n2 += (uint32_t)__popcll(m);
+            if (n2 >= GZ_Q2_RUN) {
+                stage3();
+                if (hit != ~0ull) break;
+            }
         }
     }
-    if (hit == ~0ull) {  // what is still queued (ascending: anything here lies behind every offset checked so far)
-        if (n1) stage2(n1 > 64 ? 64 : n1);
-        stage3();
-        if (n1 && hit == ~0ull) stage2(n1);
-        if (hit == ~0ull) stage3();
-    } else {
-        // a hit: queued survivors of stage 1 / 2 in FRONT of it were all checked (the queues are worked off in order, and stage 3 takes
-        // the first of its batch) -- except those of stage 1 still waiting, which lie behind every entry of q2: none can be smaller
-    }
+    if (hit == ~0ull) stage3();
     if (lane == 0) found[i] = hit;
 }
 
@@ -714,8 +719,11 @@ struct GzChain {
     uint32_t pad;
     uint8_t* carried;              // 32 KiB: in: the text in front of the first unit (its last `valid` bytes count); out: in front of the next launch
 };
+// Thread t owns symbols [32 t, 32 t + 32) of every unit's window: the next unit's 64 bytes of symbols are on their way (four 16-byte
+// loads) while this unit's are mapped, so a step costs LDS work and one barrier, not a trip to memory per symbol (the first form
+// loaded its symbols one by one inside the step: 16 us a unit, 6.8 ms for the longest stream's 420 units).
 __global__ __launch_bounds__(1024) void gz_windows(const GzChain* chains, const GzUnit* units, const uint16_t* wout, uint8_t* win_in, int32_t* chain_status) {
-    __shared__ uint8_t W[2][GZ_WIN];
+    __shared__ __attribute__((aligned(16))) uint8_t W[2][GZ_WIN];
     __shared__ uint32_t bad;
     const GzChain C = chains[blockIdx.x];
     const uint32_t tid = threadIdx.x;
@@ -724,30 +732,71 @@ __global__ __launch_bounds__(1024) void gz_windows(const GzChain* chains, const 
     __syncthreads();
     uint32_t cur = 0;
     uint64_t have = C.valid;  // text that exists in front of the current unit (saturates at 32 Ki)
-    for (uint32_t u = C.first_unit; u < C.first_unit + C.n_units; ++u) {
-        uint32_t* wi = reinterpret_cast<uint32_t*>(win_in + (size_t)u * GZ_WIN);
-        for (uint32_t j = tid; j < GZ_WIN / 4; j += 1024) wi[j] = reinterpret_cast<const uint32_t*>(W[cur])[j];
-        const uint16_t* wo = wout + (size_t)u * GZ_WIN;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 nx[4];
+    const uint32_t u_end = C.first_unit + C.n_units;
+    auto fetch = [&](uint32_t u) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(wout + (size_t)u * GZ_WIN + 32u * tid);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nx[k] = src[k];
+    };
+    if (C.n_units) fetch(C.first_unit);
+    for (uint32_t u = C.first_unit; u < u_end; ++u) {
+        u32x4 sy[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sy[k] = nx[k];
+        if (u + 1 < u_end) fetch(u + 1);
+        const uint64_t utext = units[u].text_len;
+        {   // the window in front of this unit: what its markers (and gz_fixup's) refer to
+            const u32x4* w = reinterpret_cast<const u32x4*>(W[cur] + 32u * tid);
+            u32x4* wi = reinterpret_cast<u32x4*>(win_in + (size_t)u * GZ_WIN + 32u * tid);
+            wi[0] = w[0];
+            wi[1] = w[1];
+        }
         const uint32_t floor_idx = have >= GZ_WIN ? 0u : GZ_WIN - (uint32_t)have;  // markers below it point in front of the stream's start
-        for (uint32_t j = tid; j < GZ_WIN; j += 1024) {
-            const uint32_t s = wo[j];
-            uint32_t b = s;
-            if (s & GZ_MARK) {
-                const uint32_t i = s & 0x7FFFu;
-                if (i < floor_idx) {
-                    // (a marker in front of the stream's start can only be one of this unit's own untouched window slots when the
-                    //  unit's text is shorter than 32 Ki: those bytes do not exist and nobody may refer to them)
-                    b = 0;
-                    if (j >= GZ_WIN - min((uint64_t)GZ_WIN, units[u].text_len + have)) bad = 1;
-                } else {
-                    b = W[cur][i];
+        const uint32_t own_from = GZ_WIN - (uint32_t)min((uint64_t)GZ_WIN, utext + have);
+        uint32_t outw[8];
+        bool any_bad = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t two = sy[k][q];
+                uint32_t packed = 0;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t s = (two >> (16 * h)) & 0xFFFFu, j = 32u * tid + 8u * (uint32_t)k + 2u * (uint32_t)q + (uint32_t)h;
+                    uint32_t b = s;
+                    if (s & GZ_MARK) {
+                        const uint32_t i = s & 0x7FFFu;
+                        if (i < floor_idx) {
+                            // (a marker in front of the stream's start can only be one of this unit's own untouched window slots when the
+                            //  unit's text is shorter than 32 Ki: those bytes do not exist and nobody may refer to them)
+                            b = 0;
+                            any_bad = any_bad || j >= own_from;
+                        } else {
+                            b = W[cur][i];
+                        }
+                    }
+                    packed |= (b & 0xFFu) << (8 * h);
                 }
+                const int at = 8 * k + 2 * q;  // byte index within the thread's 32
+                if ((at & 3) == 0) outw[at >> 2] = packed;
+                else outw[at >> 2] |= packed << 16;
             }
-            W[cur ^ 1][j] = (uint8_t)b;
+        }
+        if (any_bad) bad = 1;
+        {
+            u32x4* o = reinterpret_cast<u32x4*>(W[cur ^ 1] + 32u * tid);
+            u32x4 a0, a1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a0[k] = outw[k], a1[k] = outw[4 + k];
+            o[0] = a0;
+            o[1] = a1;
         }
         __syncthreads();
         cur ^= 1;
-        have = min<uint64_t>(GZ_WIN, have + units[u].text_len);
+        have = min<uint64_t>(GZ_WIN, have + utext);
     }
     for (uint32_t j = tid; j < GZ_WIN / 4; j += 1024) reinterpret_cast<uint32_t*>(C.carried)[j] = reinterpret_cast<const uint32_t*>(W[cur])[j];
     __syncthreads();
@@ -1025,7 +1074,7 @@ hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st, int slots_per
         GZCHK(G.h_found.need(probe.size() * std::max(sizeof(GzStretch), (size_t)8)));
         memcpy(G.h_found.p, probe.data(), probe.size() * sizeof(GzStretch));
         GZCHK(hipMemcpyAsync(G.d_stretch.p, G.h_found.p, probe.size() * sizeof(GzStretch), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(gz_probe, dim3((uint32_t)probe.size()), dim3(64), 64 * 128 + 256 * 4, st, G.d_stretch.as<GzStretch>(), (uint32_t)probe.size(), G.d_found.as<uint64_t>(),
+        hipLaunchKernelGGL(gz_probe, dim3((uint32_t)probe.size()), dim3(64), GZ_PROBE_LDS, st, G.d_stretch.as<GzStretch>(), (uint32_t)probe.size(), G.d_found.as<uint64_t>(),
                            text_filter ? 1u : 0u);
         GZCHK(hipGetLastError());
         GZCHK(hipStreamSynchronize(st));  // (the table above has been read: the staging buffer takes the answer)
