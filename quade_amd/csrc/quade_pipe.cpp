@@ -1677,7 +1677,10 @@ int reserve_buffers(qd_pipe* p, uint32_t B, uint32_t n_dest) {
             text += t;
             for (int k = 0; k < 2; ++k) PCHK(p, w.gz.comp[k].need((size_t)c + SEG_BYTES, k == w.gz.ccur ? (size_t)w.gz.comp_len : 0, p->cs));
         }
-        if (comp && p->gz) PCHK(p, p->gz->reserve(comp, text));
+        if (comp && p->gz) {
+            Tick tick(g_alloc_seconds);  // (the gzip kernels' buffers are the largest of a batch of gzip streams)
+            PCHK(p, p->gz->reserve(comp, text));
+        }
     }
     if (p->inflate_form == 3) {  // a batch's blocks of all streams go down together: ~a block per 64 KiB of text
         size_t blocks3 = 0;

@@ -282,6 +282,27 @@ def test_clean_bgzf_input_never_touches_the_host_fallbacks(tmp_path, level):
     assert st["text_segments"] == 0, st
 
 
+def test_a_second_pipeline_of_the_process_reuses_the_first_ones_device_buffers(tmp_path):
+    """quade_pool.h: a destroyed pipeline's device buffers wait on a per-device list for the next one (hipMalloc of a batch's ~25 GB
+    takes 0.05 .. 1.2 s on this pool's boxes); qd_pool_trim gives them back.  Same job twice: same outputs, and the second run's
+    time inside device allocations is a small part of the first's."""
+    from quade_amd import hip_backend as hb
+    rng = np.random.default_rng(17)
+    data = tmp_path / "data"
+    data.mkdir()
+    files, samples = _dataset(str(data), rng, 1, 30000, 6, fmt="gz", read_len=80)
+    lib = hb.load_library()
+    assert lib.qd_pool_trim() == hb.QD_OK  # (what earlier tests of this process left: the first run allocates)
+    runs = []
+    for k in range(2):
+        sub = tmp_path / ("run%d" % k)
+        sub.mkdir()
+        runs.append(_run_and_compare(sub, files, samples, "[gpu]\nbatch_pairs : 20000\n"))
+    assert runs[0]["pairs"] == runs[1]["pairs"] == 30000 and runs[1]["gzip_fallbacks"] == 0
+    assert runs[1]["alloc_s"] <= 0.5 * runs[0]["alloc_s"] + 0.002, (runs[0]["alloc_s"], runs[1]["alloc_s"])
+    assert lib.qd_pool_trim() == hb.QD_OK
+
+
 def test_pipeline_write_flags_and_level_minus_one(tmp_path):
     rng = np.random.default_rng(13)
     data = tmp_path / "data"
