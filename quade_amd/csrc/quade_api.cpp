@@ -320,7 +320,18 @@ int rebuild(qd_ctx* c) {
                Lu.seq_off[1] == Pu.idx2_start && Lu.seq_stride[0] == ((8 + mw + 1) & ~1) && Lu.seq_stride[1] == 8 && Lu.qual_stride[0] == 8 &&
                Lu.qual_stride[1] == 8;
     }();
-    c->lds_strip_bytes = (c->lay.mol_width > 0 && (c->lay.mol_width % 4 == 0 || umi1) && c->opt_mol_strips) ? (size_t)128 * c->lay.mol_width : 0;
+    // "UMI in both index reads" (StaticUmi2, r05): the same in both reads -- rows of 18 / 20 bytes in both streams, 18 .. 24 bytes of
+    // molecular index per pair
+    const bool umi2 = [&] {
+        const qd_layout& Lu = c->lay;
+        const qd_plan& Pu = c->plan;
+        const int mw = Pu.mol1_end - Pu.mol1_start;
+        return Lu.n_streams == 2 && K == 16 && Pu.idx1_end - Pu.idx1_start == 8 && Pu.idx2_end - Pu.idx2_start == 8 && mw >= 9 && mw <= 12 &&
+               Pu.mol2_end - Pu.mol2_start == mw && Lu.mol_width == 2 * mw && Pu.mol1_start == Pu.idx1_end && Pu.mol2_start == Pu.idx2_end &&
+               Lu.seq_off[0] == Pu.idx1_start && Lu.seq_off[1] == Pu.idx2_start && Lu.seq_stride[0] == ((8 + mw + 1) & ~1) &&
+               Lu.seq_stride[1] == ((8 + mw + 1) & ~1) && Lu.qual_stride[0] == 8 && Lu.qual_stride[1] == 8;
+    }();
+    c->lds_strip_bytes = (c->lay.mol_width > 0 && (c->lay.mol_width % 4 == 0 || umi1 || umi2) && c->opt_mol_strips) ? (size_t)128 * c->lay.mol_width : 0;
     if (c->lds_bytes + 16 * c->lds_strip_bytes > 150 * 1024) c->lds_strip_bytes = 0;  // 16 waves per workgroup at most
 
     const qd_layout& L = c->lay;
@@ -331,7 +342,7 @@ int rebuild(qd_ctx* c) {
         const int mw = (k == 0 ? c->plan.mol1_end - c->plan.mol1_start : c->plan.mol2_end - c->plan.mol2_start);
         ok = ok && mw <= 8 && L.qual_width[k] <= 8;
     }
-    c->fast_ok = ok || ((c->wide || umi1) && c->lds_bytes <= 150 * 1024);
+    c->fast_ok = ok || ((c->wide || umi1 || umi2) && c->lds_bytes <= 150 * 1024);
 
     c->cnt_stride = (uint32_t)((2 * S + 1 + 3) & ~3);
     // one counter row per workgroup (modulo), capped at 64 MiB of rows for very large tables

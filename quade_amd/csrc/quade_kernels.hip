@@ -1009,6 +1009,180 @@ struct RowsU {
     }
 };
 
+// ---- RowsU2 (r05): BOTH index reads = 8-base barcode + a molecular index of 9..12 bases right behind it (the same width in both:
+// UMI-carrying i7 and i5 adapters), the fused molecular index 18..24 bytes per pair (Quade.py:218 / :247: index 1's slice, then
+// index 2's).  Two streams of 18 / 20-byte rows -- three 16-byte loads each per lane, as RowsU's first stream -- and the two
+// 8-byte quality rows; the molecular bytes leave through the wave's LDS strip as RowsU's do, in up to three rounds of 16-byte
+// pieces (128 x M <= 3 072 bytes per wave and step).  Static only; until r05 these layouts ran the generic kernel (0.13-0.17 of
+// peak: VERDICT r04 missing #4).
+template <int MW>
+struct StaticUmi2 {
+    static constexpr bool STATIC = true;
+    static constexpr int MOLW = 2 * MW;
+    static constexpr int MW1 = MW;
+    static constexpr int STRIDE = (8 + MW + 1) & ~1;
+    static_assert(MW > 8 && MW <= 12, "molecular indexes of 9..12 bases behind 8-base barcodes");
+    static __device__ __forceinline__ void apply(DemuxParams& p) {
+        p.n_streams = 2;
+        p.K = 16;
+        p.M = 2 * MW;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            p.seq_stride[k] = STRIDE;
+            p.qual_stride[k] = 8;
+            p.idx_off[k] = 0;
+            p.idx_w[k] = 8;
+            p.idx_mask[k] = ~0ull;
+            p.mol_off[k] = 8;
+            p.mol_w[k] = MW;
+            p.mol_mask[k] = ~0ull;
+        }
+    }
+    static bool matches(const DemuxParams& p) {
+        bool ok = p.n_streams == 2 && p.K == 16 && p.M == 2 * MW;
+        for (int k = 0; k < 2; ++k)
+            ok = ok && p.seq_stride[k] == STRIDE && p.qual_stride[k] == 8 && p.idx_off[k] == 0 && p.idx_w[k] == 8 && p.mol_w[k] == MW && p.mol_off[k] == 8;
+        return ok;
+    }
+};
+
+// the fused molecular index of RowsU2: three words per pair (bytes [0, M), M = 2 MW <= 24)
+struct Mol3 {
+    u64 w[3];
+};
+template <int MW>
+__device__ __forceinline__ Mol3 fuse_mol3(u64 a_lo, u64 a_hi, u64 b_lo, u64 b_hi) {  // a: MW bytes (a_hi holds bytes 8 .. MW-1), then b
+    constexpr int R = MW - 8;                 // bytes of a word 1 that belong to a: 1 .. 4
+    constexpr u64 HI = (1ull << (8 * R)) - 1;
+    Mol3 m;
+    m.w[0] = a_lo;
+    m.w[1] = (a_hi & HI) | (b_lo << (8 * R));
+    m.w[2] = (b_lo >> (64 - 8 * R)) | ((b_hi & HI) << (8 * R));
+    return m;
+}
+// codes and molecular bytes of a lane's pair(s) on a guarded tile: plain stores
+__device__ __forceinline__ void store_unit3(const DemuxParams& p, int64_t p0, bool two, uint32_t c0, uint32_t c1, const Mol3& m0, const Mol3& m1) {
+    if (two)
+        st_wt(reinterpret_cast<uint32_t*>(p.codes + p0), c0 | (c1 << 16));
+    else
+        p.codes[p0] = (uint16_t)c0;
+    const int M = p.M;
+    uint8_t* d = p.mol + p0 * M;
+    for (int j = 0; j < M; ++j) {
+        d[j] = (uint8_t)(m0.w[j >> 3] >> (8 * (j & 7)));
+        if (two) d[M + j] = (uint8_t)(m1.w[j >> 3] >> (8 * (j & 7)));
+    }
+}
+// full tiles: the wave's 128 x M contiguous bytes through its LDS strip (store_mol_wave for three words per pair; one step's strip)
+template <int M>
+__device__ __forceinline__ void store_mol_wave3(const DemuxParams& p, uint8_t* strips, int64_t p0, const Mol3& m0, const Mol3& m1) {
+    static_assert(M % 2 == 0 && M > 16 && M <= 24, "2 x (9..12) bytes");
+    const uint32_t lane = threadIdx.x & 63u;
+    uint8_t* strip = strips + (threadIdx.x >> 6) * (128 * M);
+    uint16_t* mine = reinterpret_cast<uint16_t*>(strip + lane * 2 * M);  // (2 M is even: 16-bit pieces)
+#pragma unroll
+    for (int j = 0; j < M / 2; ++j) {
+        mine[j] = (uint16_t)(m0.w[j >> 2] >> (16 * (j & 3)));
+        mine[M / 2 + j] = (uint16_t)(m1.w[j >> 2] >> (16 * (j & 3)));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+    uint8_t* dst = p.mol + (p0 - 2 * (int64_t)lane) * M;  // the wave's first pair: 128 M bytes from a multiple of 128 pairs -- 16-byte aligned
+    constexpr int pieces = 8 * M;                           // 64 lanes x 2M bytes / 16
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int piece = r * 64 + (int)lane;
+        if (piece < pieces) {
+            const v4u32 v = *reinterpret_cast<const v4u32*>(strip + 16 * piece);
+#if QD_FAST_WT_STORES
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + 16 * piece), "v"(v) : "memory");  // pad: 5.7
+#else
+            *reinterpret_cast<v4u32*>(dst + 16 * piece) = v;
+#endif
+        }
+    }
+    __builtin_amdgcn_wave_barrier();  // the strip is reused by the wave's next unit
+}
+
+template <int BLOCK_, class SH>
+struct RowsU2 {
+    typedef SH Shape;
+    static constexpr int BLOCK = BLOCK_, S1 = SH::STRIDE, MW = SH::MW1, M = SH::MOLW;
+    static constexpr bool PREFETCH = false;   // 128 B per lane per tile
+    static constexpr bool GUARD_LAST = true;  // the first two blocks of a lane pass its rows' end on the batch's last tile
+    static constexpr int RUNS = QD_FAST_RUNS;
+    struct Tile {
+        u64 s1[6], s2[6];  // full tiles: bytes [0, 32) of the lane's two rows, then bytes [2*S1 - 16, 2*S1); guarded tiles: bytes [0, 2*S1) in a row
+        u64 q1[2], q2[2];
+    };
+
+    template <bool FULL>
+    static __device__ __forceinline__ void load(Tile& T, const DemuxParams& p, int64_t base, uint32_t tid) {
+        const int64_t n = p.n, p0 = base + (int64_t)tid * 2;
+        if (!FULL && p0 >= n) return;
+        const uint8_t* a = p.seq[0] + p0 * S1;  // p0 even, S1 even: 4-byte aligned
+        const uint8_t* b = p.seq[1] + p0 * S1;
+        if (FULL) {
+            const U128 a0 = ld16u(a), a1 = ld16u(a + 16), a2 = ld16u(a + 2 * S1 - 16);
+            const U128 b0 = ld16u(b), b1 = ld16u(b + 16), b2 = ld16u(b + 2 * S1 - 16);
+            T.s1[0] = a0.lo; T.s1[1] = a0.hi; T.s1[2] = a1.lo; T.s1[3] = a1.hi; T.s1[4] = a2.lo; T.s1[5] = a2.hi;
+            T.s2[0] = b0.lo; T.s2[1] = b0.hi; T.s2[2] = b1.lo; T.s2[3] = b1.hi; T.s2[4] = b2.lo; T.s2[5] = b2.hi;
+        } else {
+            ld_exact(T.s1, a, (p0 + 1 < n ? 2 : 1) * S1);
+            ld_exact(T.s2, b, (p0 + 1 < n ? 2 : 1) * S1);
+        }
+        if (FULL || p0 + 1 < n) {
+            const U128 x = ld16s(p.qual[0] + p0 * 8), y = ld16s(p.qual[1] + p0 * 8);
+            T.q1[0] = x.lo; T.q1[1] = x.hi; T.q2[0] = y.lo; T.q2[1] = y.hi;
+        } else {  // the batch's last, odd pair: never read past row n-1
+            T.q1[0] = ld8(p.qual[0] + p0 * 8); T.q2[0] = ld8(p.qual[1] + p0 * 8);
+            T.q1[1] = T.q2[1] = 0;
+        }
+    }
+
+    template <bool FULL, int TAG>
+    static __device__ __forceinline__ uint32_t compute(const Tile& T, const DemuxParams& p, const LdsTable& t, int64_t base, uint32_t tid,
+                                                       const CodeOut& co) {
+        asm volatile("; demux tile copy %0" ::"i"(TAG));
+        const int64_t n = p.n, p0 = base + (int64_t)tid * 2;
+        if (!FULL && p0 >= n) return 0;
+        const bool two = FULL || (p0 + 1 < n);
+        const u64 h1[4] = {T.s1[0], T.s1[1], T.s1[2], T.s1[3]}, t1[2] = {T.s1[4], T.s1[5]};
+        const u64 h2[4] = {T.s2[0], T.s2[1], T.s2[2], T.s2[3]}, t2[2] = {T.s2[4], T.s2[5]};
+        Mol3 mol[2] = {{{0, 0, 0}}, {{0, 0, 0}}};
+        uint32_t c[2] = {0, 0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !two) break;
+            // a1 + a2: the barcodes at the rows' starts, the molecular indexes behind them (raw case; Quade.py:217-218 / :246-247)
+            const u64 k1 = take8(h1, h * S1), k2 = take8(h2, h * S1);
+            u64 alo, ahi, blo, bhi;
+            if (h == 0) {
+                alo = take8(h1, 8), ahi = take8(h1, 16);
+                blo = take8(h2, 8), bhi = take8(h2, 16);
+            } else if (FULL) {  // row 1's molecular index lies in the end-aligned block, at byte (S1 + 8) - (2 * S1 - 16)
+                alo = take8(t1, 24 - S1), ahi = take8(t1, 32 - S1);
+                blo = take8(t2, 24 - S1), bhi = take8(t2, 32 - S1);
+            } else {
+                alo = take8(T.s1, S1 + 8), ahi = take8(T.s1, S1 + 16);
+                blo = take8(T.s2, S1 + 8), bhi = take8(T.s2, S1 + 16);
+            }
+            mol[h] = fuse_mol3<MW>(alo, ahi, blo, bhi);
+            u64 d0, d1;
+            c[h] = match_pair<true, false>(p, t, k1, k2, 0, 0, T.q1[h], T.q2[h], d0, d1);
+        }
+        const uint32_t undet = (c[0] == QD_CODE_UNDET) + (two && c[1] == QD_CODE_UNDET);
+        if (FULL && p.mol_strip_off) {
+            store_codes_full<RUNS>(p, co, p0, c[0] | (c[1] << 16));
+            store_mol_wave3<M>(p, t.strips, p0, mol[0], mol[1]);
+        } else {
+            store_unit3(p, p0, two, c[0], c[1], mol[0], mol[1]);
+        }
+        return undet;
+    }
+};
+
 #if QD_FAST_MINWAVES
 #define QD_FAST_BOUNDS __launch_bounds__(OPS::BLOCK, QD_FAST_MINWAVES)
 #else
@@ -1259,6 +1433,11 @@ hipError_t launch_fast_b(const DemuxParams& p, QdKernelCache& cache, int cus, in
     if (StaticUmi1<10>::matches(p)) return launch_fast_t<RowsU<BLOCK, StaticUmi1<10>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
     if (StaticUmi1<11>::matches(p)) return launch_fast_t<RowsU<BLOCK, StaticUmi1<11>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
     if (StaticUmi1<12>::matches(p)) return launch_fast_t<RowsU<BLOCK, StaticUmi1<12>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+    // ... and behind the barcodes of BOTH index reads (the same width: 18 .. 24 bytes of molecular index per pair)
+    if (StaticUmi2<9>::matches(p)) return launch_fast_t<RowsU2<BLOCK, StaticUmi2<9>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+    if (StaticUmi2<10>::matches(p)) return launch_fast_t<RowsU2<BLOCK, StaticUmi2<10>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+    if (StaticUmi2<11>::matches(p)) return launch_fast_t<RowsU2<BLOCK, StaticUmi2<11>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
+    if (StaticUmi2<12>::matches(p)) return launch_fast_t<RowsU2<BLOCK, StaticUmi2<12>>>(p, cache, cus, wg_per_cu, table_lds, lds_bytes, st);
 #endif
     if (p.seq_stride[0] > 16 || p.seq_stride[1] > 16) return hipErrorInvalidValue;  // (the host sends such plans here only for the shapes above)
     const bool all8 = p.seq_stride[0] == 8 && p.qual_stride[0] == 8 &&

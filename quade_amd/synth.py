@@ -44,12 +44,19 @@ CONFIGS = {
     # index read 2 is its 8-base barcode
     "kit8u9": dict(dual=True, S=96, read_len=17, mol=True, min_qual=25, pairs=60_000_000, iw=8, mol1_only=True),
     "kit8u12": dict(dual=True, S=96, read_len=20, mol=True, min_qual=25, pairs=60_000_000, iw=8, mol1_only=True),
+    # the molecular index behind the barcode of BOTH index reads (UMI-carrying i7 and i5 adapters): rows of 18 / 20 bytes in both streams,
+    # 18 .. 24 molecular bytes per pair (r05: StaticUmi2)
+    "kit8u9x2": dict(dual=True, S=96, read_len=17, mol=True, min_qual=25, pairs=60_000_000, iw=8),
+    "kit8u10x2": dict(dual=True, S=96, read_len=18, mol=True, min_qual=25, pairs=60_000_000, iw=8),
+    "kit8u11x2": dict(dual=True, S=96, read_len=19, mol=True, min_qual=25, pairs=60_000_000, iw=8),
+    "kit8u12x2": dict(dual=True, S=96, read_len=20, mol=True, min_qual=25, pairs=60_000_000, iw=8),
 }
 # algorithmic bytes per pair (SURVEY.md 8d / BASELINE.md section 3): barcode + molecular bases and barcode qualities
 # read, code and molecular bytes written
 ALGO_BYTES = {"cfg2": 18, "cfg3": 34, "cfg4": 58, "cfg5": 34, "wide10": 42,
               "kit6": 26, "kit8u8": 66, "kit12": 50, "kit10u6": 66,
-              "kit8u9": 52, "kit8u12": 58}  # 8 + u bases and 8 qualities of index read 1, 8 + 8 of index read 2, 2 + u bytes out
+              "kit8u9": 52, "kit8u12": 58,
+              "kit8u9x2": 70, "kit8u10x2": 74, "kit8u11x2": 78, "kit8u12x2": 82}  # 2 x (8 + u bases + 8 qualities) in, 2 + 2u bytes out  # 8 + u bases and 8 qualities of index read 1, 8 + 8 of index read 2, 2 + u bytes out
 
 
 def config_plan(name):
