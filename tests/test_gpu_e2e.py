@@ -183,6 +183,11 @@ SCENARIOS = {
     "dual_10bp_wide_fast": dict(dual=True, idx_len=12, pos=((1, 10), (1, 10), None, None), minq=25),
     "dual_10bp_umi_truncated": dict(dual=True, idx_len=16, pos=((1, 10), (2, 11), None, (12, 16)), minq=20, trunc=True,
                                     gpu="[gpu]\nbatch_pairs : 64\n"),
+    # a molecular index of 11 bases behind the barcode of BOTH index reads (rows of 20 bytes in both streams, 22 molecular bytes per
+    # pair: the fast kernel's RowsU2 shape, r05), whole reads and truncated ones (the listed exceptions redone by the fixup kernel)
+    "dual_umi_in_both_reads": dict(dual=True, idx_len=19, pos=((1, 8), (1, 8), (9, 19), (9, 19)), minq=25),
+    "dual_umi_in_both_reads_truncated": dict(dual=True, idx_len=17, pos=((1, 8), (1, 8), (9, 17), (9, 17)), minq=20, trunc=True,
+                                             gpu="[gpu]\nbatch_pairs : 64\n"),
     "wide_window_generic": dict(dual=False, idx_len=24, pos=((1, 20), None, (21, 24), None), minq=10),
     # truncated reads on a plan the fast kernel does not take: the generic kernel needs every read's length
     "wide_window_truncated": dict(dual=False, idx_len=24, pos=((1, 20), None, (21, 24), None), minq=10, trunc=True,
