@@ -352,7 +352,8 @@ def kernel_config_rate(cfg_name, n, steps, warm, local_rank):
     import torch
     from quade_amd import synth
     from quade_amd.hip_backend import Engine
-    w = synth.generate(cfg_name, n, seed=20260000 + int(cfg_name[3:]), device="cuda", barcode_seed=20260000 + int(cfg_name[3:]))
+    seed = 20260000 + (int(cfg_name[3:]) if cfg_name[3:].isdigit() else 9)
+    w = synth.generate(cfg_name, n, seed=seed, device="cuda", barcode_seed=seed)
     torch.cuda.synchronize()
     cfg = synth.CONFIGS[cfg_name]
     with Engine(local_rank) as eng:
@@ -843,6 +844,13 @@ def main():
                 continue
             try:
                 kc[name] = kernel_config_rate(name, per_gpu_default[name], max(1, args.config_steps), 30, local_rank)
+            except Exception as e:
+                kc[name] = {"error": repr(e)}
+        # ... and on two kit layouts outside BASELINE.json's configs (not part of the metric): a molecular index behind the
+        # barcode of index read 1 / of both index reads, each on its static shape of the fast kernel
+        for name in ("kit8u9", "kit8u12x2"):
+            try:
+                kc[name] = kernel_config_rate(name, 60_000_000, max(1, args.config_steps), 30, local_rank)
             except Exception as e:
                 kc[name] = {"error": repr(e)}
         extra["kernel_configs"] = kc

@@ -67,7 +67,8 @@ def test_single_gpu_line():
     assert sm1["pipeline"]["gzip_members"] == 4 and sm1["pipeline"]["gzip_fallbacks"] == 0 and sm1["pipeline"]["text_segments"] == 0, sm1["pipeline"]
     # the kernel on the other BASELINE configs, verified, in the same line
     kc = j["extra"]["kernel_configs"]
-    assert sorted(kc) == ["cfg2", "cfg4", "cfg5"]
+    assert sorted(kc) == ["cfg2", "cfg4", "cfg5", "kit8u12x2", "kit8u9"]  # (the kits: on their static shapes of the fast kernel)
+    assert kc["kit8u12x2"]["kernel"] == "demux_fast" and kc["kit8u9"]["kernel"] == "demux_fast"
     for name, k in kc.items():
         assert k["verified"] is True and k["kernel_ms"] > 0 and 0 < k["frac"] < 1, (name, k)
         assert abs(k["frac"] - k["pairs"] * k["algorithmic_bytes_per_pair"] / (k["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9
