@@ -1276,6 +1276,12 @@ hipError_t qd_gz::decode(qd_gz_step* steps, int n, hipStream_t st, int slots_per
     return hipSuccess;
 }
 
+// QUADE_GZ_RESOLVE=1024: gz_resolve<1024, 4096> (one workgroup per CU, windows of 4 096 symbols) instead of <512, 2048> (two per CU) -- A/B
+static bool resolve_wide() {
+    static const bool wide = env_int("QUADE_GZ_RESOLVE", 512) == 1024;
+    return wide;
+}
+
 hipError_t qd_gz::resolve(qd_gz_step* steps, int n, uint8_t* const* out, hipStream_t st) {
     qd_gz_impl& G = *p_;
     // Text per unit (one resolving workgroup, two of them per CU: 512 in flight).  Given (a test, a measurement): as given.  Else the
@@ -1286,8 +1292,9 @@ hipError_t qd_gz::resolve(qd_gz_step* steps, int n, uint8_t* const* out, hipStre
         uint64_t total = 0;
         for (int i = 0; i < n; ++i)
             if (!steps[i].failed) total += steps[i].text_len;
-        const uint64_t rounds = std::max<uint64_t>(1, (total + UNIT_TEXT * 508 - 1) / (UNIT_TEXT * 508));
-        UNIT_TEXT = std::max<uint64_t>(256u << 10, total / (rounds * 508) + 1);
+        const uint64_t per_round = resolve_wide() ? 254 : 508;  // (workgroups in flight: one of 1 024 lanes per CU, or two of 512)
+        const uint64_t rounds = std::max<uint64_t>(1, (total + UNIT_TEXT * per_round - 1) / (UNIT_TEXT * per_round));
+        UNIT_TEXT = std::max<uint64_t>(256u << 10, total / (rounds * per_round) + 1);
     }
     // units of ~1 MB of text: runs of accepted stretches; chains: a stream's units in order
     G.gzunits_.clear();
@@ -1387,11 +1394,19 @@ hipError_t qd_gz::resolve(qd_gz_step* steps, int n, uint8_t* const* out, hipStre
     GZCHK(stage(G.d_uoff.p, unit_out_off.data(), nr * 8));
     GZCHK(stage(G.d_floor.p, unit_floor.data(), nr * 4));
     GZCHK(hipMemsetAsync(G.d_ustat.p, 0, nr * 4 * 2, st));
-    constexpr int RNT = 512, RQ = 2048;
-    const size_t lds = sizeof(GzLds<RNT, RQ>);
-    GZCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gz_resolve<RNT, RQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((gz_resolve<RNT, RQ>), dim3((uint32_t)nr), dim3(RNT), lds, st, G.d_gzunits.as<GzUnit>(), (uint32_t)nr, G.d_units.as<qd3::Unit>(), G.d_res.as<qd3::Result>(),
-                       G.d_use.as<uint32_t>(), G.d_tokens.as<uint16_t>(), G.d_sym.as<uint16_t>(), G.d_wout.as<uint16_t>(), G.d_ustat.as<int32_t>());
+    if (resolve_wide()) {
+        constexpr int RNT = 1024, RQ = 4096;
+        const size_t lds = sizeof(GzLds<RNT, RQ>);
+        GZCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gz_resolve<RNT, RQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((gz_resolve<RNT, RQ>), dim3((uint32_t)nr), dim3(RNT), lds, st, G.d_gzunits.as<GzUnit>(), (uint32_t)nr, G.d_units.as<qd3::Unit>(), G.d_res.as<qd3::Result>(),
+                           G.d_use.as<uint32_t>(), G.d_tokens.as<uint16_t>(), G.d_sym.as<uint16_t>(), G.d_wout.as<uint16_t>(), G.d_ustat.as<int32_t>());
+    } else {
+        constexpr int RNT = 512, RQ = 2048;
+        const size_t lds = sizeof(GzLds<RNT, RQ>);
+        GZCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gz_resolve<RNT, RQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((gz_resolve<RNT, RQ>), dim3((uint32_t)nr), dim3(RNT), lds, st, G.d_gzunits.as<GzUnit>(), (uint32_t)nr, G.d_units.as<qd3::Unit>(), G.d_res.as<qd3::Result>(),
+                           G.d_use.as<uint32_t>(), G.d_tokens.as<uint16_t>(), G.d_sym.as<uint16_t>(), G.d_wout.as<uint16_t>(), G.d_ustat.as<int32_t>());
+    }
     GZCHK(hipGetLastError());
     hipLaunchKernelGGL(gz_windows, dim3((uint32_t)chains.size()), dim3(1024), 0, st, G.d_chains.as<GzChain>(), G.d_gzunits.as<GzUnit>(), G.d_wout.as<uint16_t>(), G.d_winin.p,
                        G.d_cstat.as<int32_t>());

@@ -645,6 +645,18 @@ struct qd_pipe {
     // (profiles/r04_ab_inflate_streams.txt) -- two 150 KB workgroups do not fit a CU, and blocks of two launches competing for
     // the CUs run longer than they save at the tails.  So the default is 1: down the compute stream, one after the other.
     hipStream_t is[2] = {nullptr, nullptr};
+    // Option "coder_stream" (default 0; r05, measured and not kept as the default): the tail of a batch -- the coder's launches, the
+    // pieces' CRC-32s, the members and their packing -- on a stream of its own behind the batch's format kernel, so that the scans,
+    // the row packer, the demultiplexer and the sort of batch k + 1 do not queue behind the coder of batch k.  The tail's tables
+    // (sub-blocks, ranges, CRCs, tokens) exist once: the compute stream waits for the tail of batch k before it uploads those of
+    // batch k + 1.  It overlaps as designed (profiles/r05_e2e_bgzf_timeline_coder_stream.txt: the coder on a queue of its own beside
+    // the whole token launch) and the job is no faster (profiles/r05_coder_stream_ab.txt: 34.5 / 29.8 against 31.2 / 30.8 M pairs/s;
+    // single members 24.5 / 24.8 against 24.4 / 25.3): the token launch stretches from 23 to 30-34 ms beside the coder -- the
+    // device is busy either way, the batch's time is the sum of its kernels' work.
+    hipStream_t es = nullptr;
+    hipEvent_t formatted = nullptr, coded = nullptr;
+    bool coded_pending = false;
+    int coder_stream = 0;
     hipEvent_t tables_up = nullptr;  // the launch's block tables are on the device (recorded on cs)
     int n_is = QD_PIPE_INFLATE_STREAMS, next_is = 0;
     DevBuf matches_b;                // the second stream's match lists
@@ -1907,6 +1919,10 @@ int process_batch(qd_pipe* p, uint32_t n, qd_sink* sink, int64_t batch_index) {
     PCHK(p, o.member_len.need((size_t)n_pieces * 4, 0, p->cs));
     PCHK(p, o.member_off.need((size_t)(n_pieces + 1) * 8, 0, p->cs));
     PCHK(p, o.packed.need((size_t)n_pieces * (size_t)out_stride, 0, p->cs));
+    // (the tail of the batch before still reads the sub-block tables and the coder's scratch: the uploads below wait for it)
+    const hipStream_t ts = p->coder_stream ? p->es : p->cs;  // the tail's stream
+    if (p->coded_pending && ts != p->cs) PCHK(p, hipStreamWaitEvent(p->cs, p->coded, 0));
+    p->coded_pending = false;
     PCHK(p, p->stage.upload(p->base1.p, base1.data(), (size_t)nd * 8, p->cs));
     PCHK(p, p->stage.upload(p->base2.p, base2.data(), (size_t)nd * 8, p->cs));
     PCHK(p, p->stage.upload(o.pieces.p, bo.pieces.data(), (size_t)n_pieces * sizeof(qd_deflate_piece), p->cs));
@@ -1931,6 +1947,10 @@ int process_batch(qd_pipe* p, uint32_t n, qd_sink* sink, int64_t batch_index) {
     fa.out1 = o.text.p;
     fa.out2 = o.text.p;
     PCHK(p, qd_text_format(p->plan, S, si.write_pass, si.write_fail, si.write_undet, n, fa, p->cs));
+    if (ts != p->cs) {  // the tail starts when the text is formatted (and the tables above are up)
+        PCHK(p, hipEventRecord(p->formatted, p->cs));
+        PCHK(p, hipStreamWaitEvent(ts, p->formatted, 0));
+    }
     static_assert(sizeof(qd_deflate_piece) == 16 && offsetof(qd_deflate_piece, crc32) == 12, "the combined CRCs land in the piece table");
     uint32_t* piece_crc = reinterpret_cast<uint32_t*>(o.pieces.p) + 3;
     if (si.level == 1) {
@@ -1941,18 +1961,22 @@ int process_batch(qd_pipe* p, uint32_t n, qd_sink* sink, int64_t batch_index) {
         // the sub-blocks' CRC-32s come out of the coder (taken while a sub-block's text is staged), the pieces' are combined from them
         for (uint32_t at = 0; at < n_subs; at += slice)
             PCHK(p, qd_launch_lz_subblocks(o.text.p, p->subs.as<qd_lz_sub>() + at, std::min(slice, n_subs - at), p->tokens.as<uint32_t>(), p->sub_out.p + (size_t)at * sub_stride,
-                                           sub_stride, p->sub_bytes.as<uint32_t>() + at, p->crc.as<uint32_t>() + at, p->cs));
-        PCHK(p, qd_text_crc32_combine(p->ranges.as<qd_crc_range>(), p->crc.as<uint32_t>(), p->first_sub.as<uint32_t>(), n_pieces, piece_crc, 4, p->cs));
+                                           sub_stride, p->sub_bytes.as<uint32_t>() + at, p->crc.as<uint32_t>() + at, ts));
+        PCHK(p, qd_text_crc32_combine(p->ranges.as<qd_crc_range>(), p->crc.as<uint32_t>(), p->first_sub.as<uint32_t>(), n_pieces, piece_crc, 4, ts));
         PCHK(p, qd_launch_lz_members(o.pieces.as<qd_deflate_piece>(), n_pieces, p->subs.as<qd_lz_sub>(), p->first_sub.as<uint32_t>(), n_subs, p->sub_out.p, sub_stride,
-                                     p->sub_bytes.as<uint32_t>(), o.members.p, out_stride, o.member_len.as<uint32_t>(), p->cs));
+                                     p->sub_bytes.as<uint32_t>(), o.members.p, out_stride, o.member_len.as<uint32_t>(), ts));
     } else {
-        PCHK(p, qd_text_crc32(o.text.p, p->ranges.as<qd_crc_range>(), n_subs, p->crc.as<uint32_t>(), p->cs));
-        PCHK(p, qd_text_crc32_combine(p->ranges.as<qd_crc_range>(), p->crc.as<uint32_t>(), p->first_sub.as<uint32_t>(), n_pieces, piece_crc, 4, p->cs));
-        PCHK(p, qd_launch_huffman(o.text.p, o.pieces.as<qd_deflate_piece>(), n_pieces, o.members.p, out_stride, o.member_len.as<uint32_t>(), p->cs));
+        PCHK(p, qd_text_crc32(o.text.p, p->ranges.as<qd_crc_range>(), n_subs, p->crc.as<uint32_t>(), ts));
+        PCHK(p, qd_text_crc32_combine(p->ranges.as<qd_crc_range>(), p->crc.as<uint32_t>(), p->first_sub.as<uint32_t>(), n_pieces, piece_crc, 4, ts));
+        PCHK(p, qd_launch_huffman(o.text.p, o.pieces.as<qd_deflate_piece>(), n_pieces, o.members.p, out_stride, o.member_len.as<uint32_t>(), ts));
     }
-    PCHK(p, qd_text_pack_members(o.members.p, out_stride, o.member_len.as<uint32_t>(), n_pieces, o.member_off.as<uint64_t>(), o.packed.p, p->cs));
+    PCHK(p, qd_text_pack_members(o.members.p, out_stride, o.member_len.as<uint32_t>(), n_pieces, o.member_off.as<uint64_t>(), o.packed.p, ts));
     PCHK(p, hipEventCreateWithFlags(&bo.done, hipEventDisableTiming));
-    PCHK(p, hipEventRecord(bo.done, p->cs));
+    PCHK(p, hipEventRecord(bo.done, ts));
+    if (ts != p->cs) {
+        PCHK(p, hipEventRecord(p->coded, ts));
+        p->coded_pending = true;
+    }
     to_collector(p, std::move(bo));
     return QD_OK;
 }
@@ -2383,10 +2407,13 @@ int qd_pipe_create(qd_ctx* ctx, qd_pipe** out) {
     if (const char* e = getenv("QUADE_PIPE_INFLATE_FORM")) p->inflate_form = atoi(e) == 2 ? 2 : 3;  // (measurement: A/B of the inflaters inside the pipeline)
     if (const char* e = getenv("QUADE_PIPE_DEVICE_GUNZIP")) p->device_gunzip = atoi(e) ? 1 : 0;
     if (const char* e = getenv("QUADE_PIPE_INFLATE_OVERLAP")) p->inflate_overlap = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("QUADE_PIPE_CODER_STREAM")) p->coder_stream = atoi(e) ? 1 : 0;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&p->cs, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&p->ds, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&p->is[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p->is[1], hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&p->tables_up, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&p->tables_up, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&p->es, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->formatted, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->coded, hipEventDisableTiming) != hipSuccess)
         return pfail(nullptr, QD_ERR_HIP, "stream creation failed");
     for (int i = 0; i < 2; ++i)
         if (hipEventCreateWithFlags(&p->out[i].done, hipEventDisableTiming) != hipSuccess) return pfail(nullptr, QD_ERR_HIP, "event creation failed");
@@ -2408,6 +2435,7 @@ int qd_pipe_set_option(qd_pipe* p, const char* name, int64_t value) {
     else if (n == "inflate_form" && (value == 2 || value == 3)) p->inflate_form = (int)value;
     else if (n == "device_gunzip" && (value == 0 || value == 1)) p->device_gunzip = (int)value;
     else if (n == "inflate_overlap" && (value == 0 || value == 1)) p->inflate_overlap = (int)value;
+    else if (n == "coder_stream" && (value == 0 || value == 1)) p->coder_stream = (int)value;
     else return pfail(p, QD_ERR_INVALID, "unknown option " + n);
     return QD_OK;
 }
@@ -2483,6 +2511,8 @@ int qd_pipe_run(qd_pipe* p, const qd_pipe_chunk* chunks, int32_t n_chunks, qd_pi
     }
     p->collector.join();
     (void)hipStreamSynchronize(p->cs);
+    if (p->es) (void)hipStreamSynchronize(p->es);
+    p->coded_pending = false;
     for (auto& f : feeders) f->stop();
     {
         std::lock_guard<std::mutex> g(p->cm);
@@ -2553,6 +2583,9 @@ int qd_pipe_destroy(qd_pipe* p) {
     }
     if (p->sync_ev) (void)hipEventDestroy(p->sync_ev);
     if (p->tables_up) (void)hipEventDestroy(p->tables_up);
+    if (p->formatted) (void)hipEventDestroy(p->formatted);
+    if (p->coded) (void)hipEventDestroy(p->coded);
+    if (p->es) (void)hipStreamDestroy(p->es);
     for (hipStream_t st : p->is)
         if (st) (void)hipStreamDestroy(st);
     if (p->cs) (void)hipStreamDestroy(p->cs);
