@@ -42,15 +42,20 @@ static_assert((CfgA::LANE_DW * 64 + CfgA::RING_DW) * 4 * 2 <= 160 * 1024, "two w
 // redo: only the units whose result says "table space" (the launch before this one, of a smaller configuration, gave them up) --
 // by a small grid whose waves walk all groups of 64 units (a launch as wide as the first would spend a millisecond placing
 // workgroups of 78 KB that find nothing to do).
-template <class C>
-__global__ __launch_bounds__(64) void inflate3_tokens(const qd3::Unit* units, const qd_inflate3_job* jobs, uint32_t n_units, uint16_t* tokens, uint32_t* lens_scratch,
-                                                      qd3::Result* res, uint32_t wait_rounds, uint32_t redo) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds3[];
-    const uint32_t lane = threadIdx.x;
+// WPB waves per workgroup: independent of each other (nothing here is a workgroup barrier), each with its own slice of the
+// workgroup's LDS -- a workgroup of four places four waves on ONE CU (one per SIMD) instead of wherever the dispatcher finds
+// room, which leaves whole CUs to the kernels of the other streams (the coder's workgroups need ~90 KB: a CU that holds two
+// token waves has no room for one).
+template <class C, int WPB>
+__global__ __launch_bounds__(64 * WPB) void inflate3_tokens(const qd3::Unit* units, const qd_inflate3_job* jobs, uint32_t n_units, uint16_t* tokens, uint32_t* lens_scratch,
+                                                            qd3::Result* res, uint32_t wait_rounds, uint32_t redo) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform: the ring's LDS-DMA base goes through M0)
+    uint32_t* const lds3 = lds_all + wave * (uint32_t)(C::LANE_DW * 64 + C::RING_DW);
     uint32_t* const ring = lds3;  // the wave's input ring first (16-byte aligned slots), the lanes' tables behind it
     uint16_t* const tab = reinterpret_cast<uint16_t*>(lds3 + C::RING_DW + lane * (uint32_t)C::LANE_DW);
 #pragma unroll 1
-  for (uint32_t group = blockIdx.x; 64u * group < n_units; group += gridDim.x) {
+  for (uint32_t group = blockIdx.x * (uint32_t)WPB + wave; 64u * group < n_units; group += gridDim.x * (uint32_t)WPB) {
     const uint32_t u = 64u * group + lane;
     bool mine = u < n_units;
     if (redo) {
@@ -851,15 +856,16 @@ __global__ void inflate3_jobs_from_blocks(const uint8_t* comp, uint8_t* out, con
     jobs[i] = j;
 }
 
-template <class C>
+template <class C, int WPB>
 hipError_t launch_tokens_of(const qd3::Unit* units, const qd_inflate3_job* jobs, uint32_t n_units, uint16_t* tokens, uint32_t* lens, qd3::Result* res, uint32_t redo, hipStream_t st) {
     static const int wait_turns = env_int("QUADE_INFLATE3_WAIT", 256);
-    const size_t lds = ((size_t)C::LANE_DW * 64 + C::RING_DW) * 4;
+    static_assert((C::LANE_DW * 64 + C::RING_DW) % 4 == 0, "every wave's slice of the workgroup's LDS starts 16-byte aligned (the ring's LDS-DMA slots)");
+    const size_t lds = ((size_t)C::LANE_DW * 64 + C::RING_DW) * 4 * WPB;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(inflate3_tokens<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(inflate3_tokens<C, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const uint32_t groups = (n_units + 63) / 64;
-    hipLaunchKernelGGL(inflate3_tokens<C>, dim3(redo ? std::min<uint32_t>(groups, 128u) : groups), dim3(64), lds, st, units, jobs, n_units, tokens, lens, res,
+    const uint32_t groups = (n_units + 63) / 64, blocks = (groups + WPB - 1) / WPB;
+    hipLaunchKernelGGL((inflate3_tokens<C, WPB>), dim3(redo ? std::min<uint32_t>(blocks, 128u) : blocks), dim3(64 * WPB), lds, st, units, jobs, n_units, tokens, lens, res,
                        (uint32_t)((wait_turns + C::ROUND_TURNS - 1) / C::ROUND_TURNS), redo);
     return hipGetLastError();
 }
@@ -870,9 +876,11 @@ hipError_t launch_tokens(const qd3::Unit* units, const qd_inflate3_job* jobs, ui
         const char* v = getenv("QUADE_INFLATE3_CFG");
         return v && (*v == 'a' || *v == 'A');
     }();
-    if (large_only) return launch_tokens_of<CfgA>(units, jobs, n_units, tokens, lens, res, 0, st);
-    const hipError_t e = launch_tokens_of<CfgS>(units, jobs, n_units, tokens, lens, res, 0, st);
-    return e != hipSuccess ? e : launch_tokens_of<CfgA>(units, jobs, n_units, tokens, lens, res, 1, st);
+    if (large_only) return launch_tokens_of<CfgA, 1>(units, jobs, n_units, tokens, lens, res, 0, st);
+    static const int wpb = env_int("QUADE_INFLATE3_WPB", 4);  // (A/B: 1 = a workgroup per wave, as the first form)
+    const hipError_t e = wpb == 1 ? launch_tokens_of<CfgS, 1>(units, jobs, n_units, tokens, lens, res, 0, st)
+                                  : launch_tokens_of<CfgS, 4>(units, jobs, n_units, tokens, lens, res, 0, st);
+    return e != hipSuccess ? e : launch_tokens_of<CfgA, 1>(units, jobs, n_units, tokens, lens, res, 1, st);
 }
 
 template <int NT, int Q>
