@@ -450,8 +450,9 @@ int qd_dev_gunzip(int device_id, const uint8_t* gz, int64_t gz_len, uint8_t* out
  * No counterpart in the reference (its buffers are Python objects).  The large device buffers of a pipeline -- windows, token slots,
  * upload rings -- go to a per-device free list of the process when the pipeline is destroyed, and the next pipeline is served from
  * it: hipMalloc of ~25 GB takes between 50 ms and over a second on this pool's boxes, which a process that runs several jobs pays
- * once.  The list holds at most QUADE_POOL_GB gigabytes (environment; default 64, 0 = no list).  qd_pool_trim gives everything on
- * the list back to the driver (memory in use by live objects is not touched); always QD_OK. */
+ * once.  The list holds at most QUADE_POOL_GB gigabytes (environment; default 64, 0 = no list); page-locked host buffers (the
+ * feeders' read buffers, the collector's slabs) have a list of their own (QUADE_POOL_PINNED_GB, default 4).  qd_pool_trim gives
+ * everything on both lists back to the driver (memory in use by live objects is not touched); always QD_OK. */
 int qd_pool_trim(void);
 
 /* ---- device-resident chunk pipeline (ABI v5) ---------------------------------------------------------------------

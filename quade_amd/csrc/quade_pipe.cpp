@@ -22,6 +22,7 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
@@ -115,21 +116,19 @@ struct DevBuf {  // grow-only device allocation
     T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-struct PinBuf {  // grow-only page-locked host allocation
+struct PinBuf {  // grow-only page-locked host allocation (quade_pool.h: from what an earlier pipeline of this process released)
     uint8_t* p = nullptr;
     size_t cap = 0;
     hipError_t need(size_t n) {
         if (n <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
+        if (p) qd_pool_put_pinned(p, cap);
         p = nullptr;
         cap = 0;
         const size_t want = n + n / 4 + 4096;
-        const hipError_t e = hipHostMalloc((void**)&p, want, hipHostMallocDefault);
-        if (e == hipSuccess) cap = want;
-        return e;
+        return qd_pool_get_pinned(want, (void**)&p, &cap);
     }
     void release() {
-        if (p) (void)hipHostFree(p);
+        if (p) qd_pool_put_pinned(p, cap);
         p = nullptr;
         cap = 0;
     }
@@ -236,7 +235,7 @@ class Feeder {
             ready_[i] = consumed_[i] = nullptr;
         }
         for (int i = 0; i < PIN_SLOTS; ++i) {
-            if (pin_[i]) (void)hipHostFree(pin_[i]);
+            if (pin_[i]) qd_pool_put_pinned(pin_[i], pin_cap_[i]);
             pin_[i] = nullptr;
         }
         if (ring_) qd_pool_put(ring_, ring_cap_);
@@ -291,7 +290,7 @@ class Feeder {
     uint8_t* take_pin() {
         const int j = pin_next_;
         pin_next_ = (pin_next_ + 1) % PIN_SLOTS;
-        if (!pin_[j] && hipHostMalloc((void**)&pin_[j], SEG_BYTES + 65536, hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (!pin_[j] && qd_pool_get_pinned(SEG_BYTES + 65536, (void**)&pin_[j], &pin_cap_[j]) != hipSuccess) return nullptr;
         if (pin_slot_[j] >= 0 && wait_event_napping(ready_[pin_slot_[j]]) != hipSuccess) return nullptr;
         pin_slot_[j] = -1;
         pin_cur_ = j;
@@ -580,6 +579,7 @@ class Feeder {
     hipEvent_t ready_[RING_SLOTS] = {nullptr}, consumed_[RING_SLOTS] = {nullptr};
     int state_[RING_SLOTS] = {0};  // 0 free, 1 with the driver, 2 its last reader is queued (consumed_ tells when it has run)
     uint8_t* pin_[PIN_SLOTS] = {nullptr};
+    size_t pin_cap_[PIN_SLOTS] = {0};
     int pin_slot_[PIN_SLOTS] = {-1, -1, -1};  // the ring slot whose upload read this buffer last
     int pin_next_ = 0, pin_cur_ = 0, slot_next_ = 0;
     std::mutex m_;
@@ -657,6 +657,7 @@ struct qd_pipe {
     hipEvent_t formatted = nullptr, coded = nullptr;
     bool coded_pending = false;
     int coder_stream = 0;
+    int peek_records = 1;  // option "peek_records": size a run's buffers and first top-up from the heads of its first files (peek_record_bytes)
     hipEvent_t tables_up = nullptr;  // the launch's block tables are on the device (recorded on cs)
     int n_is = QD_PIPE_INFLATE_STREAMS, next_is = 0;
     DevBuf matches_b;                // the second stream's match lists
@@ -1198,21 +1199,32 @@ size_t gz_header_bytes(const uint8_t* h, size_t n) {
     return at <= n ? at : 0;
 }
 
+// the window's file is an ordinary gzip file that the device inflates: its state (idempotent)
+int gz_activate(qd_pipe* p, Window& w) {
+    Window::Gz& g = w.gz;
+    if (g.active) return QD_OK;
+    const double ratio = g.ratio;  // (a look at the file's head may have told: gz_close keeps nothing)
+    gz_close(w);
+    g.ratio = ratio;
+    g.active = true;
+    g.fd = open(w.path.c_str(), O_RDONLY | O_CLOEXEC);
+    struct stat sb;
+    if (g.fd < 0 || fstat(g.fd, &sb) != 0) return pfail(p, QD_ERR_FORMAT, w.path + ": " + strerror(errno));
+    g.file_size = (int64_t)sb.st_size;
+    PCHK(p, g.carried.need(32768, 0, p->cs));
+    if (!p->gz) {
+        p->gz = new qd_gz();
+        p->gz_units0 = 0;
+    }
+    return QD_OK;
+}
+
 // an upload of the file's bytes joins the stream's compressed buffer
 int gz_append(qd_pipe* p, Feeder& f, Window& w, Segment& s) {
     Window::Gz& g = w.gz;
-    if (!g.active) {
-        gz_close(w);
-        g.active = true;
-        g.fd = open(w.path.c_str(), O_RDONLY | O_CLOEXEC);
-        struct stat sb;
-        if (g.fd < 0 || fstat(g.fd, &sb) != 0) return pfail(p, QD_ERR_FORMAT, w.path + ": " + strerror(errno));
-        g.file_size = (int64_t)sb.st_size;
-        PCHK(p, g.carried.need(32768, 0, p->cs));
-        if (!p->gz) {
-            p->gz = new qd_gz();
-            p->gz_units0 = 0;
-        }
+    {
+        const int rc = gz_activate(p, w);
+        if (rc != QD_OK) return rc;
     }
     if ((uint64_t)s.file_off != g.comp_off + g.comp_len) return pfail(p, QD_ERR_STATE, w.path + ": uploads out of order");
     const hipStream_t gs = p->inflate_overlap ? p->is[0] : p->cs;  // (the gzip steps' stream: gz_steps)
@@ -1997,6 +2009,56 @@ int carry_window(qd_pipe* p, Window& w, uint32_t from_in) {
     return QD_OK;
 }
 
+// Bytes per fastq record at the head of a file (gzip of any framing, BGZF, or plain text): the first ~256 KB of its text, inflated by
+// zlib on the host.  0: could not tell (unreadable, damaged, fewer than two records) -- the run then learns the size from its first
+// small window, as it always did.  What the answer is used for: sizing the buffers and the first top-up of a run (r05: a run's first
+// batch used to cost two inflate launches -- a small one to learn the record size, then the batch's own -- and a token launch takes
+// ~20 ms whatever it holds).  An estimate only: a window that turns out short is topped up, a buffer that turns out small grows.
+struct Peek {
+    double record_bytes = 0;   // 0: could not tell
+    bool plain_gzip = false;   // gzip, and not BGZF at its start: what the feeder uploads as it is when the device inflates such files
+    double ratio = 0;          // text made per compressed byte read (plain gzip)
+};
+Peek peek_record_bytes(const char* path, int64_t start) {
+    Peek pk;
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return pk;
+    std::vector<uint8_t> in(192 << 10), out(384 << 10);
+    const ssize_t got = pread(fd, in.data(), in.size(), (off_t)std::max<int64_t>(start, 0));
+    close(fd);
+    if (got < 32) return pk;
+    const uint8_t* text = in.data();
+    size_t n_text = (size_t)got;
+    if (in[0] == 0x1f && in[1] == 0x8b) {
+        pk.plain_gzip = in[2] == 8 && !qdio::bgzf_block_size(in.data(), (size_t)got);  // (the feeder's test: Feeder::one_file)
+        z_stream z;
+        memset(&z, 0, sizeof z);
+        if (inflateInit2(&z, 15 + 32) != Z_OK) return pk;
+        z.next_in = in.data();
+        z.avail_in = (uInt)got;
+        z.next_out = out.data();
+        z.avail_out = (uInt)out.size();
+        for (;;) {
+            const int rc = inflate(&z, Z_NO_FLUSH);
+            if (rc == Z_STREAM_END && z.avail_in > 18 && z.avail_out > 0) {  // the next member (BGZF: one per 64 KiB)
+                if (inflateReset(&z) != Z_OK) break;
+                continue;
+            }
+            break;  // (out of input or of room, the end, or an error: what has been made so far is text either way)
+        }
+        n_text = out.size() - z.avail_out;
+        const size_t used = (size_t)got - z.avail_in;
+        if (used) pk.ratio = (double)n_text / (double)used;
+        inflateEnd(&z);
+        text = out.data();
+    }
+    size_t lines = 0, last4 = 0;
+    for (size_t i = 0; i < n_text; ++i)
+        if (text[i] == '\n' && (++lines & 3) == 0) last4 = i + 1;
+    if (lines >= 8) pk.record_bytes = (double)last4 / (double)(lines / 4);
+    return pk;
+}
+
 int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chunk, const qd_pipe_chunk& spec, int64_t* batch_index) {
     qd_sink* sink = spec.sink;
     const int ns = p->n_streams;
@@ -2022,8 +2084,34 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
         w.pending_text = 0;
         gz_close(w);
     }
+    if (!p->reserved && p->peek_records && !spec.skip_bytes[0] && !spec.skip_kept[0]) {
+        // the run's first chunk: what a record of every stream weighs, from the head of its file -- buffers and the first top-up
+        // are sized before anything is inflated on the device
+        double avg[4] = {0, 0, 0, 0};
+        Peek pk[4];
+        bool all = true;
+        for (int s = 0; s < ns; ++s) {
+            pk[s] = peek_record_bytes(p->win[s].path.c_str(), spec.start_offset[s]);
+            avg[s] = pk[s].record_bytes;
+            all = all && avg[s] >= 16.0;
+        }
+        if (all) {
+            for (int s = 0; s < ns; ++s) {
+                p->win[s].avg = avg[s];
+                if (pk[s].plain_gzip && p->device_gunzip) {  // the gzip kernels' buffers are sized with the rest (reserve_buffers)
+                    p->win[s].gz.ratio = std::min(64.0, std::max(1.0, pk[s].ratio));
+                    const int rc = gz_activate(p, p->win[s]);
+                    if (rc != QD_OK) return rc;
+                }
+            }
+            p->reserved = true;
+            const uint32_t most = (uint32_t)std::min<double>((double)B, (double)p->max_r1_bytes * (p->r1_compressed ? 8.0 : 1.0) / avg[0] + 1024.0);
+            const int rc = reserve_buffers(p, most, 2 * qdio::sink_info(sink).n_samples + 1);
+            if (rc != QD_OK) return rc;
+        }
+    }
     std::vector<size_t> want(ns, 1);  // first round: one upload, to learn the stream's bytes per record ...
-    if (p->reserved)                  // ... unless the chunks before have told (a small first top-up is an inflate launch of its own)
+    if (p->reserved)                  // ... unless the chunks before (or a look at the files' heads) have told (a small first top-up is an inflate launch of its own)
         for (int s = 0; s < ns; ++s)
             if (p->win[s].avg > 0) want[s] = std::min<size_t>((size_t)((double)B * p->win[s].avg * 1.03) + 4096, WINDOW_MAX * 3 / 4);
     static const bool trace = getenv("QUADE_PIPE_TRACE") != nullptr;  // (debugging: one line per turn of the loop)
@@ -2408,6 +2496,7 @@ int qd_pipe_create(qd_ctx* ctx, qd_pipe** out) {
     if (const char* e = getenv("QUADE_PIPE_DEVICE_GUNZIP")) p->device_gunzip = atoi(e) ? 1 : 0;
     if (const char* e = getenv("QUADE_PIPE_INFLATE_OVERLAP")) p->inflate_overlap = atoi(e) ? 1 : 0;
     if (const char* e = getenv("QUADE_PIPE_CODER_STREAM")) p->coder_stream = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("QUADE_PIPE_PEEK")) p->peek_records = atoi(e) ? 1 : 0;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&p->cs, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&p->ds, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->sync_ev, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&p->is[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p->is[1], hipStreamNonBlocking) != hipSuccess ||
@@ -2436,6 +2525,7 @@ int qd_pipe_set_option(qd_pipe* p, const char* name, int64_t value) {
     else if (n == "device_gunzip" && (value == 0 || value == 1)) p->device_gunzip = (int)value;
     else if (n == "inflate_overlap" && (value == 0 || value == 1)) p->inflate_overlap = (int)value;
     else if (n == "coder_stream" && (value == 0 || value == 1)) p->coder_stream = (int)value;
+    else if (n == "peek_records" && (value == 0 || value == 1)) p->peek_records = (int)value;
     else return pfail(p, QD_ERR_INVALID, "unknown option " + n);
     return QD_OK;
 }

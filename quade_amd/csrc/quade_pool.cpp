@@ -19,6 +19,20 @@ struct Pool {
         return gb <= 0 ? (size_t)0 : (size_t)(gb * 1073741824.0);
     }();
 };
+struct PinnedPool {
+    std::mutex m;
+    std::multimap<size_t, void*> free_;
+    size_t held = 0;
+    size_t limit = [] {
+        const char* e = getenv("QUADE_POOL_PINNED_GB");
+        const double gb = e && *e ? atof(e) : 4.0;
+        return gb <= 0 ? (size_t)0 : (size_t)(gb * 1073741824.0);
+    }();
+};
+PinnedPool& pinned() {
+    static PinnedPool* p = new PinnedPool();
+    return *p;
+}
 Pool& pool() {
     static Pool* p = new Pool();  // (never destroyed: the runtime may be gone before static destructors run)
     return *p;
@@ -75,7 +89,46 @@ void qd_pool_put(void* p, size_t cap) {
     (void)hipFree(p);
 }
 
+hipError_t qd_pool_get_pinned(size_t want, void** p, size_t* cap) {
+    PinnedPool& P = pinned();
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        auto it = P.free_.lower_bound(want);
+        if (it != P.free_.end() && it->first <= want + want / 2 + (1u << 20)) {
+            *p = it->second;
+            *cap = it->first;
+            P.held -= it->first;
+            P.free_.erase(it);
+            return hipSuccess;
+        }
+    }
+    const hipError_t e = hipHostMalloc(p, want, hipHostMallocDefault);
+    if (e == hipSuccess) *cap = want;
+    return e;
+}
+
+void qd_pool_put_pinned(void* p, size_t cap) {
+    if (!p) return;
+    PinnedPool& P = pinned();
+    if (cap >= (1u << 20)) {
+        std::lock_guard<std::mutex> g(P.m);
+        if (P.held + cap <= P.limit) {
+            P.free_.emplace(cap, p);
+            P.held += cap;
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+}
+
 extern "C" int qd_pool_trim(void) {
+    {
+        PinnedPool& H = pinned();
+        std::lock_guard<std::mutex> g(H.m);
+        for (auto& kv : H.free_) (void)hipHostFree(kv.second);
+        H.free_.clear();
+        H.held = 0;
+    }
     Pool& P = pool();
     std::lock_guard<std::mutex> g(P.m);
     int cur = 0;

@@ -14,3 +14,7 @@
 hipError_t qd_pool_get(size_t want, void** p, size_t* cap);
 // back to the list (or to the driver); the device is drained first -- nothing queued may still use it
 void qd_pool_put(void* p, size_t cap);
+// the same for page-locked host buffers (hipHostMalloc: the feeders' 16 MB read buffers, the collector's slabs -- pinning 200 MB
+// takes tens of milliseconds at the start of every run); the list holds at most QUADE_POOL_PINNED_GB gigabytes (default 4)
+hipError_t qd_pool_get_pinned(size_t want, void** p, size_t* cap);
+void qd_pool_put_pinned(void* p, size_t cap);

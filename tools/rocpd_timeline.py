@@ -32,3 +32,22 @@ for name, st, en, q in rows:
         continue
     name = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
     print("%10.3f %10.3f %8.3f %6s  %s" % (ms, (en - st) / 1e6, gap / 1e6, q, name))
+
+# device-busy fraction per run: kernels clustered by idle gaps of more than 100 ms (a tool's runs are that far apart), intervals merged
+clusters, cur = [], None
+for name, st, en, q in rows:
+    if cur is None or st - cur["end"] > 100e6:
+        cur = {"start": st, "end": en, "busy": 0, "last": st, "n": 0}
+        clusters.append(cur)
+    lo = max(st, cur["last"])
+    if en > lo:
+        cur["busy"] += en - lo
+        cur["last"] = en
+    cur["end"] = max(cur["end"], en)
+    cur["n"] += 1
+print()
+print("device busy per run (kernels at most 100 ms apart; copies by DMA engines are not kernels):")
+for c_ in clusters:
+    span = c_["end"] - c_["start"]
+    if c_["n"] >= 50 and span > 0:
+        print("  from %9.3f ms: %6d kernels over %8.3f ms, busy %8.3f ms = %.3f" % ((c_["start"] - t0) / 1e6, c_["n"], span / 1e6, c_["busy"] / 1e6, c_["busy"] / span))
