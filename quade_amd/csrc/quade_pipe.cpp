@@ -1016,7 +1016,7 @@ int flush_inflate3(qd_pipe* p) {
     if (p->q3_jobs.empty()) return QD_OK;
     const size_t n = p->q3_jobs.size();
     // Option "inflate_overlap" (default 1): the launches go down a stream of their own, so that the token kernel of batch k + 1 -- a
-    // latency, two waves per CU -- shares the device with what batch k still has queued on the compute stream (format, coder); the
+    // latency, a wave per SIMD at most -- shares the device with what batch k still has queued on the compute stream (format, coder); the
     // windows' scans wait for the event (join_inflate).  It reads the upload ring and writes the windows' text behind what the carry
     // copies (compute stream) move to their front: no overlap with anything queued there.
     const hipStream_t xs = p->inflate_overlap ? p->is[0] : p->cs;
