@@ -1538,7 +1538,7 @@ int drain_chunk(qd_pipe* p, Feeder& f, Window& w, int chunk) {
     return QD_OK;
 }
 
-int scan_window(qd_pipe* p, Window& w, int stream_index) {
+int scan_window(qd_pipe* p, Window& w, int stream_index, qd_scan_job* job = nullptr) {
     if (join_inflate(p, w) != QD_OK) return QD_ERR_HIP;
     const uint32_t n_tiles = w.len / QD_TEXT_TILE + 1;
     PCHK(p, w.tile_counts.need((size_t)(n_tiles + 2) * 4, 0, p->cs));
@@ -1563,10 +1563,43 @@ int scan_window(qd_pipe* p, Window& w, int stream_index) {
         const bool insert = stream_index < 2;
         const int k = stream_index - 2;
         const uint32_t need = insert ? 0u : (uint32_t)(p->lay.seq_off[k] + p->lay.seq_width[k]);
+        if (job) {  // the caller launches several windows' scans together (scan_windows)
+            *job = qd_scan_job{w.buf[w.cur].p, w.len, w.eof ? 1 : 0, insert ? 1 : 0, need, sc, p->d_res.as<qd_scan_result>() + stream_index};
+            return QD_OK;
+        }
         PCHK(p, qd_text_scan(w.buf[w.cur].p, w.len, w.eof ? 1 : 0, insert ? 1 : 0, need, sc, p->d_res.as<qd_scan_result>() + stream_index, p->cs));
         PCHK(p, hipMemcpyAsync(p->h_res.p + (size_t)stream_index * sizeof(qd_scan_result), p->d_res.p + (size_t)stream_index * sizeof(qd_scan_result),
                                sizeof(qd_scan_result), hipMemcpyDeviceToHost, p->cs));
     }
+    return QD_OK;
+}
+
+// the scans of the windows that changed, stage by stage for all of them (qd_text_scan_many); false: none was dirty
+int scan_windows(qd_pipe* p, bool* scanned) {
+    qd_scan_job jobs[4];
+    int which[4], n = 0;
+    for (int s = 0; s < p->n_streams; ++s) {
+        Window& w = p->win[s];
+        if (!w.dirty) continue;
+        const int rc = scan_window(p, w, s, &jobs[n]);
+        if (rc != QD_OK) return rc;
+        which[n++] = s;
+    }
+    *scanned = n > 0;
+    if (!n) return QD_OK;
+    static const bool one_by_one = [] {  // (A/B: QUADE_PIPE_SCAN_MANY=0 launches window by window, as before r05)
+        const char* e = getenv("QUADE_PIPE_SCAN_MANY");
+        return e && atoi(e) == 0;
+    }();
+    if (one_by_one) {
+        for (int k = 0; k < n; ++k)
+            PCHK(p, qd_text_scan(jobs[k].text, jobs[k].len, jobs[k].at_eof, jobs[k].want_names, jobs[k].need, jobs[k].s, jobs[k].result, p->cs));
+    } else {
+        PCHK(p, qd_text_scan_many(n, jobs, p->cs));
+    }
+    for (int k = 0; k < n; ++k)
+        PCHK(p, hipMemcpyAsync(p->h_res.p + (size_t)which[k] * sizeof(qd_scan_result), p->d_res.p + (size_t)which[k] * sizeof(qd_scan_result), sizeof(qd_scan_result),
+                               hipMemcpyDeviceToHost, p->cs));
     return QD_OK;
 }
 
@@ -2167,12 +2200,9 @@ int run_chunk(qd_pipe* p, std::vector<std::unique_ptr<Feeder>>& feeders, int chu
         }
         // 2. records of the windows that changed
         bool scanned = false;
-        for (int s = 0; s < ns; ++s) {
-            Window& w = p->win[s];
-            if (!w.dirty) continue;
-            const int rc = scan_window(p, w, s);
+        {
+            const int rc = scan_windows(p, &scanned);
             if (rc != QD_OK) return rc;
-            scanned = true;
         }
         if (scanned) {
             mark("scans queued");

@@ -55,6 +55,18 @@ struct qd_scan_scratch {
 hipError_t qd_text_scan(const uint8_t* text, uint32_t len, int at_eof, int want_names, uint32_t need, const qd_scan_scratch& s,
                         qd_scan_result* result, hipStream_t st);
 
+// ... of up to four windows at once (a batch's streams): same results; the stages of all windows back to back, the small serial kernels
+// once for all of them
+struct qd_scan_job {
+    const uint8_t* text;
+    uint32_t len;
+    int at_eof, want_names;
+    uint32_t need;
+    qd_scan_scratch s;
+    qd_scan_result* result;
+};
+hipError_t qd_text_scan_many(int n_windows, const qd_scan_job* jobs, hipStream_t st);
+
 // carry_start of every stream for a batch that consumes the first n[s] kept records of stream s: the head of kept record n[s], or
 // tail_start when the window holds no more kept records
 hipError_t qd_text_carry_info(const qd_rec* const recs[4], qd_scan_result* const results[4], int n_streams, const uint32_t n[4], hipStream_t st);

@@ -119,6 +119,58 @@ __global__ __launch_bounds__(1024) void scan_single(const uint32_t* in, uint32_t
     if (threadIdx.x == 0) out[n] = carry;
 }
 
+// the small serial kernels for several windows at once (qd_text_scan_many): workgroup w does window w's
+struct ScanMany {
+    const uint32_t* in[4];
+    uint32_t* out[4];
+    uint32_t n[4];
+};
+__global__ __launch_bounds__(1024) void scan_single_many(const ScanMany a) {
+    __shared__ uint32_t lds[16];
+    __shared__ uint32_t carry;
+    const uint32_t* in = a.in[blockIdx.x];
+    uint32_t* out = a.out[blockIdx.x];
+    const uint32_t n = a.n[blockIdx.x];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? in[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_scan_excl<16>(v, lds, &total);
+        const uint32_t c = carry;
+        if (i < n) out[i] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+struct DoneMany {
+    const uint32_t* a[4];      // lines_done: tile_base; recs_done: rec_tile
+    const uint32_t* lines[4];  // (recs_done)
+    uint32_t n[4];             // lines_done: n_tiles; recs_done: n_tiles_max
+    uint32_t cap[4];           // (lines_done: line_cap)
+    qd_scan_result* r[4];
+};
+__global__ void lines_done_many(const DoneMany d) {
+    const uint32_t w = threadIdx.x;
+    const uint32_t n = d.a[w][d.n[w]];
+    qd_scan_result* r = d.r[w];
+    r->n_lines = n;
+    r->n_records = n / 4;
+    r->overflow = n > d.cap[w] ? 1u : 0u;
+    r->n_short = 0;
+}
+__global__ void recs_done_many(const DoneMany d) {
+    const uint32_t w = threadIdx.x;
+    qd_scan_result* r = d.r[w];
+    const uint32_t n_rec = r->overflow ? 0u : r->n_records;
+    const uint32_t n_tiles = (n_rec + 1024u - 1) / 1024u;  // (REC_TILE)
+    r->n_kept = n_tiles <= d.n[w] ? d.a[w][n_tiles] : 0u;
+    r->tail_start = n_rec ? d.lines[w][4 * n_rec - 1] + 1 : 0u;
+}
+
 __global__ void lines_done(const uint32_t* tile_base, uint32_t n_tiles, uint32_t line_cap, qd_scan_result* r) {
     const uint32_t n = tile_base[n_tiles];
     r->n_lines = n;
@@ -768,6 +820,44 @@ hipError_t qd_text_scan(const uint8_t* text, uint32_t len, int at_eof, int want_
     } else {
         hipLaunchKernelGGL(recs_done, dim3(1), dim3(1), 0, st, s.rec_tile, 0u, s.lines, result);
     }
+    return hipGetLastError();
+}
+
+// The scans of several windows (a batch's four streams) stage by stage: the big kernels of all windows back to back, the small serial
+// ones -- a one-workgroup scan of the tile counts, a one-thread kernel that reads its total -- once for all windows with a workgroup
+// (a thread) per window.  Window by window they were 2 x 0.4 ms of one workgroup per large stream with the device idle beside it
+// (profiles/r05_e2e_bgzf_timeline.txt: ~8 ms of scans per batch of 2 M pairs).
+hipError_t qd_text_scan_many(int n_windows, const qd_scan_job* jobs, hipStream_t st) {
+    if (n_windows < 1 || n_windows > 4) return hipErrorInvalidValue;
+    static_assert(REC_TILE == 1024, "recs_done_many");
+    ScanMany sm{}, sr{};
+    DoneMany dl{}, dr{};
+    uint32_t n_tiles[4], rec_tiles[4];
+    bool any_rec = false;
+    for (int w = 0; w < n_windows; ++w) {
+        const qd_scan_job& j = jobs[w];
+        n_tiles[w] = j.len / TILE + 1;
+        rec_tiles[w] = (j.s.line_cap / 4 + REC_TILE - 1) / REC_TILE;
+        any_rec = any_rec || rec_tiles[w];
+        sm.in[w] = j.s.tile_counts, sm.out[w] = j.s.tile_base, sm.n[w] = n_tiles[w];
+        sr.in[w] = j.s.rec_tile, sr.out[w] = j.s.rec_tile, sr.n[w] = rec_tiles[w];
+        dl.a[w] = j.s.tile_base, dl.n[w] = n_tiles[w], dl.cap[w] = j.s.line_cap, dl.r[w] = j.result;
+        dr.a[w] = j.s.rec_tile, dr.lines[w] = j.s.lines, dr.n[w] = rec_tiles[w], dr.r[w] = j.result;
+    }
+    for (int w = 0; w < n_windows; ++w)
+        hipLaunchKernelGGL(line_count, dim3(n_tiles[w]), dim3(LINE_BLOCK), 0, st, jobs[w].text, jobs[w].len, jobs[w].at_eof, jobs[w].s.tile_counts);
+    hipLaunchKernelGGL(scan_single_many, dim3(n_windows), dim3(1024), 0, st, sm);
+    hipLaunchKernelGGL(lines_done_many, dim3(1), dim3(n_windows), 0, st, dl);
+    for (int w = 0; w < n_windows; ++w)
+        hipLaunchKernelGGL(line_write, dim3(n_tiles[w]), dim3(LINE_BLOCK), 0, st, jobs[w].text, jobs[w].len, jobs[w].at_eof, jobs[w].s.tile_base, jobs[w].s.lines, jobs[w].s.line_cap);
+    for (int w = 0; w < n_windows; ++w)
+        if (rec_tiles[w])
+            hipLaunchKernelGGL(rec_count, dim3(rec_tiles[w]), dim3(256), 0, st, jobs[w].text, jobs[w].s.lines, jobs[w].result, jobs[w].need, jobs[w].s.rec_tile, jobs[w].result);
+    if (any_rec) hipLaunchKernelGGL(scan_single_many, dim3(n_windows), dim3(1024), 0, st, sr);  // (a window without record tiles: n = 0, its total is rec_tile[0] = 0 ... written)
+    hipLaunchKernelGGL(recs_done_many, dim3(1), dim3(n_windows), 0, st, dr);
+    for (int w = 0; w < n_windows; ++w)
+        if (rec_tiles[w])
+            hipLaunchKernelGGL(rec_write, dim3(rec_tiles[w]), dim3(256), 0, st, jobs[w].text, jobs[w].s.lines, jobs[w].result, jobs[w].want_names, jobs[w].s.rec_tile, jobs[w].s.recs);
     return hipGetLastError();
 }
 
