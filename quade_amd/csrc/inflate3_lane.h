@@ -61,6 +61,7 @@ struct Cfg {
     static constexpr int DST_HW = DBYTE ? DST_N / 2 : DST_N;                  // 16-bit units the distance table takes
     static constexpr int LANE_DW = ((LIT_N + DST_HW + NLONG + 1) / 2) | 1;    // dwords of LDS per lane (odd)
     static constexpr int NL = 15 - LB, ND = 15 - DB;                          // code lengths behind the first level
+    static constexpr int NP = 15 - DB;  // ... of either code (DB <= LB): lengths DB + 1 .. 15, the two codes' limits and bases packed in pairs
     static constexpr int RING_CHUNKS = CHUNKS_;
     static constexpr int RING_DW = RING_CHUNKS * 256;  // dwords of a wave's ring: slot j = [256 j, 256 (j + 1)), lane l's chunk at + 4 l (what one LDS-DMA writes)
     // A turn moves at most one dword into buf and looks at the one behind it: when a round starts, at least 4 CHUNKS - 3 - TURNS
@@ -130,7 +131,11 @@ struct Lane {
     const uint64_t* cands;
     uint32_t n_cands;
     uint32_t* lens;  // LENS_DW dwords of scratch (global memory)
-    uint32_t lim_l[C::NL], bas_l[C::NL], lim_d[C::ND], bas_d[C::ND];
+    // Codes longer than the first level, the canonical way: entry j is for length DB + 1 + j -- the left-aligned upper limit of that
+    // length's codes (15 bits; 0: none) and the place of its first symbol among the long symbols minus its first code, 16 bits each,
+    // the literal/length code's in the low half, the distance code's in the high half: ONE chain of compares serves a turn whatever
+    // its lane decodes (two chains, one per code, ran on nearly every turn: some lane of 64 always holds the other kind).
+    uint32_t plim[C::NP], pbas[C::NP];
     uint32_t on, on0, on_end;   // next slot, first slot, end of the region in the launch's token buffer (a wave-uniform base: turn()'s `tok`)
     uint32_t text_len, pend, stored_left;
     uint32_t state, status, final_seen;
@@ -259,10 +264,12 @@ QD3_HD uint32_t dist_entry(uint32_t sym, uint32_t nbits) { return sym >= 30 ? E_
 // One Huffman code from n code lengths (nibbles in lens[]): first-level table t[2^XB], the longer codes' symbols appended to
 // lng[] from *long_used on, their limits / bases to lim[] / bas[].  0, or a QD_INFLATE_* code.
 template <class C, bool DIST>
-QD3_HD uint32_t build(const uint32_t* lens, uint32_t n, uint16_t* t, uint16_t* lng, uint32_t* lim, uint32_t* bas, uint32_t* long_used) {
+QD3_HD uint32_t build(const uint32_t* lens, uint32_t n, uint16_t* t, uint16_t* lng, uint32_t* plim, uint32_t* pbas, uint32_t* long_used) {
     constexpr int XB = DIST ? C::DB : C::LB;
     constexpr uint32_t N = 1u << XB;
     constexpr int NX = 15 - XB;
+    constexpr int J0 = XB - C::DB;           // the packed entry of length XB + 1
+    constexpr uint32_t HS = DIST ? 16u : 0u;  // this code's half of a packed entry
     Pk cnt{0, 0, 0, 0};
     for (uint32_t w = 0; 8u * w < n; ++w) {
         const uint32_t d = lens[w];
@@ -297,15 +304,18 @@ QD3_HD uint32_t build(const uint32_t* lens, uint32_t n, uint16_t* t, uint16_t* l
         for (uint32_t i = 0; i < N / 2; ++i) reinterpret_cast<uint32_t*>(t)[i] = E_NONE | (E_NONE << 16);
     }
 #pragma unroll
-    for (int k = 0; k < NX; ++k) lim[k] = bas[k] = 0;
+    for (int j = 0; j < C::NP; ++j) {  // (this code's halves: the shorter lengths of the literal/length code stay 0 -- never "below the limit")
+        plim[j] &= ~(0xFFFFu << HS);
+        pbas[j] &= ~(0xFFFFu << HS);
+    }
     if (total == 0) return 0;                                // no codes at all: every look-up fails (zlib: as long as none is used)
     if (left > 0 && maxl != 1) return QD_INFLATE_BAD_TABLE;  // incomplete: only a single one-bit code may be (zlib's rule)
     uint32_t loff = *long_used;
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
         const uint32_t l = (uint32_t)(XB + 1 + k), c = pk_get(cnt, l), f = pk_get(first, l);
-        lim[k] = (f + c) << (15u - l);
-        bas[k] = (loff - f) & 0xFFFFu;
+        plim[J0 + k] |= ((f + c) << (15u - l)) << HS;  // (<= 2^15)
+        pbas[J0 + k] |= ((loff - f) & 0xFFFFu) << HS;
         loff += c;
     }
     if (loff > (uint32_t)C::NLONG) return QD_INFLATE_TABLE_SPACE;
@@ -331,7 +341,7 @@ QD3_HD uint32_t build(const uint32_t* lens, uint32_t n, uint16_t* t, uint16_t* l
                 uint32_t at = 0;
 #pragma unroll
                 for (int k = 0; k < NX; ++k)
-                    if ((uint32_t)(XB + 1 + k) == l) at = (bas[k] + c) & 0xFFFFu;
+                    if ((uint32_t)(XB + 1 + k) == l) at = (((pbas[J0 + k] >> HS) & 0xFFFFu) + c) & 0xFFFFu;
                 if (at < (uint32_t)C::NLONG) lng[at] = (uint16_t)e;
             }
         }
@@ -482,8 +492,8 @@ QD3_HD void header(Lane<C>& L, uint16_t* tab, uint32_t* ring, uint32_t lane) {
         if (eob_len == 0) return fail(L, QD_INFLATE_BAD_TABLE);  // no end-of-block code
     }
     uint32_t long_used = 0;
-    uint32_t rc = build<C, false>(L.lens, nlit, lit, lng, L.lim_l, L.bas_l, &long_used);
-    if (!rc) rc = build<C, true>(L.lens + 36, ndist, dst, lng, L.lim_d, L.bas_d, &long_used);
+    uint32_t rc = build<C, false>(L.lens, nlit, lit, lng, L.plim, L.pbas, &long_used);
+    if (!rc) rc = build<C, true>(L.lens + 36, ndist, dst, lng, L.plim, L.pbas, &long_used);
     if (rc) return fail(L, rc);
     L.state = ST_LIT;
     refill(L, ring, lane);  // (a turn starts with at least 33 bits in hand)
@@ -512,15 +522,12 @@ QD3_HD void turn(Lane<C>& L, const uint16_t* tab, const uint32_t* ring, uint32_t
     }
     if ((e & 0x3Fu) == E_NONE) {  // a code longer than the first level, or none: the next 15 bits MSB first against the lengths' limits
         const uint32_t x = brev32(lo32) >> 17;
+        const uint32_t half = dist ? 16u : 0u;
         uint32_t at = 0xFFFFFFFFu;
-        if (dist) {
 #pragma unroll
-            for (int k = C::ND - 1; k >= 0; --k)  // (the limits rise with the length: the last one that holds is the shortest length)
-                if (x < L.lim_d[k]) at = (L.bas_d[k] + (x >> (14 - C::DB - k))) & 0xFFFFu;
-        } else {
-#pragma unroll
-            for (int k = C::NL - 1; k >= 0; --k)
-                if (x < L.lim_l[k]) at = (L.bas_l[k] + (x >> (14 - C::LB - k))) & 0xFFFFu;
+        for (int j = C::NP - 1; j >= 0; --j) {  // (the limits rise with the length: the last one that holds is the shortest length)
+            const uint32_t lim = (L.plim[j] >> half) & 0xFFFFu, bas = (L.pbas[j] >> half) & 0xFFFFu;
+            if (x < lim) at = (bas + (x >> (14 - C::DB - j))) & 0xFFFFu;
         }
         e = at < (uint32_t)C::NLONG ? tab[C::LIT_N + C::DST_HW + at] : E_NONE;
     }
@@ -595,9 +602,7 @@ QD3_HD void lane_init(Lane<C>& L, const Unit& u, uint32_t* lens) {
     L.blk_bit = u.bit_start;
     L.blk_slots = L.blk_text = 0;
 #pragma unroll
-    for (int k = 0; k < C::NL; ++k) L.lim_l[k] = L.bas_l[k] = 0;
-#pragma unroll
-    for (int k = 0; k < C::ND; ++k) L.lim_d[k] = L.bas_d[k] = 0;
+    for (int j = 0; j < C::NP; ++j) L.plim[j] = L.pbas[j] = 0;
     rd_init(L, u.bit_start);
     if (u.bit_start >= u.bit_end) {  // nothing to decode
         L.state = ST_DONE;
