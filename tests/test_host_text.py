@@ -50,3 +50,23 @@ def test_inflate3_lane_decoder_against_zlib(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unknown-pragmas", "-o", exe, os.path.join(ROOT, "tests", "native", "inflate3_lane_test.cpp"), "-lz"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-2000:]
+
+
+def test_the_gzip_probes_text_filter_names_exactly_the_bytes_text_does_not_hold():
+    """quade_inflate3.hip: gz_text_lengths_only refuses a block header whose literal code covers a byte that fastq text cannot hold.
+    The 256-bit set in the source must be everything but tab, newline, carriage return and 32 .. 126 -- a wrong bit would refuse
+    real blocks (slow: every such stream pays the second, plain probe) or let false headers through."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "quade_amd", "csrc", "quade_inflate3.hip")).read()
+    m = re.search(r"non_text\[4\]\s*=\s*\{([^}]*)\}", src)
+    assert m, "the filter's table moved"
+    words = []
+    for tok in m.group(1).split(","):
+        tok = tok.strip()
+        words.append(0xFFFFFFFFFFFFFFFF if tok == "~0ull" else int(tok.rstrip("ul"), 16))
+    assert len(words) == 4
+    in_set = {b for b in range(256) if (words[b >> 6] >> (b & 63)) & 1}
+    text = {9, 10, 13} | set(range(32, 127))
+    assert in_set == set(range(256)) - text
+    # every byte of a fastq record is text in this sense
+    assert all(b in text for b in b"@SIM:1:FC:12:34 1:N:0:ACGT\nACGTN\n+\nFF:,#IJ~!\r\n")
